@@ -1,0 +1,24 @@
+"""pytest configuration: markers + shared paths.
+
+`-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI symbol checks (no GPU compute).
+`-m gpu`      : parity tests proper; every one calls through the C-ABI (libnps.so) on cuda:0.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,168 @@
+"""Pins the CPU oracle (oracle/refcpu.c + oracle/refcpu.py) to the reference's own golden vectors.
+
+* 13 set1 cases       -- nimpress tests/test_set1.nim:36-190 (tol 1e-4 abs, NaN positions exact)
+* 87 stats KATs       -- nimpress tests/test_stats.nim:21-139 (rel 1e-5 / abs 1e-9)
+* PLINK cross-checks  -- tests/set1.plink190.result (pinned), set1.plink200.result (5 of 6; S3 is a
+                         known fixture inconsistency)
+* output text format  -- scores/*_nimpress_res.txt ("%.16g" + ".0")
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refcpu
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def set1(golden_dir):
+    score = refcpu.read_score_file(os.path.join(golden_dir, "set1.score"))
+    vcf = refcpu.read_vcf(os.path.join(golden_dir, "set1.vcf.gz"))
+    bed = refcpu.read_bed(os.path.join(golden_dir, "set1.bed"))
+    return score, vcf, bed
+
+
+def check_floats(x, target, tol=1e-4):
+    # tests/test_set1.nim:14-22
+    assert len(x) == len(target)
+    for xi, ti in zip(x, target):
+        t_nan = ti is None or (isinstance(ti, float) and math.isnan(ti))
+        assert t_nan == bool(np.isnan(xi)), (x, target)
+        if not t_nan:
+            assert abs(ti - xi) <= tol, (x, target)
+
+
+def test_set1_fixture_shape(set1):
+    score, vcf, bed = set1
+    assert vcf.samples == ["S1", "S2", "S3", "S4", "S5", "S6"]
+    assert len(vcf.records) == 7
+    assert score.offset == 0.123 and len(score.entries) == 6
+    assert [e.pos for e in score.entries] == [100, 150, 200, 300, 400, 500]
+    assert sorted(bed) == ["1", "2", "3"]
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_set1_case(golden_dir, set1, idx):
+    score, vcf, bed = set1
+    case = _load(golden_dir, "set1_cases.json")["cases"][idx]
+    scores, nloci, stats = refcpu.compute_polygenic_scores(
+        score, vcf, case["restrict_to_covered"], bed, case["imp_locus"], case["imp_missing"],
+        case["imp_sample"], case["maxmis"], case["mincs"], case["ignore_filter"])
+    check_floats(scores, case["expected"])
+
+
+def test_set1_plink190(golden_dir, set1):
+    # tests/test_set1.nim:180-190: offset 0.123 + PLINK 1.90 SCORE column
+    score, vcf, bed = set1
+    plink = [float(l.split()[5]) for l in
+             open(os.path.join(golden_dir, "set1.plink190.result")).read().splitlines()[1:]]
+    scores, nloci, _ = refcpu.compute_polygenic_scores(score, vcf, False, bed, "ignore", "ignore",
+                                                       "int_ps", 1.0, 0, True)
+    assert nloci == 5
+    check_floats(scores, [0.123 + p for p in plink])
+
+
+def test_set1_plink200_five_of_six(golden_dir, set1):
+    # tests/test_set1.nim:207-216 (commented out in the reference).  S3 differs by 0.018 because
+    # set1.plink.freq lists 0.95 for the ALT allele of 1:100 while set1.score gives it to REF.
+    score, vcf, bed = set1
+    plink = [float(l.split()[3]) for l in
+             open(os.path.join(golden_dir, "set1.plink200.result")).read().splitlines()[1:]]
+    scores, _, _ = refcpu.compute_polygenic_scores(score, vcf, False, bed, "ps", "ignore", "ps",
+                                                   1.0, 0, True)
+    d = np.abs((scores - 0.123) - np.array(plink))
+    assert (d < 1e-4).tolist() == [True, True, False, True, True, True]
+    assert abs(d[2] - 0.018) < 1e-9
+
+
+def test_set1_cli_defaults_derived(set1):
+    # derived: CLI defaults -> every row locus-imputed, all scores 0.1545
+    score, vcf, bed = set1
+    scores, nloci, stats = refcpu.compute_polygenic_scores(score, vcf, False, bed, "ps", "homref",
+                                                           "int_ps", 0.05, 100, False)
+    assert nloci == 6
+    assert np.allclose(scores, 0.1545, atol=1e-12)
+    # per-row tallies (nmissing, neffect) of the genotyped rows
+    got = [(int(s[1]), int(s[2])) for s in stats if s[4] in (0, 4)]
+    assert got == [(1, 7), (1, 2), (5, 0), (1, 7)]
+
+
+def test_set1_case13_trace(set1):
+    # SURVEY.md appendix B worked trace: internal imputation values per row
+    score, vcf, bed = set1
+    _, nloci, stats = refcpu.compute_polygenic_scores(score, vcf, False, bed, "ignore", "ignore",
+                                                      "int_ps", 1.0, 0, True)
+    assert nloci == 5
+    used = [s for s in stats if s[3]]
+    assert [(int(s[0]), int(s[1]), int(s[2])) for s in used] == [
+        (5, 1, 7), (3, 3, 3), (5, 1, 2), (1, 5, 0), (5, 1, 7)]
+    assert [s[3] for s in stats] == [1, 1, 0, 1, 1, 1]
+
+
+def test_stats_kats(golden_dir):
+    d = _load(golden_dir, "stats_kats.json")
+    fns = {"dbinom": refcpu.dbinom, "pbinom": refcpu.pbinom, "binom_test": refcpu.binom_test,
+           "betai": refcpu.betai}
+    n = 0
+    for k in d["kats"]:
+        val = fns[k["fn"]](*k["args"])
+        tgt = k["expected"]
+        if k["mode"] == "exact":
+            assert val == tgt, k
+        elif abs(tgt) < d["abs_tol"]:     # tests/test_stats.nim:10-17
+            assert abs(val - tgt) < d["abs_tol"], k
+        else:
+            assert abs((val - tgt) / tgt) < d["rel_tol"], (k, val)
+        n += 1
+    assert n == 87
+
+
+def test_output_format_pinned_by_reference_results(golden_dir):
+    # every value in the reference's bundled result files re-prints identically
+    rf = os.path.join(golden_dir, "result_format")
+    n = 0
+    for f in sorted(os.listdir(rf)):
+        for line in open(os.path.join(rf, f)).read().splitlines():
+            name, txt = line.split("\t")
+            assert refcpu.format_score(float(txt)) == txt, (f, line)
+            n += 1
+    assert n == 3528
+
+
+def test_raw_dosage_corner_cases():
+    # nimpress.nim:385-390 with hts-nim value(): half-missing -> NaN, pad skipped, phase ignored
+    L = refcpu.lib()
+    import ctypes as C
+    gts = np.array([2, 4,  5, 3,  0, 4,  4, 0,  4, -2147483647,  0, -2147483647,  4, 4], np.int32)
+    raw = np.empty(7)
+    L.ref_raw_dosages_gt(raw.ctypes.data_as(C.POINTER(C.c_double)),
+                         gts.ctypes.data_as(C.POINTER(C.c_int32)), 7, 2, 1)
+    assert raw[0] == 1 and raw[1] == 1 and np.isnan(raw[2]) and np.isnan(raw[3])
+    assert raw[4] == 1 and np.isnan(raw[5]) and raw[6] == 2
+
+
+def test_packed_matrix_path_equals_row_path():
+    rng = np.random.default_rng(5)
+    n, m = 37, 11
+    eaf = rng.uniform(0.05, 0.5, m)
+    miss = rng.uniform(0, 0.3, m)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    codes = refcpu.synth_rows(n, 0, m, 99, th, tm, tmi)
+    beta = rng.normal(0, 0.1, m)
+    kind = np.zeros(m, np.int32)
+    rie = (rng.uniform(size=m) < 0.3).astype(np.int32)
+    p = refcpu.make_params("ps", "homref", "int_ps", 0.2, 5)
+    s1, st1, nl1 = refcpu.score_packed(codes, n, kind, rie, beta, eaf, p, 0.5)
+    sc = refcpu.RefScorer(n, p)
+    for j in range(m):
+        sc.row_gt(refcpu.codes_to_gt(codes[j], n), 2, 1, bool(rie[j]), beta[j], eaf[j])
+    s2, nl2 = sc.finish(0.5)
+    assert nl1 == nl2
+    assert np.array_equal(s1, s2, equal_nan=True)
