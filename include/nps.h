@@ -1,0 +1,223 @@
+/*
+ * nps.h -- C-ABI of libnps.so, the MI355X (gfx950) polygenic-score engine.
+ *
+ * This is the drop-in boundary for the per-variant inner loop of nimpress
+ * (reference: mpinese/nimpress, src/nimpress.nim).  The reference has no FFI of its own; the
+ * seam cut here is the body of computePolygenicScores' row loop -- everything between "the
+ * host has located the VCF record and holds its raw FORMAT buffer" and "scores[i] updated":
+ *
+ *     getRawDosages          nimpress.nim:367-391   (GT decode -> per-sample dosage)
+ *     tallyAlleles           nimpress.nim:32-47
+ *     imputeLocusDosages     nimpress.nim:417-447
+ *     imputeSampleDosages    nimpress.nim:450-481
+ *     the maxmis decision    nimpress.nim:565-571
+ *     scores[i] += d*beta    nimpress.nim:639-641
+ *     /= 2*nloci, += offset  nimpress.nim:643-649
+ *
+ * Plain C types only; no exceptions cross the boundary.  Every call returns NPS_OK (0) or a
+ * negative nps_status; nps_last_error() returns a thread-local message for the last failure.
+ * There is NO CPU backend: without a usable HIP device every compute entry point fails with
+ * NPS_E_NODEVICE.  (The CPU restatement under oracle/ is test infrastructure and is never
+ * linked or loaded by this library.)
+ *
+ * Threading: a context / cohort is used by one host thread at a time (the reference is
+ * single-threaded and synchronous, nimpress.nim:634-641).  Pushes are asynchronous on the
+ * context's HIP stream; nps_flush / nps_finish synchronise.  Multi-GPU: one context per device
+ * (one process per GPU under torch.distributed / RCCL).
+ *
+ * Ownership: the caller owns every input buffer and may reuse it as soon as the call returns
+ * (the reference reuses `gts` / `dosages` per row, nimpress.nim:381,633).  Output buffers are
+ * caller-allocated.
+ */
+#ifndef NPS_H
+#define NPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPS_ABI_VERSION 1
+
+typedef enum nps_status {
+    NPS_OK = 0,
+    NPS_E_INVAL = -1,       /* bad argument (replaces the reference's doAssert aborts) */
+    NPS_E_NODEVICE = -2,    /* no HIP device / device index out of range */
+    NPS_E_HIP = -3,         /* a HIP runtime call failed */
+    NPS_E_NOMEM = -4,       /* host or device allocation failed */
+    NPS_E_STATE = -5,       /* call not valid in the current state */
+    NPS_E_UNSUPPORTED = -6, /* e.g. ploidy > 2 on the 2-bit path */
+    NPS_E_TIMEOUT = -7      /* an in-kernel bounded wait expired (fused kernel) */
+} nps_status;
+
+/* Enum values follow the declaration order of nimpress.nim:412-414, so a Nim caller can pass
+ * ord(imputeMethodLocus) etc. unchanged. */
+typedef enum nps_imp_locus {   /* ImputeMethodLocus   nimpress.nim:412 */
+    NPS_LOCUS_PS = 0, NPS_LOCUS_HOMREF = 1, NPS_LOCUS_FAIL = 2, NPS_LOCUS_IGNORE = 3
+} nps_imp_locus;
+typedef enum nps_imp_missing { /* ImputeMethodMissing nimpress.nim:413 */
+    NPS_MISSING_HOMREF = 0, NPS_MISSING_IGNORE = 1
+} nps_imp_missing;
+typedef enum nps_imp_sample {  /* ImputeMethodSample  nimpress.nim:414 */
+    NPS_SAMPLE_PS = 0, NPS_SAMPLE_HOMREF = 1, NPS_SAMPLE_FAIL = 2, NPS_SAMPLE_INT_PS = 3,
+    NPS_SAMPLE_INT_FAIL = 4
+} nps_imp_sample;
+
+/* What the host found for a score row before touching genotypes (getImputedDosages,
+ * nimpress.nim:526-558). */
+typedef enum nps_row_kind {
+    NPS_ROW_PRESENT = 0,   /* record found, FILTER ok: genotype data follows      :561      */
+    NPS_ROW_UNCOVERED = 1, /* --cov given and locus not covered                   :526-531  */
+    NPS_ROW_ABSENT = 2,    /* findVariant returned nil                            :536-551  */
+    NPS_ROW_FILTERED = 3   /* FILTER not in {".","PASS"} and not --ignorefilt     :553-558  */
+} nps_row_kind;
+
+/* Branch of getImputedDosages taken for a row (reported back so the host can emit the
+ * reference's warnings in order, nimpress.nim:527,554,567,575). */
+typedef enum nps_reason {
+    NPS_REASON_GENOTYPED = 0, NPS_REASON_UNCOVERED = 1, NPS_REASON_ABSENT = 2,
+    NPS_REASON_FILTERED = 3, NPS_REASON_MAXMIS = 4
+} nps_reason;
+
+/* The scalar arguments of computePolygenicScores that reach the inner loop
+ * (nimpress.nim:592-599; afMismatchPthresh only gates warnings and stays on the host). */
+typedef struct nps_params {
+    int32_t imp_locus;        /* nps_imp_locus   */
+    int32_t imp_missing;      /* nps_imp_missing */
+    int32_t imp_sample;       /* nps_imp_sample  */
+    int32_t reserved;         /* must be 0 */
+    double max_missing_rate;  /* --maxmis, compared as nmissing/N > rate (strict, double) :565 */
+    int64_t min_cs;           /* --mincs, compared as ngenotyped >= mincs in double      :471 */
+} nps_params;
+
+/* Per-row result, in push order.  For GT rows all three tallies are exact integers
+ * (tallyAlleles, nimpress.nim:32-47); for DS rows neffect is a float64 sum. */
+typedef struct nps_locus_stat {
+    uint64_t ngenotyped;
+    uint64_t nmissing;
+    double neffect;
+    int32_t used;    /* return value of getImputedDosages (nimpress.nim:484) */
+    int32_t reason;  /* nps_reason */
+} nps_locus_stat;
+
+/* One score row for the resident-cohort entry point (ScoreEntry fields that reach the loop,
+ * nimpress.nim:221-228, plus what the host found). */
+typedef struct nps_row_desc {
+    double beta;
+    double eaf;            /* may be NaN (makescore.R:533) */
+    int32_t kind;          /* nps_row_kind; PRESENT rows consume cohort rows in order */
+    int32_t ref_is_effect; /* scoreEntry.refseq == scoreEntry.easeq */
+} nps_row_desc;
+
+/* Device time per kernel class, measured with HIP events on the context's stream. */
+typedef struct nps_profile {
+    double ms_decode;      /* raw FORMAT -> packed codes (+tally) */
+    double ms_tally;       /* tally of packed rows */
+    double ms_params;      /* per-row LUT / decision kernel */
+    double ms_accumulate;  /* score accumulation (two-pass path) */
+    double ms_fused;       /* fused single-read tally+accumulate kernel */
+    double ms_reduce;      /* partial-score combine / finish */
+    uint64_t n_decode, n_tally, n_params, n_accumulate, n_fused, n_reduce; /* launches */
+} nps_profile;
+
+typedef struct nps_ctx nps_ctx;
+typedef struct nps_cohort nps_cohort;
+typedef struct nps_scoredef nps_scoredef;
+
+/* ---- library ------------------------------------------------------------------------- */
+int nps_abi_version(void);
+const char *nps_last_error(void);
+/* number of HIP devices visible (0 when there is none; never initialises a device) */
+int nps_device_count(void);
+
+/* ---- streaming scorer: one call per score row, in score-file order --------------------- */
+
+/* Replaces the set-up of computePolygenicScores (nimpress.nim:623-633): zeroed scores for
+ * n_samples, nloci = 0.  device = HIP device ordinal. */
+int nps_create(nps_ctx **out, int device, uint64_t n_samples, const nps_params *params);
+
+/* PRESENT row with FORMAT/GT.  `gts` is the buffer bcf_get_genotypes fills (what hts-nim's
+ * `genotypes(variant.format, gts)` iterates, nimpress.nim:381-384): n_samples*ploidy int32,
+ * allele a encoded (a+1)<<1|phased, missing allele 0, vector-end pad 0x80000001.
+ * eaidx: 0 = REF, k = ALT[k-1] (nimpress.nim:375-379).  Replaces getRawDosages ..
+ * `scores[i] += dosages[i]*beta` for this row (nimpress.nim:561-583, 639-641). */
+int nps_push_gt(nps_ctx *ctx, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
+                double beta, double eaf);
+
+/* PRESENT row with FORMAT/DS (build-defined extension, the reference decodes GT only):
+ * n_samples float32 ALT dosages, NaN = missing; ref_is_effect -> dosage = 2 - DS. */
+int nps_push_ds(nps_ctx *ctx, const float *ds, int ref_is_effect, double beta, double eaf);
+
+/* PRESENT row already in the device layout: ceil(n_samples/16) little-endian uint32, sample i
+ * in bits 2*(i%16).. of word i/16, code = effect-allele dosage 0/1/2, 3 = missing; padding
+ * bits zero.  `row` is a host pointer. */
+int nps_push_packed(nps_ctx *ctx, const uint32_t *row, int ref_is_effect, double beta, double eaf);
+
+/* Row without genotype data: kind = UNCOVERED / ABSENT / FILTERED.  Replaces the early
+ * returns of getImputedDosages (nimpress.nim:526-558). */
+int nps_push_locus(nps_ctx *ctx, int kind, int ref_is_effect, double beta, double eaf);
+
+/* Completes all pushed rows and copies out their nps_locus_stat in push order, starting after
+ * the rows a previous flush returned.  stats_out may be NULL (cap ignored) to only synchronise.
+ * *n_out = number of stats written. */
+int nps_flush(nps_ctx *ctx, nps_locus_stat *stats_out, size_t cap, size_t *n_out);
+
+/* nimpress.nim:643-649: scores[i] = sum/(2*nloci) + offset -> scores_out[n_samples];
+ * *nloci_out = rows for which getImputedDosages returned true.  nloci = 0 gives NaN (0/0) as in
+ * the reference.  The context can be reused after nps_reset. */
+int nps_finish(nps_ctx *ctx, double offset, double *scores_out, uint64_t *nloci_out);
+/* Same, but scores are written to a caller-allocated DEVICE buffer of n_samples doubles (e.g. a
+ * torch tensor handed to an RCCL all-gather): no PCIe round trip. */
+int nps_finish_device(nps_ctx *ctx, double offset, double *d_scores_out, uint64_t *nloci_out);
+int nps_reset(nps_ctx *ctx, const nps_params *params /* NULL = keep */);
+void nps_destroy(nps_ctx *ctx);
+
+/* ---- resident cohort: a packed genotype matrix kept in HBM ------------------------------ */
+#define NPS_FMT_GT2 0  /* 2-bit codes, 16 per uint32, variant-major / sample-minor */
+#define NPS_FMT_DS32 1 /* float32 dosages, NaN = missing, variant-major / sample-minor */
+
+int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
+                      int format);
+/* row stride in bytes of the device layout (rows are padded to 256 B) */
+uint64_t nps_cohort_row_stride(const nps_cohort *c);
+uint64_t nps_cohort_n_rows(const nps_cohort *c);
+/* copy rows [row0,row0+nrows) from host memory laid out with host_stride bytes per row */
+int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
+                      size_t host_stride);
+int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t nrows, void *host_rows,
+                        size_t host_stride);
+/* Fill rows on the device with the counter-based synthetic generator (DESIGN.md "Synthetic
+ * cohorts"): per-row uint32 thresholds, code(seed,row,sample) reproducible on the CPU. */
+int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
+                     const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss);
+void nps_cohort_destroy(nps_cohort *c);
+
+/* Score n_desc rows in order; PRESENT rows take cohort rows cohort_row0, cohort_row0+1, ...
+ * Equivalent to the matching sequence of nps_push_* calls, without host traffic.
+ * mode: NPS_MODE_AUTO picks the fused single-read kernel when the shape allows it. */
+#define NPS_MODE_AUTO 0
+#define NPS_MODE_TWOPASS 1 /* tally kernel, then accumulate kernel (reads the matrix twice) */
+#define NPS_MODE_FUSED 2   /* persistent fused kernel (reads the matrix once) */
+int nps_score_cohort(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
+                     const nps_row_desc *rows, uint64_t n_desc, int mode);
+
+/* A score definition (the rows of one .scores file, nimpress.nim:247-254, plus what the host
+ * found for each) kept on the device, so that re-scoring needs no host->device traffic. */
+int nps_scoredef_create(nps_scoredef **out, int device, const nps_row_desc *rows, uint64_t n_desc);
+uint64_t nps_scoredef_n_present(const nps_scoredef *d); /* rows that consume a cohort row */
+void nps_scoredef_destroy(nps_scoredef *d);
+int nps_score_cohort_def(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
+                         const nps_scoredef *def, int mode);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+int nps_profile_enable(nps_ctx *ctx, int on); /* record HIP events around every launch */
+int nps_profile_get(nps_ctx *ctx, nps_profile *out, int reset);
+/* the HIP stream (hipStream_t) the context launches on, for callers that add their own events */
+void *nps_stream(nps_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPS_H */

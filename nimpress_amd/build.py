@@ -1,0 +1,58 @@
+"""Build helpers: compile the HIP sources of this package for gfx950 into in-tree shared objects.
+
+hipcc cross-compiles without a GPU.  The .so files are git-ignored but travel with the working
+tree (gpurun snapshot), so the GPU box loads exactly what was built here.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from typing import List
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIBNPS = os.path.join(PKG_DIR, "libnps.so")
+
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+               # float64 score arithmetic must not be contracted into FMAs the reference lacks
+               "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libnps.so cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def libnps_sources() -> List[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target: str, deps: List[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_libnps(force: bool = False, verbose: bool = False) -> str:
+    srcs = libnps_sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "nps.h"))
+    if force or _stale(LIBNPS, deps):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIBNPS] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIBNPS
+
+
+def build_all(force: bool = False, verbose: bool = False) -> List[str]:
+    """Everything native in this package (currently libnps.so)."""
+    return [build_libnps(force=force, verbose=verbose)]
+
+
+if __name__ == "__main__":
+    print(build_all(force=True, verbose=True))

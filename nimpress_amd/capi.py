@@ -1,0 +1,311 @@
+"""ctypes binding of the libnps C-ABI (include/nps.h).
+
+This is plumbing for tests, bench.py and Python callers; the product is libnps.so.  There is no
+fallback: if libnps.so is missing or no MI355X is visible, calls raise ``NpsError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnps.so")
+
+# enums (nimpress.nim:412-414 declaration order)
+LOCUS = {"ps": 0, "homref": 1, "fail": 2, "ignore": 3}
+MISSING = {"homref": 0, "ignore": 1}
+SAMPLE = {"ps": 0, "homref": 1, "fail": 2, "int_ps": 3, "int_fail": 4}
+ROW_PRESENT, ROW_UNCOVERED, ROW_ABSENT, ROW_FILTERED = 0, 1, 2, 3
+REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMIS = range(5)
+FMT_GT2, FMT_DS32 = 0, 1
+MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
+
+NPS_OK = 0
+STATUS_NAMES = {0: "NPS_OK", -1: "NPS_E_INVAL", -2: "NPS_E_NODEVICE", -3: "NPS_E_HIP",
+                -4: "NPS_E_NOMEM", -5: "NPS_E_STATE", -6: "NPS_E_UNSUPPORTED", -7: "NPS_E_TIMEOUT"}
+
+
+class NpsParams(C.Structure):
+    _fields_ = [("imp_locus", C.c_int32), ("imp_missing", C.c_int32), ("imp_sample", C.c_int32),
+                ("reserved", C.c_int32), ("max_missing_rate", C.c_double), ("min_cs", C.c_int64)]
+
+
+class NpsProfile(C.Structure):
+    _fields_ = [("ms_decode", C.c_double), ("ms_tally", C.c_double), ("ms_params", C.c_double),
+                ("ms_accumulate", C.c_double), ("ms_fused", C.c_double), ("ms_reduce", C.c_double),
+                ("n_decode", C.c_uint64), ("n_tally", C.c_uint64), ("n_params", C.c_uint64),
+                ("n_accumulate", C.c_uint64), ("n_fused", C.c_uint64), ("n_reduce", C.c_uint64)]
+
+
+STAT_DTYPE = np.dtype([("ngenotyped", "<u8"), ("nmissing", "<u8"), ("neffect", "<f8"),
+                       ("used", "<i4"), ("reason", "<i4")])
+ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
+                           ("ref_is_effect", "<i4")])
+
+# every symbol include/nps.h declares (tests/test_capi_symbols.py checks the two lists agree)
+SYMBOLS = [
+    "nps_abi_version", "nps_last_error", "nps_device_count", "nps_create", "nps_push_gt",
+    "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
+    "nps_finish_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
+    "nps_scoredef_destroy", "nps_score_cohort_def",
+    "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
+    "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_destroy",
+    "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream",
+]
+
+
+class NpsError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, str(status)), msg))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """dlopen libnps.so (raises if it has not been built -- there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NpsError(-2, "libnps.so not built (%s); run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` -- the HIP library is the only compute path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, dbl = C.c_void_p, C.c_uint64, C.c_int, C.c_double
+    L.nps_abi_version.restype = C.c_int
+    L.nps_last_error.restype = C.c_char_p
+    L.nps_device_count.restype = C.c_int
+    L.nps_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams)]
+    L.nps_push_gt.argtypes = [vp, vp, i32, i32, i32, dbl, dbl]
+    L.nps_push_ds.argtypes = [vp, vp, i32, dbl, dbl]
+    L.nps_push_packed.argtypes = [vp, vp, i32, dbl, dbl]
+    L.nps_push_locus.argtypes = [vp, i32, i32, dbl, dbl]
+    L.nps_flush.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.nps_finish.argtypes = [vp, dbl, vp, C.POINTER(u64)]
+    L.nps_finish_device.argtypes = [vp, dbl, vp, C.POINTER(u64)]
+    L.nps_scoredef_create.argtypes = [C.POINTER(vp), i32, vp, u64]
+    L.nps_scoredef_n_present.argtypes = [vp]
+    L.nps_scoredef_n_present.restype = u64
+    L.nps_scoredef_destroy.argtypes = [vp]
+    L.nps_scoredef_destroy.restype = None
+    L.nps_score_cohort_def.argtypes = [vp, vp, u64, vp, i32]
+    L.nps_reset.argtypes = [vp, C.POINTER(NpsParams)]
+    L.nps_destroy.argtypes = [vp]
+    L.nps_destroy.restype = None
+    L.nps_cohort_create.argtypes = [C.POINTER(vp), i32, u64, u64, i32]
+    L.nps_cohort_row_stride.argtypes = [vp]
+    L.nps_cohort_row_stride.restype = u64
+    L.nps_cohort_n_rows.argtypes = [vp]
+    L.nps_cohort_n_rows.restype = u64
+    L.nps_cohort_upload.argtypes = [vp, u64, u64, vp, C.c_size_t]
+    L.nps_cohort_download.argtypes = [vp, u64, u64, vp, C.c_size_t]
+    L.nps_cohort_synth.argtypes = [vp, u64, u64, u64, vp, vp, vp]
+    L.nps_cohort_destroy.argtypes = [vp]
+    L.nps_cohort_destroy.restype = None
+    L.nps_score_cohort.argtypes = [vp, vp, u64, vp, u64, i32]
+    L.nps_profile_enable.argtypes = [vp, i32]
+    L.nps_profile_get.argtypes = [vp, C.POINTER(NpsProfile), i32]
+    L.nps_stream.argtypes = [vp]
+    L.nps_stream.restype = vp
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != NPS_OK:
+        raise NpsError(rc, load().nps_last_error().decode("utf-8", "replace"))
+
+
+def make_params(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05,
+                mincs=100) -> NpsParams:
+    """Defaults are the CLI defaults, nimpress.nim:670-684."""
+    return NpsParams(LOCUS[imp_locus], MISSING[imp_missing], SAMPLE[imp_sample], 0, float(maxmis),
+                     int(mincs))
+
+
+def device_count() -> int:
+    return load().nps_device_count()
+
+
+class Cohort:
+    """A genotype matrix resident in HBM (2-bit codes, variant-major / sample-minor)."""
+
+    def __init__(self, n_samples: int, n_rows: int, device: int = 0, fmt: int = FMT_GT2):
+        self._h = C.c_void_p()
+        self.n_samples, self.n_rows, self.device, self.fmt = int(n_samples), int(n_rows), device, fmt
+        _check(load().nps_cohort_create(C.byref(self._h), device, self.n_samples, self.n_rows, fmt))
+
+    @property
+    def row_stride(self) -> int:
+        return int(load().nps_cohort_row_stride(self._h))
+
+    def upload(self, row0: int, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows)
+        assert rows.ndim == 2
+        _check(load().nps_cohort_upload(self._h, row0, rows.shape[0], rows.ctypes.data,
+                                        rows.strides[0]))
+
+    def download(self, row0: int, nrows: int) -> np.ndarray:
+        width = (self.n_samples + 15) // 16
+        out = np.zeros((nrows, max(width, 1)), dtype=np.uint32)
+        _check(load().nps_cohort_download(self._h, row0, nrows, out.ctypes.data, out.strides[0]))
+        return out[:, :width]
+
+    def synth(self, row0: int, seed: int, t_het, t_hom, t_miss):
+        th, tm, tmi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (t_het, t_hom, t_miss))
+        assert th.size == tm.size == tmi.size
+        _check(load().nps_cohort_synth(self._h, row0, th.size, seed, th.ctypes.data, tm.ctypes.data,
+                                       tmi.ctypes.data))
+
+    def close(self):
+        if self._h:
+            load().nps_cohort_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ScoreDef:
+    """The rows of one score file (+ what the host found for each), resident on the device."""
+
+    def __init__(self, rows: np.ndarray, device: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DESC_DTYPE)
+        self._h = C.c_void_p()
+        self.n_desc = rows.size
+        _check(load().nps_scoredef_create(C.byref(self._h), device, rows.ctypes.data, rows.size))
+
+    @property
+    def n_present(self) -> int:
+        return int(load().nps_scoredef_n_present(self._h))
+
+    def close(self):
+        if self._h:
+            load().nps_scoredef_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scorer:
+    """computePolygenicScores (nimpress.nim:592-649) with the row loop on the GPU."""
+
+    def __init__(self, n_samples: int, params: NpsParams, device: int = 0):
+        self._h = C.c_void_p()
+        self.n = int(n_samples)
+        self.device = device
+        _check(load().nps_create(C.byref(self._h), device, self.n, C.byref(params)))
+
+    # -- one call per score row, in score-file order
+    def push_gt(self, gts: np.ndarray, ploidy: int, eaidx: int, ref_is_effect, beta: float, eaf: float):
+        gts = np.ascontiguousarray(gts, dtype=np.int32)
+        if gts.size != self.n * ploidy:
+            raise ValueError("gts has %d values, expected %d" % (gts.size, self.n * ploidy))
+        _check(load().nps_push_gt(self._h, gts.ctypes.data, ploidy, eaidx, int(bool(ref_is_effect)),
+                                  float(beta), float(eaf)))
+
+    def push_ds(self, ds: np.ndarray, ref_is_effect, beta: float, eaf: float):
+        ds = np.ascontiguousarray(ds, dtype=np.float32)
+        if ds.size != self.n:
+            raise ValueError("ds has %d values, expected %d" % (ds.size, self.n))
+        _check(load().nps_push_ds(self._h, ds.ctypes.data, int(bool(ref_is_effect)), float(beta),
+                                  float(eaf)))
+
+    def push_packed(self, row: np.ndarray, ref_is_effect, beta: float, eaf: float):
+        row = np.ascontiguousarray(row, dtype=np.uint32)
+        if row.size < (self.n + 15) // 16:
+            raise ValueError("packed row too short")
+        _check(load().nps_push_packed(self._h, row.ctypes.data, int(bool(ref_is_effect)),
+                                      float(beta), float(eaf)))
+
+    def push_locus(self, kind: int, ref_is_effect, beta: float, eaf: float):
+        _check(load().nps_push_locus(self._h, kind, int(bool(ref_is_effect)), float(beta), float(eaf)))
+
+    def score_cohort(self, cohort: Cohort, rows: np.ndarray, cohort_row0: int = 0,
+                     mode: int = MODE_AUTO):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DESC_DTYPE)
+        _check(load().nps_score_cohort(self._h, cohort._h, cohort_row0, rows.ctypes.data, rows.size,
+                                       mode))
+
+    def score_cohort_def(self, cohort: Cohort, sdef: ScoreDef, cohort_row0: int = 0,
+                         mode: int = MODE_AUTO):
+        _check(load().nps_score_cohort_def(self._h, cohort._h, cohort_row0, sdef._h, mode))
+
+    def finish_device(self, offset: float, d_scores_ptr: int) -> int:
+        """scores -> caller-allocated device buffer (n_samples float64); returns nloci."""
+        nloci = C.c_uint64(0)
+        _check(load().nps_finish_device(self._h, float(offset), C.c_void_p(d_scores_ptr),
+                                        C.byref(nloci)))
+        return int(nloci.value)
+
+    def flush(self, max_rows: Optional[int] = None) -> np.ndarray:
+        """Completes pushed rows; returns their stats (structured array, push order)."""
+        out = []
+        while True:
+            cap = 65536 if max_rows is None else max_rows
+            buf = np.zeros(cap, dtype=STAT_DTYPE)
+            n = C.c_size_t(0)
+            _check(load().nps_flush(self._h, buf.ctypes.data, cap, C.byref(n)))
+            out.append(buf[: n.value])
+            if n.value < cap or max_rows is not None:
+                break
+        return np.concatenate(out) if out else np.zeros(0, dtype=STAT_DTYPE)
+
+    def sync(self):
+        n = C.c_size_t(0)
+        _check(load().nps_flush(self._h, None, 0, C.byref(n)))
+
+    def finish(self, offset: float) -> Tuple[np.ndarray, int]:
+        scores = np.empty(max(self.n, 1), dtype=np.float64)
+        nloci = C.c_uint64(0)
+        _check(load().nps_finish(self._h, float(offset), scores.ctypes.data, C.byref(nloci)))
+        return scores[: self.n], int(nloci.value)
+
+    def reset(self, params: Optional[NpsParams] = None):
+        _check(load().nps_reset(self._h, C.byref(params) if params is not None else None))
+
+    def profile_enable(self, on: bool = True):
+        _check(load().nps_profile_enable(self._h, int(on)))
+
+    def profile_get(self, reset: bool = False) -> NpsProfile:
+        p = NpsProfile()
+        _check(load().nps_profile_get(self._h, C.byref(p), int(reset)))
+        return p
+
+    @property
+    def stream(self) -> int:
+        return int(load().nps_stream(self._h) or 0)
+
+    def close(self):
+        if self._h:
+            load().nps_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def row_descs(beta, eaf, kind=None, ref_is_effect=None) -> np.ndarray:
+    beta = np.asarray(beta, dtype=np.float64)
+    out = np.zeros(beta.size, dtype=ROW_DESC_DTYPE)
+    out["beta"] = beta
+    out["eaf"] = np.asarray(eaf, dtype=np.float64)
+    if kind is not None:
+        out["kind"] = np.asarray(kind, dtype=np.int32)
+    if ref_is_effect is not None:
+        out["ref_is_effect"] = np.asarray(ref_is_effect, dtype=np.int32)
+    return out

@@ -1,0 +1,886 @@
+// nps_engine.hip -- implementation of the C-ABI declared in include/nps.h.
+//
+// Host-side orchestration only: staging, batching, launches, bookkeeping of per-row stats.  All
+// per-sample arithmetic happens in nps_kernels.hip (and nps_fused.hip).  There is no CPU compute
+// path here: if HIP is unusable every entry point that would compute returns NPS_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nps_kernels.h"
+
+using namespace nps;
+
+// ------------------------------------------------------------------------------------------
+// errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP, "%s failed: %s",  \
+                        #expr, hipGetErrorString(_e));                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+enum ProfClass { P_DECODE = 0, P_TALLY, P_PARAMS, P_ACCUM, P_FUSED, P_REDUCE, P_COUNT };
+
+struct ProfSpan {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct nps_cohort {
+    int device = 0;
+    int format = NPS_FMT_GT2;
+    uint64_t n_samples = 0, n_rows = 0;
+    uint64_t stride_bytes = 0;  // per row
+    void *d_data = nullptr;
+};
+
+struct PendingRow {
+    int32_t batch_idx;  // >= 0: index into the current batch's device stats; -1: host stat
+    nps_locus_stat host;
+};
+
+struct nps_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t n = 0;         // samples
+    uint64_t n_words = 0;   // ceil(n/16)
+    uint64_t stride_words = 0;
+    nps_params params{};
+
+    // streaming batch
+    uint32_t batch_cap = 0, batch_rows = 0;
+    uint32_t *d_codes = nullptr;            // [batch_cap][stride_words]
+    unsigned long long *d_tally = nullptr;  // [batch_cap]
+    nps_row_desc *d_desc = nullptr;         // [batch_cap]
+    nps_row_desc *h_desc = nullptr;         // pinned [batch_cap]
+    double *d_lut = nullptr;                // [batch_cap][4]
+    nps_locus_stat *d_stats = nullptr;      // [batch_cap]
+    nps_locus_stat *h_stats = nullptr;      // pinned [batch_cap]
+    int32_t *d_raw = nullptr;               // raw FORMAT staging for one row (n*2 int32)
+    static constexpr int kRawSlots = 2;
+    int32_t *h_raw[kRawSlots] = {nullptr, nullptr};  // pinned staging ring for caller buffers
+    hipEvent_t ev_raw[kRawSlots] = {nullptr, nullptr};
+    int raw_next = 0;
+
+    // accumulators
+    AccumGeom geom{};         // streaming geometry (groups_per_chunk for a full batch)
+    uint32_t n_chunks = 1;
+    double *d_part = nullptr;  // [n_chunks][part_chunk_stride]
+    double *d_scores = nullptr;
+    unsigned long long *d_nloci = nullptr;
+    double const_sum = 0.0;   // contributions of rows without genotype data (host decided)
+    uint64_t host_nloci = 0;
+
+    // resident runs (nps_score_cohort*): per-row buffers, grown on demand
+    uint64_t res_cap = 0;
+    unsigned long long *d_rtally = nullptr;
+    double *d_rlut = nullptr;
+    nps_locus_stat *d_rstats = nullptr;
+    bool res_pending = false;               // stats of the last resident run still on the device
+    uint64_t res_m = 0;
+    std::vector<int64_t> res_index;
+    std::vector<nps_locus_stat> res_host_stats;
+
+    // stats in push order
+    std::vector<PendingRow> pending;        // rows of the open batch (+ no-data rows since)
+    std::vector<nps_locus_stat> ready;      // completed, not yet returned by nps_flush
+    size_t ready_cursor = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<ProfSpan> spans;
+    nps_profile prof{};
+};
+
+static DevParams dev_params(const nps_params &p) {
+    DevParams d;
+    d.imp_locus = p.imp_locus;
+    d.imp_missing = p.imp_missing;
+    d.imp_sample = p.imp_sample;
+    d.max_missing_rate = p.max_missing_rate;
+    d.min_cs = (double)p.min_cs;
+    return d;
+}
+
+static int check_params(const nps_params *p) {
+    if (!p) return fail(NPS_E_INVAL, "params is NULL");
+    if (p->imp_locus < 0 || p->imp_locus > NPS_LOCUS_IGNORE)
+        return fail(NPS_E_INVAL, "imp_locus %d out of range", p->imp_locus);
+    if (p->imp_missing < 0 || p->imp_missing > NPS_MISSING_IGNORE)
+        return fail(NPS_E_INVAL, "imp_missing %d out of range", p->imp_missing);
+    if (p->imp_sample < 0 || p->imp_sample > NPS_SAMPLE_INT_FAIL)
+        return fail(NPS_E_INVAL, "imp_sample %d out of range", p->imp_sample);
+    return NPS_OK;
+}
+
+// profiling helpers -------------------------------------------------------------------------
+struct ProfScope {
+    nps_ctx *c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(nps_ctx *ctx, int k) : c(ctx), cls(k) {
+        if (c->profiling) {
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+                (void)hipEventRecord(a, c->stream);
+            else
+                a = b = nullptr;
+        }
+    }
+    ~ProfScope() {
+        if (a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({a, b, cls});
+        }
+    }
+};
+
+static void resolve_spans(nps_ctx *c) {
+    for (auto &s : c->spans) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(s.b);
+        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        double *acc[P_COUNT] = {&c->prof.ms_decode, &c->prof.ms_tally,  &c->prof.ms_params,
+                                &c->prof.ms_accumulate, &c->prof.ms_fused, &c->prof.ms_reduce};
+        uint64_t *cnt[P_COUNT] = {&c->prof.n_decode, &c->prof.n_tally,  &c->prof.n_params,
+                                  &c->prof.n_accumulate, &c->prof.n_fused, &c->prof.n_reduce};
+        *acc[s.cls] += ms;
+        *cnt[s.cls] += 1;
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int nps_abi_version(void) { return NPS_ABI_VERSION; }
+extern "C" const char *nps_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int nps_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(NPS_E_NODEVICE, "no HIP device available (%s); libnps has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(NPS_E_NODEVICE, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return NPS_OK;
+}
+
+// geometry of the partial-score buffer: sample tiles x row chunks >= ~2048 blocks
+static void choose_geometry(nps_ctx *c) {
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, (c->n_words + 255) / 256);
+    uint32_t chunks = (2048 + tiles - 1) / tiles;
+    chunks = std::max(1u, std::min(chunks, 64u));
+    c->n_chunks = chunks;
+    c->geom.n_words = (uint32_t)c->n_words;
+    c->geom.n_chunks = chunks;
+    c->geom.part_chunk_stride = (uint64_t)tiles * 256 * 16;
+}
+
+static void free_ctx(nps_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    (void)hipFree(c->d_codes);
+    (void)hipFree(c->d_tally);
+    (void)hipFree(c->d_desc);
+    (void)hipHostFree(c->h_desc);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_stats);
+    (void)hipHostFree(c->h_stats);
+    (void)hipFree(c->d_raw);
+    for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
+        (void)hipHostFree(c->h_raw[k]);
+        if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
+    }
+    (void)hipFree(c->d_rtally);
+    (void)hipFree(c->d_rlut);
+    (void)hipFree(c->d_rstats);
+    (void)hipFree(c->d_part);
+    (void)hipFree(c->d_scores);
+    (void)hipFree(c->d_nloci);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int zero_state(nps_ctx *c) {
+    HIP_TRY(hipMemsetAsync(c->d_part, 0, sizeof(double) * c->n_chunks * c->geom.part_chunk_stride,
+                           c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_nloci, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * c->batch_cap, c->stream));
+    c->const_sum = 0.0;
+    c->host_nloci = 0;
+    c->batch_rows = 0;
+    c->pending.clear();
+    c->ready.clear();
+    c->ready_cursor = 0;
+    c->res_pending = false;  // unflushed stats of a resident run are dropped, never copied
+    c->res_index.clear();
+    c->res_host_stats.clear();
+    return NPS_OK;
+}
+
+extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const nps_params *params) {
+    if (!out) return fail(NPS_E_INVAL, "out is NULL");
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n_samples > 0x7fffffffull)
+        return fail(NPS_E_UNSUPPORTED, "n_samples %llu exceeds 2^31-1",
+                    (unsigned long long)n_samples);
+    rc = select_device(device);
+    if (rc) return rc;
+    nps_ctx *c = new (std::nothrow) nps_ctx;
+    if (!c) return fail(NPS_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->n = n_samples;
+    c->n_words = words_for(n_samples);
+    c->stride_words = stride_words_for(n_samples);
+    c->params = *params;
+    choose_geometry(c);
+
+    const uint64_t row_bytes = c->stride_words * 4;
+    uint64_t cap = (64ull << 20) / row_bytes;
+    cap = std::max<uint64_t>(16, std::min<uint64_t>(cap, 4096));
+    cap = cap / 16 * 16;
+    c->batch_cap = (uint32_t)cap;
+    c->geom.groups_per_chunk =
+        std::max(1u, ((c->batch_cap / 4) + c->n_chunks - 1) / c->n_chunks);
+
+#define CTX_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            int code = fail(_e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP,         \
+                            "%s failed: %s", #expr, hipGetErrorString(_e));              \
+            free_ctx(c);                                                                 \
+            return code;                                                                 \
+        }                                                                                \
+    } while (0)
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTX_TRY(hipMalloc(&c->d_codes, row_bytes * c->batch_cap));
+    CTX_TRY(hipMemsetAsync(c->d_codes, 0, row_bytes * c->batch_cap, c->stream));
+    CTX_TRY(hipMalloc(&c->d_tally, sizeof(unsigned long long) * c->batch_cap));
+    CTX_TRY(hipMalloc(&c->d_desc, sizeof(nps_row_desc) * c->batch_cap));
+    CTX_TRY(hipHostMalloc(&c->h_desc, sizeof(nps_row_desc) * c->batch_cap));
+    CTX_TRY(hipMalloc(&c->d_lut, sizeof(double) * 4 * c->batch_cap));
+    CTX_TRY(hipMalloc(&c->d_stats, sizeof(nps_locus_stat) * c->batch_cap));
+    CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(nps_locus_stat) * c->batch_cap));
+    CTX_TRY(hipMalloc(&c->d_raw, sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1)));
+    for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
+        CTX_TRY(hipHostMalloc(&c->h_raw[k], sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1)));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_raw[k], hipEventDisableTiming));
+    }
+    CTX_TRY(hipMalloc(&c->d_part, sizeof(double) * c->n_chunks * c->geom.part_chunk_stride));
+    CTX_TRY(hipMalloc(&c->d_scores, sizeof(double) * std::max<uint64_t>(c->n, 1)));
+    CTX_TRY(hipMalloc(&c->d_nloci, sizeof(unsigned long long)));
+#undef CTX_TRY
+    rc = zero_state(c);
+    if (rc) {
+        free_ctx(c);
+        return rc;
+    }
+    *out = c;
+    return NPS_OK;
+}
+
+extern "C" void nps_destroy(nps_ctx *ctx) { free_ctx(ctx); }
+
+extern "C" int nps_reset(nps_ctx *c, const nps_params *params) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (params) {
+        int rc = check_params(params);
+        if (rc) return rc;
+        c->params = *params;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return zero_state(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// rows without genotype data are decided entirely on the host: nimpress.nim:526-558 + 417-447
+static void host_locus_row(nps_ctx *c, int kind, int rie, double beta, double eaf,
+                           nps_locus_stat *st) {
+    st->ngenotyped = 0;
+    st->nmissing = 0;
+    st->neffect = 0.0;
+    int used;
+    double dosage = 0.0;
+    if (kind == NPS_ROW_ABSENT) {  // :536-551
+        st->reason = NPS_REASON_ABSENT;
+        if (c->params.imp_missing == NPS_MISSING_HOMREF) {
+            used = 1;
+            dosage = rie ? 2.0 : 0.0;
+        } else {
+            used = 0;
+        }
+    } else {  // UNCOVERED :526-531, FILTERED :553-558 -> imputeLocusDosages :417-447
+        st->reason = kind == NPS_ROW_UNCOVERED ? NPS_REASON_UNCOVERED : NPS_REASON_FILTERED;
+        switch (c->params.imp_locus) {
+        case NPS_LOCUS_IGNORE: used = 0; break;
+        case NPS_LOCUS_PS: used = 1; dosage = eaf * 2.0; break;
+        case NPS_LOCUS_HOMREF: used = 1; dosage = rie ? 2.0 : 0.0; break;
+        default: used = 1; dosage = std::numeric_limits<double>::quiet_NaN(); break;
+        }
+    }
+    st->used = used;
+    if (used) {
+        volatile double term = dosage * beta;  // same product as nimpress.nim:640, not contracted
+        c->const_sum += term;
+        c->host_nloci += 1;
+    }
+}
+
+static int materialize_resident_stats(nps_ctx *c);
+
+// run the open batch: params -> accumulate; then collect its stats
+static int run_batch(nps_ctx *c) {
+    if (c->res_pending && !c->pending.empty()) {  // keep stats in push order
+        int rc = materialize_resident_stats(c);
+        if (rc) return rc;
+    }
+    if (c->batch_rows == 0) {
+        // only host rows pending: move them to ready
+        for (auto &p : c->pending) c->ready.push_back(p.host);
+        c->pending.clear();
+        return NPS_OK;
+    }
+    const uint32_t rows = c->batch_rows;
+    const uint32_t rows_pad = (rows + 3) / 4 * 4;
+    HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(nps_row_desc) * rows, hipMemcpyHostToDevice,
+                           c->stream));
+    {
+        ProfScope ps(c, P_PARAMS);
+        HIP_TRY(launch_row_params(c->stream, c->d_tally, c->d_desc, rows, rows_pad, c->n,
+                                  dev_params(c->params), c->d_lut, c->d_stats, c->d_nloci));
+    }
+    if (c->n > 0) {
+        ProfScope ps(c, P_ACCUM);
+        HIP_TRY(launch_accumulate(c->stream, c->d_codes, c->stride_words, rows, c->d_lut, c->geom,
+                                  c->d_part));
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(nps_locus_stat) * rows,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * rows, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) c->ready.push_back(p.batch_idx >= 0 ? c->h_stats[p.batch_idx] : p.host);
+    c->pending.clear();
+    c->batch_rows = 0;
+    return NPS_OK;
+}
+
+static int begin_data_row(nps_ctx *c, int ref_is_effect, double beta, double eaf, uint32_t *slot) {
+    if (c->batch_rows == c->batch_cap) {
+        int rc = run_batch(c);
+        if (rc) return rc;
+    }
+    *slot = c->batch_rows;
+    nps_row_desc &d = c->h_desc[*slot];
+    d.beta = beta;
+    d.eaf = eaf;
+    d.kind = NPS_ROW_PRESENT;
+    d.ref_is_effect = ref_is_effect ? 1 : 0;
+    return NPS_OK;
+}
+
+static void commit_data_row(nps_ctx *c, uint32_t slot) {
+    PendingRow p;
+    p.batch_idx = (int32_t)slot;
+    memset(&p.host, 0, sizeof p.host);
+    c->pending.push_back(p);
+    c->batch_rows = slot + 1;
+}
+
+extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
+                           double beta, double eaf) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !gts) return fail(NPS_E_INVAL, "gts is NULL");
+    if (ploidy < 1) return fail(NPS_E_INVAL, "ploidy %d < 1", ploidy);
+    if (ploidy > 2)
+        return fail(NPS_E_UNSUPPORTED,
+                    "ploidy %d: the 2-bit GT path holds dosages 0..2 (nimpress is diploid-specific, "
+                    "README.md:158)", ploidy);
+    if (eaidx < 0) return fail(NPS_E_INVAL, "eaidx %d < 0 (nimpress.nim:380 doAssert)", eaidx);
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t slot;
+    int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
+    if (rc) return rc;
+    if (c->n) {
+        // the caller may reuse `gts` on return: copy it into a pinned ring slot first
+        const int k = c->raw_next;
+        c->raw_next = (k + 1) % nps_ctx::kRawSlots;
+        HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
+        const size_t bytes = sizeof(int32_t) * (size_t)ploidy * c->n;
+        memcpy(c->h_raw[k], gts, bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_raw, c->h_raw[k], bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
+        ProfScope ps(c, P_DECODE);
+        HIP_TRY(launch_decode_gt(c->stream, c->d_raw, c->n, ploidy, eaidx,
+                                 c->d_codes + (uint64_t)slot * c->stride_words, c->d_tally + slot));
+    }
+    commit_data_row(c, slot);
+    return NPS_OK;
+}
+
+extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effect, double beta,
+                               double eaf) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !row) return fail(NPS_E_INVAL, "row is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t slot;
+    int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
+    if (rc) return rc;
+    if (c->n) {
+        uint32_t *dst = c->d_codes + (uint64_t)slot * c->stride_words;
+        const int k = c->raw_next;
+        c->raw_next = (k + 1) % nps_ctx::kRawSlots;
+        HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
+        memcpy(c->h_raw[k], row, sizeof(uint32_t) * c->n_words);
+        HIP_TRY(hipMemcpyAsync(dst, c->h_raw[k], sizeof(uint32_t) * c->n_words,
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
+        ProfScope ps(c, P_TALLY);
+        HIP_TRY(launch_tally_packed(c->stream, dst, c->stride_words, c->n, 1, c->d_tally + slot));
+    }
+    commit_data_row(c, slot);
+    return NPS_OK;
+}
+
+extern "C" int nps_push_ds(nps_ctx *c, const float *ds, int ref_is_effect, double beta, double eaf) {
+    (void)ds; (void)ref_is_effect; (void)beta; (void)eaf;
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    return fail(NPS_E_UNSUPPORTED, "FORMAT/DS path not built yet");
+}
+
+extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double beta, double eaf) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (kind != NPS_ROW_UNCOVERED && kind != NPS_ROW_ABSENT && kind != NPS_ROW_FILTERED)
+        return fail(NPS_E_INVAL, "kind %d is not a no-data row kind", kind);
+    PendingRow p;
+    p.batch_idx = -1;
+    host_locus_row(c, kind, ref_is_effect, beta, eaf, &p.host);
+    c->pending.push_back(p);
+    return NPS_OK;
+}
+
+extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size_t *n_out) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = NPS_OK;
+    if (stats_out) rc = materialize_resident_stats(c);
+    if (rc) return rc;
+    rc = run_batch(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t n = 0;
+    if (stats_out) {
+        while (c->ready_cursor < c->ready.size() && n < cap) stats_out[n++] = c->ready[c->ready_cursor++];
+        if (c->ready_cursor == c->ready.size()) {
+            c->ready.clear();
+            c->ready_cursor = 0;
+        }
+    }
+    if (n_out) *n_out = n;
+    return NPS_OK;
+}
+
+static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nloci_out) {
+    int rc = run_batch(c);
+    if (rc) return rc;
+    unsigned long long dev_nloci = 0;
+    HIP_TRY(hipMemcpyAsync(&dev_nloci, c->d_nloci, sizeof dev_nloci, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t nloci = c->host_nloci + dev_nloci;
+    if (nloci_out) *nloci_out = nloci;
+    if (c->n) {
+        const double denom = (double)nloci * 2.0;  // nimpress.nim:645
+        ProfScope ps(c, P_REDUCE);
+        HIP_TRY(launch_finish(c->stream, c->d_part, c->n_chunks, c->geom.part_chunk_stride, c->n,
+                              c->const_sum, denom, offset, d_dst));
+    }
+    return NPS_OK;
+}
+
+extern "C" int nps_finish(nps_ctx *c, double offset, double *scores_out, uint64_t *nloci_out) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !scores_out) return fail(NPS_E_INVAL, "scores_out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = finish_common(c, offset, c->d_scores, nloci_out);
+    if (rc) return rc;
+    if (c->n)
+        HIP_TRY(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * c->n, hipMemcpyDeviceToHost,
+                               c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NPS_OK;
+}
+
+extern "C" int nps_finish_device(nps_ctx *c, double offset, double *d_scores_out,
+                                 uint64_t *nloci_out) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !d_scores_out) return fail(NPS_E_INVAL, "d_scores_out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = finish_common(c, offset, d_scores_out, nloci_out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NPS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// resident cohort
+extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
+                                 int format) {
+    if (!out) return fail(NPS_E_INVAL, "out is NULL");
+    *out = nullptr;
+    if (format != NPS_FMT_GT2)
+        return fail(NPS_E_UNSUPPORTED, "cohort format %d not built yet", format);
+    if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
+    int rc = select_device(device);
+    if (rc) return rc;
+    nps_cohort *c = new (std::nothrow) nps_cohort;
+    if (!c) return fail(NPS_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->format = format;
+    c->n_samples = n_samples;
+    c->n_rows = n_rows;
+    c->stride_bytes = stride_words_for(n_samples) * 4;
+    const uint64_t bytes = std::max<uint64_t>(c->stride_bytes * n_rows, 256);
+    hipError_t e = hipMalloc(&c->d_data, bytes);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(NPS_E_NOMEM, "hipMalloc(%llu bytes) for the cohort failed: %s",
+                    (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    e = hipMemset(c->d_data, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(c->d_data);
+        delete c;
+        return fail(NPS_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return NPS_OK;
+}
+
+extern "C" uint64_t nps_cohort_row_stride(const nps_cohort *c) { return c ? c->stride_bytes : 0; }
+extern "C" uint64_t nps_cohort_n_rows(const nps_cohort *c) { return c ? c->n_rows : 0; }
+
+extern "C" void nps_cohort_destroy(nps_cohort *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->d_data);
+    delete c;
+}
+
+static int check_range(const nps_cohort *c, uint64_t row0, uint64_t nrows) {
+    if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
+    if (row0 > c->n_rows || nrows > c->n_rows - row0)
+        return fail(NPS_E_INVAL, "rows [%llu,+%llu) outside cohort of %llu rows",
+                    (unsigned long long)row0, (unsigned long long)nrows,
+                    (unsigned long long)c->n_rows);
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
+                                 size_t host_stride) {
+    int rc = check_range(c, row0, nrows);
+    if (rc) return rc;
+    const size_t width = words_for(c->n_samples) * 4;
+    if (nrows == 0 || width == 0) return NPS_OK;
+    if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
+                        host_stride, width, nrows, hipMemcpyHostToDevice));
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t nrows,
+                                   void *host_rows, size_t host_stride) {
+    int rc = check_range(c, row0, nrows);
+    if (rc) return rc;
+    const size_t width = words_for(c->n_samples) * 4;
+    if (nrows == 0 || width == 0) return NPS_OK;
+    if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2D(host_rows, host_stride, (const char *)c->d_data + row0 * c->stride_bytes,
+                        c->stride_bytes, width, nrows, hipMemcpyDeviceToHost));
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
+                                const uint32_t *t_het, const uint32_t *t_hom,
+                                const uint32_t *t_miss) {
+    int rc = check_range(c, row0, nrows);
+    if (rc) return rc;
+    if (nrows == 0) return NPS_OK;
+    if (!t_het || !t_hom || !t_miss) return fail(NPS_E_INVAL, "threshold arrays are NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d_t = nullptr;
+    HIP_TRY(hipMalloc(&d_t, sizeof(uint32_t) * 3 * nrows));
+    hipError_t e = hipMemcpy(d_t, t_het, sizeof(uint32_t) * nrows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_t + nrows, t_hom, sizeof(uint32_t) * nrows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_t + 2 * nrows, t_miss, sizeof(uint32_t) * nrows, hipMemcpyHostToDevice);
+    const uint64_t step = 32768;
+    for (uint64_t r = 0; e == hipSuccess && r < nrows; r += step) {
+        const uint64_t k = std::min(step, nrows - r);
+        e = launch_synth_gt(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
+                            row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_t);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
+    return NPS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// score definitions kept on the device
+struct nps_scoredef {
+    int device = 0;
+    uint64_t n_desc = 0;
+    uint64_t m = 0;                       // PRESENT rows (consume cohort rows)
+    std::vector<nps_row_desc> host_rows;  // rows without genotype data, in order
+    std::vector<int64_t> data_index;      // per desc: >= 0 index among PRESENT rows, -1 host row
+    nps_row_desc *d_desc = nullptr;       // [m] PRESENT rows, compact
+};
+
+extern "C" int nps_scoredef_create(nps_scoredef **out, int device, const nps_row_desc *rows,
+                                   uint64_t n_desc) {
+    if (!out) return fail(NPS_E_INVAL, "out is NULL");
+    *out = nullptr;
+    if (n_desc && !rows) return fail(NPS_E_INVAL, "rows is NULL");
+    int rc = select_device(device);
+    if (rc) return rc;
+    nps_scoredef *d = new (std::nothrow) nps_scoredef;
+    if (!d) return fail(NPS_E_NOMEM, "out of host memory");
+    d->device = device;
+    d->n_desc = n_desc;
+    std::vector<nps_row_desc> data;
+    data.reserve(n_desc);
+    d->data_index.resize(n_desc);
+    for (uint64_t j = 0; j < n_desc; ++j) {
+        const nps_row_desc &r = rows[j];
+        if (r.kind == NPS_ROW_PRESENT) {
+            d->data_index[j] = (int64_t)data.size();
+            data.push_back(r);
+        } else if (r.kind == NPS_ROW_UNCOVERED || r.kind == NPS_ROW_ABSENT ||
+                   r.kind == NPS_ROW_FILTERED) {
+            d->data_index[j] = -1;
+            d->host_rows.push_back(r);
+        } else {
+            delete d;
+            return fail(NPS_E_INVAL, "row %llu: bad kind %d", (unsigned long long)j, r.kind);
+        }
+    }
+    d->m = data.size();
+    if (d->m > 0xfffffff0ull) {
+        delete d;
+        return fail(NPS_E_UNSUPPORTED, "too many rows");
+    }
+    if (d->m) {
+        hipError_t e = hipMalloc(&d->d_desc, sizeof(nps_row_desc) * d->m);
+        if (e == hipSuccess)
+            e = hipMemcpy(d->d_desc, data.data(), sizeof(nps_row_desc) * d->m, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d->d_desc);
+            delete d;
+            return fail(e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP,
+                        "uploading the score definition failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = d;
+    return NPS_OK;
+}
+
+extern "C" uint64_t nps_scoredef_n_present(const nps_scoredef *d) { return d ? d->m : 0; }
+
+extern "C" void nps_scoredef_destroy(nps_scoredef *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipFree(d->d_desc);
+    delete d;
+}
+
+// ------------------------------------------------------------------------------------------
+// resident scoring.  Two-pass mode: per block of rows, tally -> params -> accumulate.
+static uint64_t env_u64(const char *name, uint64_t dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    char *end = nullptr;
+    unsigned long long v = strtoull(s, &end, 10);
+    return end && *end == 0 ? (uint64_t)v : dflt;
+}
+
+// stats of the last resident run stay on the device until somebody asks for them
+static int materialize_resident_stats(nps_ctx *c) {
+    if (!c->res_pending) return NPS_OK;
+    std::vector<nps_locus_stat> dev(c->res_m);
+    if (c->res_m) {
+        HIP_TRY(hipMemcpyAsync(dev.data(), c->d_rstats, sizeof(nps_locus_stat) * c->res_m,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    size_t h = 0;
+    for (size_t j = 0; j < c->res_index.size(); ++j)
+        c->ready.push_back(c->res_index[j] >= 0 ? dev[(size_t)c->res_index[j]] : c->res_host_stats[h++]);
+    c->res_pending = false;
+    c->res_index.clear();
+    c->res_host_stats.clear();
+    return NPS_OK;
+}
+
+static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
+    if (m_pad <= c->res_cap) return NPS_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_rtally);
+    (void)hipFree(c->d_rlut);
+    (void)hipFree(c->d_rstats);
+    c->d_rtally = nullptr;
+    c->d_rlut = nullptr;
+    c->d_rstats = nullptr;
+    c->res_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_rtally, sizeof(unsigned long long) * m_pad));
+    HIP_TRY(hipMalloc(&c->d_rlut, sizeof(double) * 4 * m_pad));
+    HIP_TRY(hipMalloc(&c->d_rstats, sizeof(nps_locus_stat) * m_pad));
+    c->res_cap = m_pad;
+    return NPS_OK;
+}
+
+extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t cohort_row0,
+                                    const nps_scoredef *def, int mode) {
+    if (!c || !co || !def) return fail(NPS_E_INVAL, "ctx, cohort or scoredef is NULL");
+    if (co->device != c->device || def->device != c->device)
+        return fail(NPS_E_INVAL, "cohort / scoredef / context on different devices");
+    if (co->n_samples != c->n)
+        return fail(NPS_E_INVAL, "cohort has %llu samples, context %llu",
+                    (unsigned long long)co->n_samples, (unsigned long long)c->n);
+    if (co->format != NPS_FMT_GT2) return fail(NPS_E_UNSUPPORTED, "cohort format not supported");
+    if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
+        return fail(NPS_E_INVAL, "bad mode %d", mode);
+    if (mode == NPS_MODE_FUSED) return fail(NPS_E_UNSUPPORTED, "fused mode not built yet");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = run_batch(c);  // keep push order: finish whatever was streamed before
+    if (rc) return rc;
+    rc = materialize_resident_stats(c);
+    if (rc) return rc;
+    const uint64_t m = def->m;
+    rc = check_range(co, cohort_row0, m);
+    if (rc) return rc;
+
+    // rows without genotype data, in order (host decided; nimpress.nim:526-558)
+    c->res_host_stats.clear();
+    c->res_host_stats.reserve(def->host_rows.size());
+    for (const nps_row_desc &r : def->host_rows) {
+        nps_locus_stat st;
+        host_locus_row(c, r.kind, r.ref_is_effect, r.beta, r.eaf, &st);
+        c->res_host_stats.push_back(st);
+    }
+    c->res_index = def->data_index;
+    c->res_m = m;
+    c->res_pending = true;
+    if (m == 0) return NPS_OK;
+
+    const uint64_t m_pad = (m + 3) / 4 * 4;
+    rc = ensure_resident_buffers(c, m_pad);
+    if (rc) return rc;
+    const uint64_t stride_words = co->stride_bytes / 4;
+    const uint32_t *codes = (const uint32_t *)co->d_data + cohort_row0 * stride_words;
+    // rows per tally/accumulate pair; default ~96 MB so the second read can hit the 256 MB
+    // Infinity Cache
+    uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
+    if (block_rows == 0) block_rows = std::max<uint64_t>(64, (96ull << 20) / co->stride_bytes);
+    block_rows = (block_rows + 15) / 16 * 16;
+    for (uint64_t r0 = 0; r0 < m; r0 += block_rows) {
+        const uint64_t k = std::min(block_rows, m - r0);
+        const uint64_t k_pad = (k + 3) / 4 * 4;  // only the last block can be ragged
+        {
+            ProfScope ps(c, P_TALLY);
+            HIP_TRY(launch_tally_packed(c->stream, codes + r0 * stride_words, stride_words, c->n, k,
+                                        c->d_rtally + r0));
+        }
+        {
+            ProfScope ps(c, P_PARAMS);
+            HIP_TRY(launch_row_params(c->stream, c->d_rtally + r0, def->d_desc + r0, k, k_pad, c->n,
+                                      dev_params(c->params), c->d_rlut + r0 * 4, c->d_rstats + r0,
+                                      c->d_nloci));
+        }
+        if (c->n) {
+            AccumGeom g = c->geom;
+            const uint32_t groups = (uint32_t)(k_pad / 4);
+            g.groups_per_chunk = std::max(1u, (groups + g.n_chunks - 1) / g.n_chunks);
+            ProfScope ps(c, P_ACCUM);
+            HIP_TRY(launch_accumulate(c->stream, codes + r0 * stride_words, stride_words, k,
+                                      c->d_rlut + r0 * 4, g, c->d_part));
+        }
+    }
+    return NPS_OK;
+}
+
+extern "C" int nps_score_cohort(nps_ctx *c, const nps_cohort *co, uint64_t cohort_row0,
+                                const nps_row_desc *rows, uint64_t n_desc, int mode) {
+    if (!c || !co) return fail(NPS_E_INVAL, "ctx or cohort is NULL");
+    nps_scoredef *def = nullptr;
+    int rc = nps_scoredef_create(&def, c->device, rows, n_desc);
+    if (rc) return rc;
+    rc = nps_score_cohort_def(c, co, cohort_row0, def, mode);
+    // the launches read def->d_desc: complete them before the temporary definition goes away
+    if (rc == NPS_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(NPS_E_HIP, "resident scoring failed: %s", hipGetErrorString(e));
+    }
+    nps_scoredef_destroy(def);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int nps_profile_enable(nps_ctx *c, int on) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    c->profiling = on != 0;
+    return NPS_OK;
+}
+
+extern "C" int nps_profile_get(nps_ctx *c, nps_profile *out, int reset) {
+    if (!c || !out) return fail(NPS_E_INVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_spans(c);
+    *out = c->prof;
+    if (reset) c->prof = nps_profile{};
+    return NPS_OK;
+}
+
+extern "C" void *nps_stream(nps_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -1,0 +1,65 @@
+// nps_kernels.h -- host-callable launchers for the gfx950 kernels of libnps.
+// Internal header (not part of the C-ABI; the public boundary is include/nps.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nps.h"
+
+namespace nps {
+
+// Device layout of a packed GT row (DESIGN.md "Data layout"): ceil(N/16) uint32, row stride padded
+// to 64 words (256 B).  Tally word per row: (nmissing << 32) | neffect.
+constexpr uint32_t kStrideAlignWords = 64;
+
+static inline uint64_t words_for(uint64_t n_samples) { return (n_samples + 15) / 16; }
+static inline uint64_t stride_words_for(uint64_t n_samples) {
+    uint64_t w = words_for(n_samples);
+    if (w == 0) w = 1;
+    return (w + kStrideAlignWords - 1) / kStrideAlignWords * kStrideAlignWords;
+}
+
+struct DevParams {
+    int32_t imp_locus, imp_missing, imp_sample;
+    double max_missing_rate;
+    double min_cs;  // compared in double, nimpress.nim:471
+};
+
+// raw bcf_get_genotypes buffer (device copy) -> packed row + tally (atomic add into *tally)
+hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
+                            uint32_t *d_row, unsigned long long *d_tally);
+
+// tally of packed rows [0,n_rows): tally[row] = (nmiss<<32)|neff   (direct store)
+hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
+                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally);
+
+// per-row decision + LUT {0b,1b,2b,imp*b} (or the locus constant); rows [n_rows, n_rows_pad) get a
+// zero LUT.  Adds the number of used rows to *d_nloci.
+hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,
+                             const nps_row_desc *d_desc, uint64_t n_rows, uint64_t n_rows_pad,
+                             uint64_t n_samples, DevParams p, double *d_lut, nps_locus_stat *d_stats,
+                             unsigned long long *d_nloci);
+
+// scores partials: part[chunk][sample] += sum over the chunk's rows of LUT[row][code]
+struct AccumGeom {
+    uint32_t n_words;          // ceil(N/16)
+    uint32_t n_chunks;         // grid.y
+    uint32_t groups_per_chunk; // row groups (4 rows) per chunk
+    uint64_t part_chunk_stride; // doubles between chunks in `part` (>= n_words*16)
+};
+hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
+                             uint64_t n_rows, const double *d_lut, const AccumGeom &g,
+                             double *d_part);
+
+// scores[i] = (sum_chunks part[c][i] + const_sum) / denom + offset      nimpress.nim:643-649
+hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks,
+                         uint64_t part_chunk_stride, uint64_t n_samples, double const_sum,
+                         double denom, double offset, double *d_scores);
+
+// synthetic cohort rows (counter-based generator shared with oracle/refcpu.c)
+hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
+                           uint64_t n_samples, uint64_t row0, uint64_t n_rows, uint64_t seed,
+                           const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                           const uint32_t *d_t_miss);
+
+}  // namespace nps

@@ -1,0 +1,429 @@
+// nps_kernels.hip -- gfx950 (MI355X, wave64) kernels for the nimpress per-variant inner loop.
+//
+//   decode_gt_kernel      getRawDosages + tallyAlleles        nimpress.nim:367-391, 32-47
+//   tally_packed_kernel   tallyAlleles on 2-bit rows          nimpress.nim:32-47
+//   row_params_kernel     maxmis decision + imputation value  nimpress.nim:565-571, 417-481
+//   accumulate_kernel     scores[i] += dosages[i]*beta        nimpress.nim:639-641
+//   finish_kernel         /= 2*nloci ; += offset              nimpress.nim:643-649
+//
+// Arithmetic: integer popcounts for the tallies (bit-exact), float64 for everything that touches
+// a score.  No MFMA: this is a streaming weighted reduction (0.25 B per genotype).
+//
+// The accumulate kernel never converts a genotype to a float.  Per group of 4 rows it builds a
+// 256-entry float64 table in LDS, T[c0|c1<<2|c2<<4|c3<<6] = ((l0[c0]+l1[c1])+l2[c2])+l3[c3] with
+// l_r[c] = LUT of row r (0*b, 1*b, 2*b, imputed*b), transposes four 16-sample words into sixteen
+// byte indices with 16 bit-field ops, and does one ds_read_b64 + one v_add_f64 per FOUR genotypes.
+#include "nps_kernels.h"
+
+namespace nps {
+
+// ------------------------------------------------------------------------------------------
+// wave64 / block reductions
+static __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+// sums (a,b,c) over the first `nthreads` threads of a group of waves; result valid in thread 0
+// of the group.  `slot` = LDS scratch of 3*4 uint32 per group.
+template <int WAVES>
+static __device__ __forceinline__ void group_sum3(uint32_t &a, uint32_t &b, uint32_t &c,
+                                                  uint32_t *slot, int tig /* thread in group */) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    if (WAVES > 1) {
+        const int w = tig >> 6;
+        if ((tig & 63) == 0) {
+            slot[w * 3 + 0] = a;
+            slot[w * 3 + 1] = b;
+            slot[w * 3 + 2] = c;
+        }
+        __syncthreads();
+        if (tig == 0) {
+            a = b = c = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) {
+                a += slot[k * 3 + 0];
+                b += slot[k * 3 + 1];
+                c += slot[k * 3 + 2];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode: bcf_get_genotypes int32 buffer -> 2-bit codes + tally.
+// hts-nim value(): a < 0 (vector-end pad) is skipped; a in {0,1} is the missing allele (value -1);
+// otherwise allele index (a>>1)-1.  Any missing allele makes the sample missing (NaN is sticky in
+// nimpress.nim:385-390).
+template <int PLOIDY>
+__global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restrict__ gts, uint64_t n,
+                                                        int eaidx, uint32_t *__restrict__ out_row,
+                                                        unsigned long long *__restrict__ tally) {
+    __shared__ uint32_t red[4 * 3];
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t code = 0;
+    bool miss = false;
+    if (s < n) {
+        int32_t a[PLOIDY];
+        if (PLOIDY == 2) {
+            const int2 v = reinterpret_cast<const int2 *>(gts)[s];
+            a[0] = v.x;
+            a[PLOIDY - 1] = v.y;
+        } else {
+            a[0] = gts[s];
+        }
+#pragma unroll
+        for (int k = 0; k < PLOIDY; ++k) {
+            if (a[k] >= 0) {
+                if (a[k] < 2)
+                    miss = true;
+                else
+                    code += (((a[k] >> 1) - 1) == eaidx) ? 1u : 0u;
+            }
+        }
+        if (miss) code = 3;
+    }
+    uint32_t sh = code << (2 * (lane & 15));
+    sh |= __shfl_xor(sh, 1, 64);
+    sh |= __shfl_xor(sh, 2, 64);
+    sh |= __shfl_xor(sh, 4, 64);
+    sh |= __shfl_xor(sh, 8, 64);
+    if ((lane & 15) == 0 && s < n) out_row[s >> 4] = sh;
+
+    uint32_t m = miss ? 1u : 0u, e = miss ? 0u : code, z = 0;
+    group_sum3<4>(m, e, z, red, threadIdx.x);
+    if (threadIdx.x == 0 && (m | e))
+        atomicAdd(tally, ((unsigned long long)m << 32) | (unsigned long long)e);
+}
+
+hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
+                            uint32_t *d_row, unsigned long long *d_tally) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (ploidy == 2)
+        hipLaunchKernelGGL(decode_gt_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
+                           eaidx, d_row, d_tally);
+    else if (ploidy == 1)
+        hipLaunchKernelGGL(decode_gt_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
+                           eaidx, d_row, d_tally);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// tally of packed rows.  For a word w of sixteen 2-bit codes (0,1,2 = dosage, 3 = missing):
+//   popc(w)              = het + hom + 2*miss
+//   popc(w & 0xAAAAAAAA) = hom + miss
+//   popc(w & w>>1 & 0x55555555) = miss
+//   neffect = het + 2*hom = popc(w) + popc(w & 0xAAAAAAAA) - 3*miss
+static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint32_t &ch,
+                                                  uint32_t &cm) {
+    cw += __popc(w);
+    ch += __popc(w & 0xAAAAAAAAu);
+    cm += __popc(w & (w >> 1) & 0x55555555u);
+}
+
+template <int TPR>  // threads per row: 64 (one wave) or 256 (whole block)
+__global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__restrict__ codes,
+                                                           uint64_t stride_words, uint32_t n_vec4,
+                                                           uint64_t n_rows,
+                                                           unsigned long long *__restrict__ tally) {
+    __shared__ uint32_t red[4 * 3];
+    constexpr int RPB = 256 / TPR;
+    const uint64_t row = (uint64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int t = threadIdx.x % TPR;
+    uint32_t cw = 0, ch = 0, cm = 0;
+    if (row < n_rows) {
+        // rows are 256-B aligned and zero padded to a multiple of 64 words, so whole uint4 reads
+        // up to n_vec4 = ceil(n_words/4) stay inside the row.
+        const uint4 *p = reinterpret_cast<const uint4 *>(codes + row * stride_words);
+        for (uint32_t v = t; v < n_vec4; v += TPR) {
+            const uint4 q = p[v];
+            tally_word(q.x, cw, ch, cm);
+            tally_word(q.y, cw, ch, cm);
+            tally_word(q.z, cw, ch, cm);
+            tally_word(q.w, cw, ch, cm);
+        }
+    }
+    group_sum3<TPR / 64>(cw, ch, cm, red, t);
+    if (t == 0 && row < n_rows)
+        tally[row] = ((unsigned long long)cm << 32) | (unsigned long long)(cw + ch - 3u * cm);
+}
+
+hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
+                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally) {
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t n_words = words_for(n_samples);
+    const uint32_t n_vec4 = (uint32_t)((n_words + 3) / 4);
+    if (n_words >= 1024) {
+        if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(tally_packed_kernel<256>, dim3((uint32_t)n_rows), dim3(256), 0, st,
+                           d_codes, stride_words, n_vec4, n_rows, d_tally);
+    } else {
+        const uint64_t blocks = (n_rows + 3) / 4;
+        if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(tally_packed_kernel<64>, dim3((uint32_t)blocks), dim3(256), 0, st,
+                           d_codes, stride_words, n_vec4, n_rows, d_tally);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// per-row decision and LUT.  Mirrors nimpress.nim:565-571 (maxmis, strict > on a double quotient),
+// :417-447 (locus imputation constant) and :450-481 (sample imputation value).
+__global__ __launch_bounds__(256) void row_params_kernel(
+    const unsigned long long *__restrict__ tally, const nps_row_desc *__restrict__ desc,
+    uint64_t n_rows, uint64_t n_rows_pad, uint64_t n_samples, DevParams p, double *__restrict__ lut,
+    nps_locus_stat *__restrict__ stats, unsigned long long *__restrict__ nloci) {
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    int used = 0;
+    if (row < n_rows_pad) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (row < n_rows) {
+            const unsigned long long t = tally[row];
+            const uint64_t nmiss = t >> 32;
+            const uint64_t neff = t & 0xffffffffull;
+            const uint64_t ngen = n_samples - nmiss;
+            const double beta = desc[row].beta, eaf = desc[row].eaf;
+            const bool rie = desc[row].ref_is_effect != 0;
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            int reason;
+            const double missingrate = (double)nmiss / (double)n_samples;
+            if (missingrate > p.max_missing_rate) {  // :565-571
+                reason = NPS_REASON_MAXMIS;
+                if (p.imp_locus == NPS_LOCUS_IGNORE) {
+                    used = 0;
+                } else {
+                    const double c = p.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                                     : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                                       : nan;
+                    used = 1;
+                    v0 = v1 = v2 = v3 = c * beta;
+                }
+            } else {  // :582-585
+                reason = NPS_REASON_GENOTYPED;
+                used = 1;
+                double imp;
+                switch (p.imp_sample) {
+                case NPS_SAMPLE_PS: imp = eaf * 2.0; break;
+                case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
+                case NPS_SAMPLE_FAIL: imp = nan; break;
+                default:
+                    if ((double)ngen >= p.min_cs)
+                        imp = (double)neff / (double)ngen;
+                    else
+                        imp = p.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
+                    break;
+                }
+                v0 = 0.0 * beta;
+                v1 = 1.0 * beta;
+                v2 = 2.0 * beta;
+                v3 = imp * beta;
+            }
+            if (stats) {
+                nps_locus_stat s;
+                s.ngenotyped = ngen;
+                s.nmissing = nmiss;
+                s.neffect = (double)neff;
+                s.used = used;
+                s.reason = reason;
+                stats[row] = s;
+            }
+        }
+        double4 *l4 = reinterpret_cast<double4 *>(lut + row * 4);
+        *l4 = make_double4(v0, v1, v2, v3);
+    }
+    const int cnt = __syncthreads_count(used);
+    if (threadIdx.x == 0 && cnt) atomicAdd(nloci, (unsigned long long)cnt);
+}
+
+hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,
+                             const nps_row_desc *d_desc, uint64_t n_rows, uint64_t n_rows_pad,
+                             uint64_t n_samples, DevParams p, double *d_lut, nps_locus_stat *d_stats,
+                             unsigned long long *d_nloci) {
+    if (n_rows_pad == 0) return hipSuccess;
+    const uint64_t blocks = (n_rows_pad + 255) / 256;
+    hipLaunchKernelGGL(row_params_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_tally, d_desc,
+                       n_rows, n_rows_pad, n_samples, p, d_lut, d_stats, d_nloci);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// 4 rows x 16 samples of 2-bit codes -> 16 byte indices (c0 | c1<<2 | c2<<4 | c3<<6).
+// x[q] byte k = index of sample 4k+q.
+static __device__ __forceinline__ void transpose_4x16(uint32_t w0, uint32_t w1, uint32_t w2,
+                                                      uint32_t w3, uint32_t (&x)[4]) {
+    const uint32_t m2 = 0x33333333u, m4 = 0x0F0F0F0Fu;
+    // nibbles: e = even samples, o = odd samples, rows (0,1) and (2,3)
+    const uint32_t e01 = (w0 & m2) | ((w1 << 2) & ~m2);
+    const uint32_t o01 = ((w0 >> 2) & m2) | (w1 & ~m2);
+    const uint32_t e23 = (w2 & m2) | ((w3 << 2) & ~m2);
+    const uint32_t o23 = ((w2 >> 2) & m2) | (w3 & ~m2);
+    x[0] = (e01 & m4) | ((e23 << 4) & ~m4);         // samples 0,4,8,12
+    x[1] = (o01 & m4) | ((o23 << 4) & ~m4);         // samples 1,5,9,13
+    x[2] = ((e01 >> 4) & m4) | (e23 & ~m4);         // samples 2,6,10,14
+    x[3] = ((o01 >> 4) & m4) | (o23 & ~m4);         // samples 3,7,11,15
+}
+
+constexpr int kAccThreads = 256;
+constexpr int kGps = 4;  // row groups per stage (16 rows)
+
+__global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
+    const uint32_t *__restrict__ codes, uint64_t stride_words, uint64_t n_rows, uint32_t n_words,
+    const double *__restrict__ lut, uint32_t n_groups, uint32_t groups_per_chunk,
+    double *__restrict__ part, uint64_t part_chunk_stride) {
+    __shared__ double T[2][kGps][256];  // 16 KiB
+    const int tid = threadIdx.x;
+    const uint32_t col = blockIdx.x * kAccThreads + tid;
+    const bool active = col < n_words;
+    const uint32_t g_begin = blockIdx.y * groups_per_chunk;
+    if (g_begin >= n_groups) return;  // block-uniform
+    const uint32_t g_end = min(n_groups, g_begin + groups_per_chunk);
+
+    double acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+
+    int buf = 0;
+    for (uint32_t g0 = g_begin; g0 < g_end; g0 += kGps, buf ^= 1) {
+        const uint32_t ng = min((uint32_t)kGps, g_end - g0);
+        uint32_t w[kGps][4];
+#pragma unroll
+        for (int gg = 0; gg < kGps; ++gg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t row = (uint64_t)(g0 + gg) * 4 + r;
+                w[gg][r] = (active && gg < (int)ng && row < n_rows) ? codes[row * stride_words + col]
+                                                                   : 0u;
+            }
+        // table for entry `tid` of each group of this stage (two LDS buffers -> one barrier/stage)
+#pragma unroll
+        for (int gg = 0; gg < kGps; ++gg) {
+            if (gg < (int)ng) {
+                const double *l = lut + (uint64_t)(g0 + gg) * 16;
+                T[buf][gg][tid] = ((l[tid & 3] + l[4 + ((tid >> 2) & 3)]) + l[8 + ((tid >> 4) & 3)]) +
+                                  l[12 + (tid >> 6)];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < kGps; ++gg) {
+            if (gg < (int)ng) {
+                uint32_t x[4];
+                transpose_4x16(w[gg][0], w[gg][1], w[gg][2], w[gg][3], x);
+                const double *Tg = T[buf][gg];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[4 * k + q] += Tg[(x[q] >> (8 * k)) & 0xFFu];
+            }
+        }
+    }
+    if (active) {
+        double *dst = part + (uint64_t)blockIdx.y * part_chunk_stride + (uint64_t)col * 16;
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            double2 v = *reinterpret_cast<double2 *>(dst + s);
+            v.x += acc[s];
+            v.y += acc[s + 1];
+            *reinterpret_cast<double2 *>(dst + s) = v;
+        }
+    }
+}
+
+hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
+                             uint64_t n_rows, const double *d_lut, const AccumGeom &g,
+                             double *d_part) {
+    if (n_rows == 0 || g.n_words == 0) return hipSuccess;
+    const uint32_t n_groups = (uint32_t)((n_rows + 3) / 4);
+    const uint32_t tiles = (g.n_words + kAccThreads - 1) / kAccThreads;
+    if (g.n_chunks == 0 || g.n_chunks > 65535 || g.groups_per_chunk == 0) return hipErrorInvalidValue;
+    if ((uint64_t)g.n_chunks * g.groups_per_chunk < n_groups) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(tiles, g.n_chunks), dim3(kAccThreads), 0, st, d_codes,
+                       stride_words, n_rows, g.n_words, d_lut, n_groups, g.groups_per_chunk, d_part,
+                       g.part_chunk_stride);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ part,
+                                                     uint32_t n_chunks, uint64_t part_chunk_stride,
+                                                     uint64_t n_samples, double const_sum,
+                                                     double denom, double offset,
+                                                     double *__restrict__ scores) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    double s = 0.0;
+    for (uint32_t c = 0; c < n_chunks; ++c) s += part[(uint64_t)c * part_chunk_stride + i];
+    s += const_sum;
+    s /= denom;   // nimpress.nim:645
+    s += offset;  // nimpress.nim:649
+    scores[i] = s;
+}
+
+hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks,
+                         uint64_t part_chunk_stride, uint64_t n_samples, double const_sum,
+                         double denom, double offset, double *d_scores) {
+    if (n_samples == 0) return hipSuccess;
+    const uint64_t blocks = (n_samples + 255) / 256;
+    hipLaunchKernelGGL(finish_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_part, n_chunks,
+                       part_chunk_stride, n_samples, const_sum, denom, offset, d_scores);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic cohort generator -- device copy of ref_synth_code (oracle/refcpu.c); the two must
+// produce identical codes (tests/test_gpu_parity.py::test_synth_matches_oracle).
+static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ codes,
+                                                       uint64_t stride_words, uint64_t n_samples,
+                                                       uint32_t n_words, uint64_t row0, uint64_t seed,
+                                                       const uint32_t *__restrict__ t_het,
+                                                       const uint32_t *__restrict__ t_hom,
+                                                       const uint32_t *__restrict__ t_miss) {
+    const uint32_t word = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r = blockIdx.y;
+    if (word >= n_words) return;
+    const uint64_t key = mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull));
+    const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t s = (uint64_t)word * 16 + k;
+        if (s < n_samples) {
+            const uint64_t h = mix64(key + s);
+            const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
+            const uint32_t c = ms < tmi ? 3u : (g < tm ? 2u : (g < th ? 1u : 0u));
+            w |= c << (2 * k);
+        }
+    }
+    codes[(row0 + r) * stride_words + word] = w;
+}
+
+hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
+                           uint64_t n_samples, uint64_t row0, uint64_t n_rows, uint64_t seed,
+                           const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                           const uint32_t *d_t_miss) {
+    const uint64_t n_words = words_for(n_samples);
+    if (n_rows == 0 || n_words == 0) return hipSuccess;
+    // grid.y <= 65535: caller splits larger row ranges
+    if (n_rows > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(synth_gt_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)n_rows),
+                       dim3(256), 0, st, d_codes, stride_words, n_samples, (uint32_t)n_words, row0,
+                       seed, d_t_het, d_t_hom, d_t_miss);
+    return hipGetLastError();
+}
+
+}  // namespace nps

@@ -22,6 +22,7 @@
  *   htslib (1.10.2, Dockerfile:32) bcf_get_genotypes layout: n_samples*ploidy int32,
  *     allele a encoded (a+1)<<1 | phased.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -452,4 +453,24 @@ void ref_synth_rows_ds(float *ds, size_t stride, size_t n, size_t row0, size_t n
         for (size_t i = 0; i < n; ++i)
             ds[r * stride + i] =
                 ref_synth_ds(seed, row0 + r, i, t_het[r], t_hom[r], t_miss[r]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* CPU baseline for bench.py: the literal per-row path (decode, tally, impute, accumulate;
+ * nimpress.nim:561-583, 639-641) over m rows whose bcf_get_genotypes buffers cycle through
+ * n_distinct pre-built rows.  Returns wall seconds measured around the loop only. */
+#include <time.h>
+double ref_bench_gt(const int32_t *gts_rows, size_t n_distinct, size_t n, size_t m,
+                    const double *beta, const double *eaf, const ref_params *p,
+                    double *scores_out, int64_t *nloci_out) {
+    ref_state *s = ref_begin(n, p);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t j = 0; j < m; ++j) {
+        ref_locus_stat st;
+        ref_row_gt(s, gts_rows + (j % n_distinct) * 2 * n, 2, 1, 0, beta[j], eaf[j], &st);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    ref_finish(s, 0.0, scores_out, nloci_out);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

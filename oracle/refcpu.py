@@ -109,6 +109,9 @@ def lib():
     L.ref_synth_rows_ds.restype = None
     L.ref_codes_to_gt.argtypes = [u32p, C.c_size_t, i32p]
     L.ref_codes_to_gt.restype = None
+    L.ref_bench_gt.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp,
+                               C.POINTER(RefParams), dp, C.POINTER(C.c_int64)]
+    L.ref_bench_gt.restype = C.c_double
     _lib = L
     return L
 
@@ -236,6 +239,21 @@ def codes_to_gt(row: np.ndarray, n: int) -> np.ndarray:
     out = np.empty(2 * max(n, 1), dtype=np.int32)
     lib().ref_codes_to_gt(_p(row, C.c_uint32), n, _p(out, C.c_int32))
     return out[: 2 * n]
+
+
+def bench_gt(gts_rows: np.ndarray, n: int, m: int, beta, eaf, params: RefParams):
+    """CPU baseline leg of bench.py: seconds for m rows of the literal per-row path (1 thread)."""
+    gts_rows = np.ascontiguousarray(gts_rows, dtype=np.int32)
+    n_distinct = gts_rows.shape[0]
+    assert gts_rows.shape[1] == 2 * n
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    eaf = np.ascontiguousarray(eaf, dtype=np.float64)
+    scores = np.empty(max(n, 1), dtype=np.float64)
+    nloci = C.c_int64(0)
+    secs = lib().ref_bench_gt(_p(gts_rows, C.c_int32), n_distinct, n, m, _p(beta, C.c_double),
+                              _p(eaf, C.c_double), C.byref(params), _p(scores, C.c_double),
+                              C.byref(nloci))
+    return float(secs), scores[:n], int(nloci.value)
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,61 @@
+"""CPU-side checks of the C-ABI: the library loads, exports every symbol include/nps.h declares,
+and refuses to compute without a GPU (no CPU fallback).  No compute calls are made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from nimpress_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nps.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nps_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), "libnps.so does not export %s" % name
+
+
+def test_abi_version_matches_header():
+    text = open(os.path.join(ROOT, "include", "nps.h")).read()
+    ver = int(re.search(r"#define NPS_ABI_VERSION (\d+)", text).group(1))
+    assert capi.load().nps_abi_version() == ver
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(capi.NpsParams) == 32
+    assert capi.STAT_DTYPE.itemsize == 32
+    assert capi.ROW_DESC_DTYPE.itemsize == 24
+    assert ctypes.sizeof(capi.NpsProfile) == 96
+
+
+def test_no_cpu_fallback_without_device():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible; the refusal path is covered on CPU-only hosts")
+    with pytest.raises(capi.NpsError) as ei:
+        capi.Scorer(6, capi.make_params())
+    assert ei.value.status == -2  # NPS_E_NODEVICE
+    with pytest.raises(capi.NpsError):
+        capi.Cohort(6, 4)
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under nimpress_amd/ may reference it
+    pkg = os.path.join(ROOT, "nimpress_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                for bad in ("import oracle", "from oracle", "librefcpu", "refcpu.h"):
+                    assert bad not in src, (f, bad)

@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP path behind the C-ABI (libnps.so) vs the CPU oracle.
+
+Bars (BASELINE.json north_star): nmissing / ngenotyped / neffect / used / reason / nloci bit-exact;
+scores within 1e-6 relative (floored) -- in practice ~1e-15.
+Every test calls through the C-ABI; the oracle is only the checker.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from nimpress_amd import capi
+from oracle import refcpu
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+
+
+def rel_err(got, ref, beta, nloci):
+    """max |d| / max(|ref|, 1e-12 * sum|beta| / (2 nloci))  -- SURVEY.md section 8(d)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN positions differ"
+    ok = ~np.isnan(ref)
+    if not ok.any():
+        return 0.0
+    floor = 1e-12 * float(np.sum(np.abs(beta))) / max(2.0 * nloci, 1.0)
+    return float(np.max(np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), max(floor, 1e-300))))
+
+
+def assert_stats_equal(gpu_stats, ref_stats):
+    assert len(gpu_stats) == len(ref_stats)
+    for k, (g, r) in enumerate(zip(gpu_stats, ref_stats)):
+        assert int(g["ngenotyped"]) == int(r[0]), (k, g, r)
+        assert int(g["nmissing"]) == int(r[1]), (k, g, r)
+        assert float(g["neffect"]) == float(r[2]), (k, g, r)
+        assert int(g["used"]) == int(r[3]), (k, g, r)
+        assert int(g["reason"]) == int(r[4]), (k, g, r)
+
+
+# ------------------------------------------------------------------------------------------
+# config 1: tests/set1 through the C-ABI, all 13 golden cases of the reference
+@pytest.fixture(scope="module")
+def set1(golden_dir):
+    score = refcpu.read_score_file(os.path.join(golden_dir, "set1.score"))
+    vcf = refcpu.read_vcf(os.path.join(golden_dir, "set1.vcf.gz"))
+    bed = refcpu.read_bed(os.path.join(golden_dir, "set1.bed"))
+    cases = json.load(open(os.path.join(golden_dir, "set1_cases.json")))["cases"]
+    return score, vcf, bed, cases
+
+
+def gpu_set1(score, vcf, bed, case):
+    """The row loop of computePolygenicScores with the per-row work on the GPU."""
+    sc = capi.Scorer(len(vcf.samples), capi.make_params(case["imp_locus"], case["imp_missing"],
+                                                        case["imp_sample"], case["maxmis"],
+                                                        case["mincs"]))
+    for e in score.entries:
+        rie = e.refseq == e.easeq
+        if case["restrict_to_covered"] and not refcpu.is_variant_covered(e, bed):
+            sc.push_locus(capi.ROW_UNCOVERED, rie, e.beta, e.eaf)
+            continue
+        rec = refcpu.find_variant(vcf, e)
+        if rec is None:
+            sc.push_locus(capi.ROW_ABSENT, rie, e.beta, e.eaf)
+            continue
+        if not case["ignore_filter"] and rec.filt not in (".", "PASS"):
+            sc.push_locus(capi.ROW_FILTERED, rie, e.beta, e.eaf)
+            continue
+        eaidx = 0 if rie else rec.alts.index(e.easeq) + 1
+        sc.push_gt(rec.gts, rec.ploidy, eaidx, rie, e.beta, e.eaf)
+    stats = sc.flush()
+    scores, nloci = sc.finish(score.offset)
+    sc.close()
+    return scores, nloci, stats
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_set1_golden_case(set1, idx):
+    score, vcf, bed, cases = set1
+    case = cases[idx]
+    scores, nloci, stats = gpu_set1(score, vcf, bed, case)
+    # (a) the reference's own expected values, tests/test_set1.nim tolerance 1e-4, NaN exact
+    for got, exp in zip(scores, case["expected"]):
+        assert (exp is None) == bool(np.isnan(got)), (scores, case["expected"])
+        if exp is not None:
+            assert abs(got - exp) <= 1e-4
+    # (b) the oracle, to the north-star bar
+    ref_scores, ref_nloci, ref_stats = refcpu.compute_polygenic_scores(
+        score, vcf, case["restrict_to_covered"], bed, case["imp_locus"], case["imp_missing"],
+        case["imp_sample"], case["maxmis"], case["mincs"], case["ignore_filter"])
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, ref_stats)
+    assert rel_err(scores, ref_scores, [e.beta for e in score.entries], max(nloci, 1)) <= REL_TOL
+
+
+def test_set1_cli_defaults(set1):
+    score, vcf, bed, _ = set1
+    case = dict(restrict_to_covered=False, imp_locus="ps", imp_missing="homref", imp_sample="int_ps",
+                maxmis=0.05, mincs=100, ignore_filter=False)
+    scores, nloci, stats = gpu_set1(score, vcf, bed, case)
+    assert nloci == 6
+    assert np.allclose(scores, 0.1545, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic cohorts
+def make_cohort(n, m, seed, rng, max_miss=0.1, force_missing_rows=True):
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, max_miss, m)
+    if force_missing_rows and m >= 8:
+        miss[::7] = 0.3          # exceed any maxmis <= 0.3 on some rows
+        miss[3] = 1.0 - 1e-9     # (almost) all missing
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    rie = (rng.uniform(size=m) < 0.25).astype(np.int32)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    codes = refcpu.synth_rows(n, 0, m, seed, th, tm, tmi)
+    return dict(n=n, m=m, eaf=eaf, beta=beta, rie=rie, th=th, tm=tm, tmi=tmi, codes=codes, seed=seed)
+
+
+def oracle_scores(co, params_kw, offset, kind=None):
+    p = refcpu.make_params(**params_kw)
+    kind = np.zeros(co["m"], np.int32) if kind is None else kind
+    n_present = int((kind == 0).sum())
+    return refcpu.score_packed(co["codes"][:n_present], co["n"], kind, co["rie"], co["beta"],
+                               co["eaf"], p, offset)
+
+
+def test_synth_matches_oracle():
+    rng = np.random.default_rng(11)
+    for n, m in [(1, 3), (15, 4), (16, 5), (17, 6), (1000, 33), (4097, 9)]:
+        co = make_cohort(n, m, 1234 + n, rng)
+        dev = capi.Cohort(n, m)
+        dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+        got = dev.download(0, m)
+        dev.close()
+        assert np.array_equal(got, co["codes"][:, : (n + 15) // 16]), (n, m)
+
+
+PARAM_GRID = [
+    dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=100),
+    dict(imp_locus="homref", imp_missing="ignore", imp_sample="ps", maxmis=0.2, mincs=0),
+    dict(imp_locus="ignore", imp_missing="homref", imp_sample="homref", maxmis=0.05, mincs=100),
+    dict(imp_locus="fail", imp_missing="homref", imp_sample="int_ps", maxmis=0.5, mincs=10),
+    dict(imp_locus="ps", imp_missing="homref", imp_sample="fail", maxmis=1.0, mincs=100),
+    dict(imp_locus="ps", imp_missing="homref", imp_sample="int_fail", maxmis=1.0, mincs=3000),
+    dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=1.0, mincs=3000),
+]
+
+
+@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
+@pytest.mark.parametrize("shape", [(1, 1), (6, 7), (16, 4), (17, 5), (255, 13), (2049, 37),
+                                   (5000, 130)])
+def test_streaming_packed_vs_oracle(pk, shape):
+    n, m = shape
+    rng = np.random.default_rng(100 * pk + n)
+    co = make_cohort(n, m, 777 + pk, rng)
+    kw = PARAM_GRID[pk]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for j in range(m):
+        sc.push_packed(co["codes"][j], co["rie"][j], co["beta"][j], co["eaf"][j])
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.25)
+    sc.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.25)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+@pytest.mark.parametrize("pk", [0, 1, 3])
+def test_streaming_gt_decode_vs_oracle(pk):
+    """raw bcf_get_genotypes buffers (int32) decoded on the device, incl. phased, half-missing,
+    haploid-padded and multi-allelic calls."""
+    n, m = 777, 21
+    rng = np.random.default_rng(5 + pk)
+    kw = PARAM_GRID[pk]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    ref = refcpu.RefScorer(n, refcpu.make_params(**kw))
+    betas = []
+    for j in range(m):
+        ploidy = 1 if j % 5 == 4 else 2
+        n_alt = 1 + j % 3
+        eaidx = int(rng.integers(0, n_alt + 1))
+        alle = rng.integers(-1, n_alt + 1, size=(n, ploidy))            # -1 = missing allele
+        alle[rng.uniform(size=n) < 0.03] = -1
+        phased = rng.integers(0, 2, size=(n, ploidy))
+        gts = ((alle + 1) << 1) | phased
+        gts = gts.astype(np.int32)
+        if ploidy == 2:
+            hap = rng.uniform(size=n) < 0.05                              # haploid call, padded
+            gts[hap, 1] = -2147483647
+        beta, eaf = float(rng.normal(0, 0.1)), float(rng.uniform(0.05, 0.6))
+        rie = eaidx == 0
+        sc.push_gt(gts.ravel(), ploidy, eaidx, rie, beta, eaf)
+        ref.row_gt(gts.ravel(), ploidy, eaidx, rie, beta, eaf)
+        betas.append(beta)
+        if j % 6 == 2:
+            kind = [capi.ROW_UNCOVERED, capi.ROW_ABSENT, capi.ROW_FILTERED][j % 3]
+            sc.push_locus(kind, rie, beta * 0.5, eaf)
+            ref.row_locus(kind, rie, beta * 0.5, eaf)
+            betas.append(beta * 0.5)
+    stats = sc.flush()
+    scores, nloci = sc.finish(-1.5)
+    sc.close()
+    ref_scores, ref_nloci = ref.finish(-1.5)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, ref.stats)
+    assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
+
+
+@pytest.mark.parametrize("mode", [capi.MODE_TWOPASS, capi.MODE_AUTO])
+@pytest.mark.parametrize("shape", [(33, 1), (100, 3), (1000, 64), (4096, 257), (20000, 1001)])
+def test_resident_cohort_vs_oracle(shape, mode):
+    n, m = shape
+    rng = np.random.default_rng(n + m)
+    co = make_cohort(n, m, 4242, rng)
+    kw = PARAM_GRID[0]
+    dev = capi.Cohort(n, m)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, mode)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+def test_resident_mixed_kinds_and_upload():
+    """uploaded (not synthesised) rows, interleaved with rows that have no genotype data"""
+    n, m = 999, 50
+    rng = np.random.default_rng(9)
+    co = make_cohort(n, m, 1, rng)
+    kind = np.zeros(m, np.int32)
+    kind[[2, 11, 12, 30, 49]] = [1, 2, 3, 2, 1]
+    n_present = int((kind == 0).sum())
+    kw = PARAM_GRID[1]
+    dev = capi.Cohort(n, n_present)
+    dev.upload(0, co["codes"][:n_present])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], kind, co["rie"]))
+    stats = sc.flush()
+    scores, nloci = sc.finish(1.0)
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 1.0, kind)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+    sc.close()
+    dev.close()
+
+
+def test_batch_rollover_and_reset():
+    """more rows than one device batch holds (batch cap 4096 rows at small N), then reuse"""
+    n, m = 40, 4500
+    rng = np.random.default_rng(3)
+    co = make_cohort(n, m, 17, rng, force_missing_rows=False)
+    kw = PARAM_GRID[0]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for rep in range(2):
+        for j in range(m):
+            sc.push_packed(co["codes"][j], co["rie"][j], co["beta"][j], co["eaf"][j])
+        stats = sc.flush()
+        scores, nloci = sc.finish(0.5)
+        ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.5)
+        assert nloci == ref_nloci
+        assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+        assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+        sc.reset()
+    sc.close()
+
+
+def test_empty_inputs():
+    # no rows at all: nloci = 0 -> 0/0 = NaN for every sample (nimpress.nim:645)
+    sc = capi.Scorer(5, capi.make_params())
+    scores, nloci = sc.finish(0.1)
+    assert nloci == 0 and np.isnan(scores).all()
+    sc.close()
+    # every row ignored
+    sc = capi.Scorer(5, capi.make_params(imp_locus="ignore", imp_missing="ignore"))
+    sc.push_locus(capi.ROW_ABSENT, False, 0.3, 0.2)
+    sc.push_locus(capi.ROW_UNCOVERED, False, 0.3, 0.2)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.1)
+    assert nloci == 0 and np.isnan(scores).all() and [int(s["used"]) for s in stats] == [0, 0]
+    sc.close()
+
+
+def test_nan_eaf_and_fail_propagation():
+    n = 64
+    rng = np.random.default_rng(21)
+    co = make_cohort(n, 8, 5, rng, force_missing_rows=False)
+    co["eaf"][2] = np.nan   # makescore.R:533 writes NaN eaf; ps then imputes NaN
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="ps", maxmis=1.0, mincs=0)
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for j in range(8):
+        sc.push_packed(co["codes"][j], co["rie"][j], co["beta"][j], co["eaf"][j])
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    ref_scores, _, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert rel_err(scores, ref_scores, co["beta"], nloci) <= REL_TOL
+
+
+def test_bad_arguments_are_errors_not_aborts():
+    sc = capi.Scorer(4, capi.make_params())
+    with pytest.raises(capi.NpsError) as ei:
+        sc.push_gt(np.zeros(12, np.int32), 3, 1, False, 0.1, 0.1)     # ploidy 3
+    assert ei.value.status == -6
+    with pytest.raises(capi.NpsError):
+        sc.push_locus(0, False, 0.1, 0.1)                              # PRESENT is not a no-data kind
+    with pytest.raises(capi.NpsError):
+        sc.push_gt(np.zeros(8, np.int32), 2, -1, False, 0.1, 0.1)     # eaidx < 0 (nimpress.nim:380)
+    sc.close()
+    with pytest.raises(capi.NpsError):
+        capi.Scorer(4, capi.NpsParams(9, 0, 0, 0, 0.05, 100))
+
+
+def test_linearity_property_large():
+    """size-independent property at a size the oracle would not finish quickly:
+    scores(beta1 + beta2) - offset == (scores(beta1) - offset) + (scores(beta2) - offset) when no
+    imputation value depends on beta (it never does) -- checked on 100k samples x 4096 rows."""
+    n, m = 100_000, 4096
+    rng = np.random.default_rng(77)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0, 0.04, m)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m)
+    dev.synth(0, 99, th, tm, tmi)
+    b1 = np.round(rng.normal(0, 0.02, m), 4)
+    b2 = np.round(rng.normal(0, 0.02, m), 4)
+    outs = []
+    for b in (b1, b2, b1 + b2):
+        sc = capi.Scorer(n, capi.make_params())
+        sc.score_cohort(dev, capi.row_descs(b, eaf))
+        s, nloci = sc.finish(0.0)
+        assert nloci == m
+        outs.append(s)
+        sc.close()
+    dev.close()
+    scale = np.sum(np.abs(b1) + np.abs(b2)) / (2 * m)
+    assert np.max(np.abs(outs[2] - (outs[0] + outs[1]))) <= 1e-12 * scale * 10
