@@ -100,6 +100,11 @@ struct nps_ctx {
     unsigned long long *d_rtally = nullptr;
     double *d_rlut = nullptr;
     nps_locus_stat *d_rstats = nullptr;
+    double *d_part_fused = nullptr;         // [Q][team stride] partial scores of the fused kernel
+    uint64_t part_fused_cap = 0;            // doubles
+    unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernel
+    unsigned int *h_timeout = nullptr;      // pinned copy, checked at the next synchronisation
+    bool timeout_check = false;
     bool res_pending = false;               // stats of the last resident run still on the device
     uint64_t res_m = 0;
     std::vector<int64_t> res_index;
@@ -228,6 +233,9 @@ static void free_ctx(nps_ctx *c) {
         (void)hipHostFree(c->h_raw[k]);
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
     }
+    (void)hipFree(c->d_part_fused);
+    (void)hipFree(c->d_timeout);
+    (void)hipHostFree(c->h_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -249,6 +257,8 @@ static int zero_state(nps_ctx *c) {
     c->pending.clear();
     c->ready.clear();
     c->ready_cursor = 0;
+    c->timeout_check = false;
+    *c->h_timeout = 0;
     c->res_pending = false;  // unflushed stats of a resident run are dropped, never copied
     c->res_index.clear();
     c->res_host_stats.clear();
@@ -309,6 +319,9 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipMalloc(&c->d_part, sizeof(double) * c->n_chunks * c->geom.part_chunk_stride));
     CTX_TRY(hipMalloc(&c->d_scores, sizeof(double) * std::max<uint64_t>(c->n, 1)));
     CTX_TRY(hipMalloc(&c->d_nloci, sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc(&c->d_timeout, 16));
+    CTX_TRY(hipHostMalloc(&c->h_timeout, 16));
+    *c->h_timeout = 0;
 #undef CTX_TRY
     rc = zero_state(c);
     if (rc) {
@@ -368,6 +381,7 @@ static void host_locus_row(nps_ctx *c, int kind, int rie, double beta, double ea
 }
 
 static int materialize_resident_stats(nps_ctx *c);
+static int check_timeout(nps_ctx *c);
 
 // run the open batch: params -> accumulate; then collect its stats
 static int run_batch(nps_ctx *c) {
@@ -508,6 +522,8 @@ extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size
     rc = run_batch(c);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = check_timeout(c);
+    if (rc) return rc;
     size_t n = 0;
     if (stats_out) {
         while (c->ready_cursor < c->ready.size() && n < cap) stats_out[n++] = c->ready[c->ready_cursor++];
@@ -520,12 +536,26 @@ extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size
     return NPS_OK;
 }
 
+// after a stream synchronisation: did a bounded wait inside the fused kernel expire?
+static int check_timeout(nps_ctx *c) {
+    if (!c->timeout_check) return NPS_OK;
+    c->timeout_check = false;
+    if (*c->h_timeout) {
+        *c->h_timeout = 0;
+        return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
+                                   "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
+    }
+    return NPS_OK;
+}
+
 static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nloci_out) {
     int rc = run_batch(c);
     if (rc) return rc;
     unsigned long long dev_nloci = 0;
     HIP_TRY(hipMemcpyAsync(&dev_nloci, c->d_nloci, sizeof dev_nloci, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = check_timeout(c);
+    if (rc) return rc;
     const uint64_t nloci = c->host_nloci + dev_nloci;
     if (nloci_out) *nloci_out = nloci;
     if (c->n) {
@@ -766,6 +796,9 @@ static int materialize_resident_stats(nps_ctx *c) {
 static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     if (m_pad <= c->res_cap) return NPS_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_part_fused);
+    (void)hipFree(c->d_timeout);
+    (void)hipHostFree(c->h_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -791,8 +824,16 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (co->format != NPS_FMT_GT2) return fail(NPS_E_UNSUPPORTED, "cohort format not supported");
     if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
-    if (mode == NPS_MODE_FUSED) return fail(NPS_E_UNSUPPORTED, "fused mode not built yet");
     HIP_TRY(hipSetDevice(c->device));
+    FusedPlan plan;
+    if (mode != NPS_MODE_TWOPASS) {
+        HIP_TRY(fused_plan(c->device, c->n, def->m, &plan));
+        if (const char *e = getenv("NPS_DISABLE_FUSED"))
+            if (*e == '1' && mode == NPS_MODE_AUTO) plan.ok = false;
+        if (!plan.ok && mode == NPS_MODE_FUSED && c->n && def->m)
+            return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the fused "
+                        "persistent grid", (unsigned long long)c->n, (unsigned long long)def->m);
+    }
     int rc = run_batch(c);  // keep push order: finish whatever was streamed before
     if (rc) return rc;
     rc = materialize_resident_stats(c);
@@ -814,11 +855,47 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     c->res_pending = true;
     if (m == 0) return NPS_OK;
 
-    const uint64_t m_pad = (m + 3) / 4 * 4;
+    const uint64_t m_pad = (m + 15) / 16 * 16;
     rc = ensure_resident_buffers(c, m_pad);
     if (rc) return rc;
     const uint64_t stride_words = co->stride_bytes / 4;
     const uint32_t *codes = (const uint32_t *)co->d_data + cohort_row0 * stride_words;
+    if (plan.ok && c->n) {
+        // fused single-read path
+        const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
+        if (need > c->part_fused_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_part_fused);
+            c->d_part_fused = nullptr;
+            c->part_fused_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_part_fused, sizeof(double) * need));
+            c->part_fused_cap = need;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_rtally, 0, sizeof(unsigned long long) * m_pad, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_timeout, 0, 16, c->stream));
+        hipError_t fe;
+        {
+            ProfScope ps(c, P_FUSED);
+            fe = launch_fused(c->stream, plan, codes, stride_words, c->n, m, def->d_desc,
+                              dev_params(c->params), c->d_rtally, c->d_rstats, c->d_nloci,
+                              c->d_part_fused, c->d_timeout);
+        }
+        if (fe == hipSuccess) {
+            {
+                ProfScope ps(c, P_REDUCE);
+                HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n,
+                                    c->d_part));
+            }
+            HIP_TRY(hipMemcpyAsync(c->h_timeout, c->d_timeout, sizeof(unsigned int),
+                                   hipMemcpyDeviceToHost, c->stream));
+            c->timeout_check = true;
+            return NPS_OK;
+        }
+        // the runtime refused the cooperative grid (it would not be fully resident): nothing ran
+        (void)hipGetLastError();
+        if (mode == NPS_MODE_FUSED || fe != hipErrorCooperativeLaunchTooLarge)
+            return fail(NPS_E_HIP, "fused kernel launch failed: %s", hipGetErrorString(fe));
+    }
     // rows per tally/accumulate pair; default ~96 MB so the second read can hit the 256 MB
     // Infinity Cache
     uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);

@@ -62,4 +62,22 @@ hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_wo
                            const uint32_t *d_t_het, const uint32_t *d_t_hom,
                            const uint32_t *d_t_miss);
 
+// ---- fused single-read kernel (nps_fused.hip) ---------------------------------------------
+struct FusedPlan {
+    bool ok = false;       // shape fits the persistent grid
+    uint32_t threads = 0;  // workgroup size
+    uint32_t P = 0, Q = 0; // slices per team, teams
+    uint32_t n_batches = 0;
+    uint64_t part_team_stride = 0;  // doubles per team in the partial-score buffer
+};
+hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan);
+// d_tally: [plan.n_batches*16] zeroed; d_part: [Q*part_team_stride]; d_timeout: zeroed word
+hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d_codes,
+                        uint64_t stride_words, uint64_t n_samples, uint64_t n_rows,
+                        const nps_row_desc *d_desc, DevParams prm, unsigned long long *d_tally,
+                        nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
+                        unsigned int *d_timeout);
+hipError_t launch_fold(hipStream_t st, const double *d_part, uint32_t Q, uint64_t team_stride,
+                       uint64_t n_samples, double *d_part0);
+
 }  // namespace nps

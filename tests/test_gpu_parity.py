@@ -210,13 +210,16 @@ def test_streaming_gt_decode_vs_oracle(pk):
     assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
 
 
-@pytest.mark.parametrize("mode", [capi.MODE_TWOPASS, capi.MODE_AUTO])
-@pytest.mark.parametrize("shape", [(33, 1), (100, 3), (1000, 64), (4096, 257), (20000, 1001)])
+@pytest.mark.parametrize("mode", [capi.MODE_TWOPASS, capi.MODE_FUSED, capi.MODE_AUTO])
+@pytest.mark.parametrize("shape", [(33, 1), (100, 3), (1000, 64), (4096, 257), (20000, 1001),
+                                   (16385, 47), (40000, 160), (1, 50), (70000, 33)])
 def test_resident_cohort_vs_oracle(shape, mode):
+    """two-pass kernels, the fused single-read persistent kernel (1, 2, 3 and 5 sample slices per
+    team; ragged last batch; fewer batches than CUs) and AUTO all against the oracle"""
     n, m = shape
     rng = np.random.default_rng(n + m)
     co = make_cohort(n, m, 4242, rng)
-    kw = PARAM_GRID[0]
+    kw = PARAM_GRID[(n + m) % len(PARAM_GRID)]
     dev = capi.Cohort(n, m)
     dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
     sc = capi.Scorer(n, capi.make_params(**kw))
@@ -229,6 +232,61 @@ def test_resident_cohort_vs_oracle(shape, mode):
     assert nloci == ref_nloci
     assert_stats_equal(stats, [tuple(s) for s in ref_stats])
     assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
+def test_fused_all_imputation_modes(pk):
+    n, m = 3000, 200
+    rng = np.random.default_rng(900 + pk)
+    co = make_cohort(n, m, 31 + pk, rng)
+    kw = PARAM_GRID[pk]
+    dev = capi.Cohort(n, m)
+    dev.upload(0, co["codes"])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, capi.MODE_FUSED)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.125)
+    sc.close()
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.125)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+def test_fused_equals_twopass_large():
+    """500 000 samples x 4096 rows (31 slices x 8 teams, the bench geometry): the two HIP paths
+    must agree -- tallies bit for bit, scores to rounding -- at a size the oracle cannot reach."""
+    n, m = 500_000, 4096
+    rng = np.random.default_rng(123)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0, 0.02, m)
+    miss[::100] = 0.1
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m)
+    dev.synth(0, 5, th, tm, tmi)
+    res = []
+    for mode in (capi.MODE_TWOPASS, capi.MODE_FUSED):
+        sc = capi.Scorer(n, capi.make_params())
+        sc.score_cohort(dev, capi.row_descs(beta, eaf), 0, mode)
+        stats = sc.flush()
+        scores, nloci = sc.finish(0.0)
+        res.append((stats, scores, nloci))
+        sc.close()
+    dev.close()
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0])
+    assert int((res[0][0]["reason"] == capi.REASON_MAXMIS).sum()) >= 30
+    scale = np.sum(np.abs(beta)) / (2 * res[0][2])
+    assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-12 * scale
+    # spot-check 3 rows' tallies against the oracle's generator (full width, CPU seconds)
+    for j in (0, 100, 4095):
+        codes = refcpu.synth_rows(n, j, 1, 5, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
+        c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
+        code = (c[:, 0] + 2 * c[:, 1])[:n]
+        assert int((code == 3).sum()) == int(res[1][0]["nmissing"][j])
+        assert int((code == 1).sum() + 2 * (code == 2).sum()) == int(res[1][0]["neffect"][j])
 
 
 def test_resident_mixed_kinds_and_upload():
