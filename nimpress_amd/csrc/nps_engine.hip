@@ -83,6 +83,7 @@ struct nps_ctx {
     int32_t *d_raw = nullptr;               // raw FORMAT staging for one row (n*2 int32)
     static constexpr int kRawSlots = 2;
     int32_t *h_raw[kRawSlots] = {nullptr, nullptr};  // pinned staging ring for caller buffers
+    void *h_arena = nullptr;  // ONE pinned allocation holding h_desc, h_stats and h_raw[]
     hipEvent_t ev_raw[kRawSlots] = {nullptr, nullptr};
     int raw_next = 0;
 
@@ -103,7 +104,7 @@ struct nps_ctx {
     double *d_part_fused = nullptr;         // [Q][team stride] partial scores of the fused kernel
     uint64_t part_fused_cap = 0;            // doubles
     unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernel
-    unsigned int *h_timeout = nullptr;      // pinned copy, checked at the next synchronisation
+    unsigned int h_timeout = 0;             // host copy, checked at the next synchronisation
     bool timeout_check = false;
     bool res_pending = false;               // stats of the last resident run still on the device
     uint64_t res_m = 0;
@@ -224,18 +225,14 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_codes);
     (void)hipFree(c->d_tally);
     (void)hipFree(c->d_desc);
-    (void)hipHostFree(c->h_desc);
+    (void)hipHostFree(c->h_arena);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_stats);
-    (void)hipHostFree(c->h_stats);
     (void)hipFree(c->d_raw);
-    for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
-        (void)hipHostFree(c->h_raw[k]);
+    for (int k = 0; k < nps_ctx::kRawSlots; ++k)
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
-    }
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
-    (void)hipHostFree(c->h_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -258,7 +255,7 @@ static int zero_state(nps_ctx *c) {
     c->ready.clear();
     c->ready_cursor = 0;
     c->timeout_check = false;
-    *c->h_timeout = 0;
+    c->h_timeout = 0;
     c->res_pending = false;  // unflushed stats of a resident run are dropped, never copied
     c->res_index.clear();
     c->res_host_stats.clear();
@@ -307,21 +304,37 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipMemsetAsync(c->d_codes, 0, row_bytes * c->batch_cap, c->stream));
     CTX_TRY(hipMalloc(&c->d_tally, sizeof(unsigned long long) * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_desc, sizeof(nps_row_desc) * c->batch_cap));
-    CTX_TRY(hipHostMalloc(&c->h_desc, sizeof(nps_row_desc) * c->batch_cap));
+    {
+        // One pinned arena, carved at 4 KiB boundaries and padded to 64 KiB.  (Several tiny
+        // hipHostMalloc blocks proved fragile: a 16-byte one became unmapped after later hipMalloc
+        // calls under the HIP runtime that ships inside the PyTorch wheel.)
+        auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
+        const size_t sz_desc = up(sizeof(nps_row_desc) * c->batch_cap);
+        const size_t sz_stats = up(sizeof(nps_locus_stat) * c->batch_cap);
+        const size_t sz_raw = up(sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1));
+        size_t total = sz_desc + sz_stats + nps_ctx::kRawSlots * sz_raw;
+        total = (total + 65535) / 65536 * 65536;
+        CTX_TRY(hipHostMalloc(&c->h_arena, total));
+        char *p = (char *)c->h_arena;
+        c->h_desc = (nps_row_desc *)p;
+        p += sz_desc;
+        c->h_stats = (nps_locus_stat *)p;
+        p += sz_stats;
+        for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
+            c->h_raw[k] = (int32_t *)p;
+            p += sz_raw;
+        }
+    }
     CTX_TRY(hipMalloc(&c->d_lut, sizeof(double) * 4 * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_stats, sizeof(nps_locus_stat) * c->batch_cap));
-    CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(nps_locus_stat) * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_raw, sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1)));
     for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
-        CTX_TRY(hipHostMalloc(&c->h_raw[k], sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1)));
         CTX_TRY(hipEventCreateWithFlags(&c->ev_raw[k], hipEventDisableTiming));
     }
     CTX_TRY(hipMalloc(&c->d_part, sizeof(double) * c->n_chunks * c->geom.part_chunk_stride));
     CTX_TRY(hipMalloc(&c->d_scores, sizeof(double) * std::max<uint64_t>(c->n, 1)));
-    CTX_TRY(hipMalloc(&c->d_nloci, sizeof(unsigned long long)));
-    CTX_TRY(hipMalloc(&c->d_timeout, 16));
-    CTX_TRY(hipHostMalloc(&c->h_timeout, 16));
-    *c->h_timeout = 0;
+    CTX_TRY(hipMalloc(&c->d_nloci, 256));
+    CTX_TRY(hipMalloc(&c->d_timeout, 256));
 #undef CTX_TRY
     rc = zero_state(c);
     if (rc) {
@@ -540,8 +553,8 @@ extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size
 static int check_timeout(nps_ctx *c) {
     if (!c->timeout_check) return NPS_OK;
     c->timeout_check = false;
-    if (*c->h_timeout) {
-        *c->h_timeout = 0;
+    if (c->h_timeout) {
+        c->h_timeout = 0;
         return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
                                    "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
     }
@@ -798,7 +811,6 @@ static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
-    (void)hipHostFree(c->h_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -886,7 +898,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n,
                                     c->d_part));
             }
-            HIP_TRY(hipMemcpyAsync(c->h_timeout, c->d_timeout, sizeof(unsigned int),
+            HIP_TRY(hipMemcpyAsync(&c->h_timeout, c->d_timeout, sizeof(unsigned int),
                                    hipMemcpyDeviceToHost, c->stream));
             c->timeout_check = true;
             return NPS_OK;

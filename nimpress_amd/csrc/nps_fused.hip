@@ -394,6 +394,7 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
 hipError_t launch_fold(hipStream_t st, const double *d_part, uint32_t Q, uint64_t team_stride,
                        uint64_t n_samples, double *d_part0) {
     if (n_samples == 0 || Q == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(fold_kernel, dim3((uint32_t)((n_samples + 255) / 256)), dim3(256), 0, st,
                        d_part, Q, team_stride, n_samples, d_part0);
     return hipGetLastError();

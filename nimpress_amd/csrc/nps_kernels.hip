@@ -105,6 +105,7 @@ hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, in
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     if (ploidy == 2)
         hipLaunchKernelGGL(decode_gt_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
                            eaidx, d_row, d_tally);
@@ -163,11 +164,13 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
     const uint32_t n_vec4 = (uint32_t)((n_words + 3) / 4);
     if (n_words >= 1024) {
         if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
+        (void)hipGetLastError();  // drop any stale sticky error: report this launch only
         hipLaunchKernelGGL(tally_packed_kernel<256>, dim3((uint32_t)n_rows), dim3(256), 0, st,
                            d_codes, stride_words, n_vec4, n_rows, d_tally);
     } else {
         const uint64_t blocks = (n_rows + 3) / 4;
         if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+        (void)hipGetLastError();  // drop any stale sticky error: report this launch only
         hipLaunchKernelGGL(tally_packed_kernel<64>, dim3((uint32_t)blocks), dim3(256), 0, st,
                            d_codes, stride_words, n_vec4, n_rows, d_tally);
     }
@@ -249,6 +252,7 @@ hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,
                              unsigned long long *d_nloci) {
     if (n_rows_pad == 0) return hipSuccess;
     const uint64_t blocks = (n_rows_pad + 255) / 256;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(row_params_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_tally, d_desc,
                        n_rows, n_rows_pad, n_samples, p, d_lut, d_stats, d_nloci);
     return hipGetLastError();
@@ -345,6 +349,7 @@ hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t s
     const uint32_t tiles = (g.n_words + kAccThreads - 1) / kAccThreads;
     if (g.n_chunks == 0 || g.n_chunks > 65535 || g.groups_per_chunk == 0) return hipErrorInvalidValue;
     if ((uint64_t)g.n_chunks * g.groups_per_chunk < n_groups) return hipErrorInvalidValue;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(accumulate_kernel, dim3(tiles, g.n_chunks), dim3(kAccThreads), 0, st, d_codes,
                        stride_words, n_rows, g.n_words, d_lut, n_groups, g.groups_per_chunk, d_part,
                        g.part_chunk_stride);
@@ -372,6 +377,7 @@ hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks
                          double denom, double offset, double *d_scores) {
     if (n_samples == 0) return hipSuccess;
     const uint64_t blocks = (n_samples + 255) / 256;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(finish_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_part, n_chunks,
                        part_chunk_stride, n_samples, const_sum, denom, offset, d_scores);
     return hipGetLastError();
@@ -420,6 +426,7 @@ hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_wo
     if (n_rows == 0 || n_words == 0) return hipSuccess;
     // grid.y <= 65535: caller splits larger row ranges
     if (n_rows > 65535) return hipErrorInvalidValue;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(synth_gt_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)n_rows),
                        dim3(256), 0, st, d_codes, stride_words, n_samples, (uint32_t)n_words, row0,
                        seed, d_t_het, d_t_hom, d_t_miss);
