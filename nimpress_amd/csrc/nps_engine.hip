@@ -305,9 +305,7 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipMalloc(&c->d_tally, sizeof(unsigned long long) * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_desc, sizeof(nps_row_desc) * c->batch_cap));
     {
-        // One pinned arena, carved at 4 KiB boundaries and padded to 64 KiB.  (Several tiny
-        // hipHostMalloc blocks proved fragile: a 16-byte one became unmapped after later hipMalloc
-        // calls under the HIP runtime that ships inside the PyTorch wheel.)
+        // One pinned arena for all host staging, carved at 4 KiB boundaries, padded to 64 KiB.
         auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
         const size_t sz_desc = up(sizeof(nps_row_desc) * c->batch_cap);
         const size_t sz_stats = up(sizeof(nps_locus_stat) * c->batch_cap);
@@ -809,8 +807,6 @@ static int materialize_resident_stats(nps_ctx *c) {
 static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     if (m_pad <= c->res_cap) return NPS_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_part_fused);
-    (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
