@@ -835,7 +835,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     HIP_TRY(hipSetDevice(c->device));
     FusedPlan plan;
     if (mode != NPS_MODE_TWOPASS) {
-        HIP_TRY(fused_plan(c->device, c->n, def->m, &plan));
+        HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0), &plan));
         if (const char *e = getenv("NPS_DISABLE_FUSED"))
             if (*e == '1' && mode == NPS_MODE_AUTO) plan.ok = false;
         if (!plan.ok && mode == NPS_MODE_FUSED && c->n && def->m)
