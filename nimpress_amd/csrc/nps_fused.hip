@@ -22,6 +22,7 @@
 //
 // HBM traffic = the matrix once (+ 8 B of atomics per row per slice, + row descriptors).
 #include <algorithm>
+#include <cstdlib>
 
 #include "nps_kernels.h"
 
@@ -47,6 +48,8 @@ struct FusedArgs {
     double *part;               // [Q][part_team_stride]
     uint64_t part_team_stride;
     unsigned int *timeout;      // zeroed before the launch
+    unsigned long long *telemetry;  // 8 counters (control-wave variant), zeroed before the launch
+    int dbg_same_rows;              // diagnostics only: every batch re-reads rows 0..15 (L2 hits)
 };
 
 // ---- DPP helpers --------------------------------------------------------------------------
@@ -67,25 +70,49 @@ static __device__ __forceinline__ uint32_t tally_pack(uint32_t w) {
     return (t << 16) | m;
 }
 
-// 4 rows x 16 samples of 2-bit codes -> 16 byte indices, then the bank-spreading fold
-// e -> e ^ (e >> 5) (tables are stored at the folded position).  x[q] byte k = sample 4k+q.
+// Table index of a sample in a group of 4 rows with codes c0..c3: the four LOW code bits in the low
+// nibble, the four HIGH code bits in the high nibble.  Codes 0/1 (hom-ref, het) dominate real
+// genotypes, so the low nibble carries most of the entropy and lands in the LDS bank-select bits:
+// 2.6 LDS cycles per 32-lane lookup on HWE genotypes against 3.3 for the naive c0|c1<<2|c2<<4|c3<<6,
+// with no extra VALU work (this kernel is VALU-issue bound: every instruction counts).
+static __host__ __device__ __forceinline__ int table_index(int c0, int c1, int c2, int c3) {
+    return (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c3 & 1) << 3) | ((c0 >> 1) << 4) |
+           ((c1 >> 1) << 5) | ((c2 >> 1) << 6) | ((c3 >> 1) << 7);
+}
+
+// (a & m) | (b & ~m) as ONE instruction.  Written as asm because hipcc (ROCm 7.2) otherwise breaks
+// the three merge stages below into separate v_and / v_bitop3 ops (~70 instead of 24 per group), and
+// this kernel is bound by VALU issue.  m is wave-uniform (SGPR).
+static __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(m), "v"(a), "v"(b));
+    return d;
+}
+
+// 4 rows x 16 samples of 2-bit codes -> 16 table indices in 24 VALU ops (3 stages x 4 merges, each a
+// shift + v_bfi): x[q] byte k = table_index of sample 4k+q.
 static __device__ __forceinline__ void transpose_fold_4x16(uint32_t w0, uint32_t w1, uint32_t w2,
                                                            uint32_t w3, uint32_t (&x)[4]) {
-    const uint32_t m2 = 0x33333333u, m4 = 0x0F0F0F0Fu;
-    const uint32_t e01 = (w0 & m2) | ((w1 << 2) & ~m2);
-    const uint32_t o01 = ((w0 >> 2) & m2) | (w1 & ~m2);
-    const uint32_t e23 = (w2 & m2) | ((w3 << 2) & ~m2);
-    const uint32_t o23 = ((w2 >> 2) & m2) | (w3 & ~m2);
-    x[0] = (e01 & m4) | ((e23 << 4) & ~m4);
-    x[1] = (o01 & m4) | ((o23 << 4) & ~m4);
-    x[2] = ((e01 >> 4) & m4) | (e23 & ~m4);
-    x[3] = ((o01 >> 4) & m4) | (o23 & ~m4);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) x[q] ^= (x[q] >> 5) & 0x07070707u;
+    const uint32_t m1 = 0x55555555u, m2 = 0x33333333u, m4 = 0x0F0F0F0Fu;
+    // stage 1: per sample a 2-bit field with the same-plane bits of two rows
+    const uint32_t l01 = bfi(m1, w0, w1 << 1);
+    const uint32_t h01 = bfi(m1, w0 >> 1, w1);
+    const uint32_t l23 = bfi(m1, w2, w3 << 1);
+    const uint32_t h23 = bfi(m1, w2 >> 1, w3);
+    // stage 2: nibbles (four rows, one plane) of the even / odd samples
+    const uint32_t le = bfi(m2, l01, l23 << 2);
+    const uint32_t lo = bfi(m2, l01 >> 2, l23);
+    const uint32_t he = bfi(m2, h01, h23 << 2);
+    const uint32_t ho = bfi(m2, h01 >> 2, h23);
+    // stage 3: bytes = low-plane nibble | high-plane nibble << 4
+    x[0] = bfi(m4, le, he << 4);   // samples 0,4,8,12
+    x[2] = bfi(m4, le >> 4, he);   // samples 2,6,10,14
+    x[1] = bfi(m4, lo, ho << 4);   // samples 1,5,9,13
+    x[3] = bfi(m4, lo >> 4, ho);   // samples 3,7,11,15
 }
 
 // LDS layout (bytes)
-//   [0, 8192)        float64 tables, 4 groups x 256 entries (folded index)
+//   [0, 8192)        float64 tables, 4 groups x 256 entries (table_index order)
 //   [8192, 8704)     row LUTs of the batch being consumed, 16 rows x 4 float64
 //   [8704, 8832)     partial tallies, 2 parities x 16 rows x uint32
 struct __attribute__((aligned(16))) FusedLds {
@@ -98,11 +125,10 @@ struct __attribute__((aligned(16))) FusedLds {
 // Row LUT from a complete tally word: the maxmis decision (nimpress.nim:565-571), the locus constant
 // (:417-447) or the sample imputation value (:450-481).  One lane per row.
 static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long long x, uint64_t row,
-                                               bool write_stats, double (&v)[4], int &used) {
+                                               double beta, double eaf, bool rie, bool write_stats,
+                                               double (&v)[4], int &used) {
     const uint64_t nmiss = (x >> 28) & 0xFFFFFFFull, neff = x & 0xFFFFFFFull;
     const uint64_t ngen = a.n_samples - nmiss;
-    const double beta = a.desc[row].beta, eaf = a.desc[row].eaf;
-    const bool rie = a.desc[row].ref_is_effect != 0;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     int reason;
     used = 0;
@@ -158,7 +184,7 @@ static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long
 //   --- barrier Y
 //   S6  accumulate batch k from the ring registers: ds_read_b64 + v_add_f64 per 4 genotypes
 template <int T>
-__global__ __launch_bounds__(T, 4) void fused_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(T, (T >= 1024 ? 4 : T >= 768 ? 3 : 4)) void fused_kernel(const FusedArgs a) {
     static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "workgroup size");
     __shared__ FusedLds lds;
     const int tid = threadIdx.x;
@@ -289,7 +315,9 @@ __global__ __launch_bounds__(T, 4) void fused_kernel(const FusedArgs a) {
             int used = 0;
             if (lane < kRowsPerBatch) {
                 double v[4] = {0.0, 0.0, 0.0, 0.0};
-                if (valid && ok) row_lut(a, polled, row, slice == 0 && a.stats != nullptr, v, used);
+                if (valid && ok)
+                    row_lut(a, polled, row, a.desc[row].beta, a.desc[row].eaf,
+                            a.desc[row].ref_is_effect != 0, slice == 0 && a.stats != nullptr, v, used);
                 *reinterpret_cast<double2 *>(&lds.lut[lane][0]) = make_double2(v[0], v[1]);
                 *reinterpret_cast<double2 *>(&lds.lut[lane][2]) = make_double2(v[2], v[3]);
             }
@@ -297,15 +325,15 @@ __global__ __launch_bounds__(T, 4) void fused_kernel(const FusedArgs a) {
         }
     };
 
-    // S4: tables of the batch whose LUTs are in LDS; entry e of group g at e ^ (e >> 5)
+    // S4: tables of the batch whose LUTs are in LDS (entry order: table_index)
     auto build_tables = [&]() {
 #pragma unroll
         for (int i = tid; i < 4 * 256; i += T) {
             const int g = i >> 8, e = i & 255;
-            const double v = ((lds.lut[4 * g][e & 3] + lds.lut[4 * g + 1][(e >> 2) & 3]) +
-                              lds.lut[4 * g + 2][(e >> 4) & 3]) +
-                             lds.lut[4 * g + 3][e >> 6];
-            lds.table[g][e ^ (e >> 5)] = v;
+            const int c0 = e & 3, c1 = (e >> 2) & 3, c2 = (e >> 4) & 3, c3 = e >> 6;
+            const double v = ((lds.lut[4 * g][c0] + lds.lut[4 * g + 1][c1]) + lds.lut[4 * g + 2][c2]) +
+                             lds.lut[4 * g + 3][c3];
+            lds.table[g][table_index(c0, c1, c2, c3)] = v;
         }
     };
 
@@ -332,31 +360,78 @@ __global__ __launch_bounds__(T, 4) void fused_kernel(const FusedArgs a) {
         }
     };
 
-    auto step = [&](uint32_t k, uint32_t(&r_next2)[kRowsPerBatch], const uint32_t(&r_next1)[kRowsPerBatch],
-                    const uint32_t(&r_cur)[kRowsPerBatch]) {
-        load_batch(k + 2, r_next2);   // S1
-        poll_issue(k);
-        tally_local(k + 1, r_next1);  // S2
-        poll_finish_lut(k);
-        __syncthreads();              // X
-        publish(k + 1);               // S4
-        build_tables();
-        __syncthreads();              // Y
-        accumulate(r_cur);            // S6
+    // S6+S2 merged: accumulate batch k (LDS-bound: table lookups) and tally batch k+2 (VALU-bound:
+    // popcounts + DPP) in ONE instruction stream, a row of tally work behind every four lookups, so
+    // that all 16 waves of the CU issue a uniform LDS/VALU mix instead of queueing on the LDS in one
+    // phase and on the VALU in the next.
+    auto accumulate_and_tally = [&](const uint32_t(&cur)[kRowsPerBatch], uint32_t k_tal,
+                                    const uint32_t(&tal)[kRowsPerBatch]) {
+        const int par = k_tal & 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t x[4];
+            transpose_fold_4x16(cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], x);
+            const double *Tg = lds.table[g];
+            uint32_t tp[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = Tg[(x[q] >> (8 * kk)) & 0xFFu];
+                tp[kk] = tally_pack(tal[4 * g + kk]);  // VALU work while the lookups are in flight
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[4 * kk + q]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool odd = lane & 1;
+            const uint32_t x0 = odd ? tp[2] : tp[0], y0 = odd ? tp[0] : tp[2];
+            const uint32_t x1 = odd ? tp[3] : tp[1], y1 = odd ? tp[1] : tp[3];
+            const uint32_t b0 = x0 + dpp<kQuadSwap1>(y0);
+            const uint32_t b1 = x1 + dpp<kQuadSwap1>(y1);
+            const bool hi = lane & 2;
+            const uint32_t xx = hi ? b1 : b0, yy = hi ? b0 : b1;
+            uint32_t c = xx + dpp<kQuadSwap2>(yy);
+            c += dpp<kRowShr4>(c);
+            c += dpp<kRowShr8>(c);
+            if ((lane & 12) == 12) {
+                const int r = ((lane & 1) << 1) | ((lane >> 1) & 1);
+                atomicAdd(&lds.tally[par][4 * g + r], c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
-    // prologue: batch 0 loaded + tallied + published, batch 1 loaded
+    // One pipeline step: consume batch k (ring slot r_cur) while tallying batch k+2 (slot r_tal),
+    // then refill slot r_cur with batch k+3.
+    auto step = [&](uint32_t k, uint32_t(&r_cur)[kRowsPerBatch], const uint32_t(&r_tal)[kRowsPerBatch]) {
+        __syncthreads();     // X: LUTs of batch k and the LDS tally sums of batch k+1 are complete
+        publish(k + 1);
+        build_tables();
+        __syncthreads();     // Y: tables of batch k ready
+        poll_issue(k + 1);   // wave 0: its latency hides under the work below
+        accumulate_and_tally(r_cur, k + 2, r_tal);
+        load_batch(k + 3, r_cur);
+        poll_finish_lut(k + 1);
+    };
+
+    // prologue: batches 0..2 loading, batch 0 tallied + published, batch 1 tallied, LUTs of batch 0
     load_batch(0, ring[0]);
     load_batch(1, ring[1]);
+    load_batch(2, ring[2]);
     tally_local(0, ring[0]);
     __syncthreads();
     publish(0);
+    poll_issue(0);
+    tally_local(1, ring[1]);
+    poll_finish_lut(0);
     // batches past the end (k >= n_local, only in the last ring turn) run through unchanged: their
     // loads return zeros, nothing is published or waited for, LUTs are zero: +0.0 to every score
     for (uint32_t k = 0; k < n_local; k += 3) {
-        step(k, ring[2], ring[1], ring[0]);
-        step(k + 1, ring[0], ring[2], ring[1]);
-        step(k + 2, ring[1], ring[0], ring[2]);
+        step(k, ring[0], ring[2]);
+        step(k + 1, ring[1], ring[0]);
+        step(k + 2, ring[2], ring[1]);
     }
 
     if (active) {
@@ -366,6 +441,285 @@ __global__ __launch_bounds__(T, 4) void fused_kernel(const FusedArgs a) {
             *reinterpret_cast<double2 *>(dst + s) = make_double2(acc[s], acc[s + 1]);
     }
     if (slice == 0 && tid == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Control-wave variant.  Same data path, but wave 0 of every workgroup carries no samples: it does
+// everything that is serial per batch -- publishing the workgroup's partial tallies, waiting for the
+// other slices, the 16 row LUTs (two float64 divisions each) and the four 256-entry tables -- while
+// the other T/64-1 waves accumulate the previous batch.  One barrier per batch, tables double
+// buffered.  Slices are (T-64)*16 samples wide.
+struct __attribute__((aligned(16))) FusedCwLds {
+    double table[2][4][256];
+    double lut[kRowsPerBatch][4];
+    uint32_t tally[2][kRowsPerBatch];
+};
+
+template <int T>
+__global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
+    static_assert(T % 64 == 0 && T >= 128 && T <= 1024, "workgroup size");
+    constexpr int TD = T - 64;  // data threads
+    constexpr int kRing = 4;    // batches in flight per data thread: k (accumulating) .. k+3 (tallying)
+    __shared__ FusedCwLds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t team = blockIdx.y;   // grid = (P slices, Q teams)
+    const uint32_t slice = blockIdx.x;
+    const uint32_t n_local = a.n_batches > team ? (a.n_batches - team + a.Q - 1) / a.Q : 0;
+    const uint32_t n_steps = (n_local + kRing - 1) / kRing * kRing;  // data loop unrolled by the ring
+
+    auto batch_row0 = [&](uint32_t k) -> uint64_t {
+        return (uint64_t)(team + (uint64_t)k * a.Q) * kRowsPerBatch;
+    };
+
+    if (tid < 2 * kRowsPerBatch) (&lds.tally[0][0])[tid] = 0;
+    __syncthreads();
+
+    // Barrier #j (j = 0,1,2,...) closes the phase in which the data waves tallied batch j.
+    //   data waves, phase k (between #(k+2) and #(k+3)): accumulate batch k with tables[k&1],
+    //       tally batch k+3, refill the ring slot of batch k with batch k+4
+    //   control wave, same phase: publish batch k+2 (tallied in the previous phase); the tally words
+    //       of batch k+1 were published by every slice one whole phase ago, so one poll normally
+    //       suffices: LUTs and tables of batch k+1 -> tables[(k+1)&1]
+    if (tid < 64) {
+        // ------------------------------------------------------------------ control wave
+        uint32_t nloci_local = 0;
+        bool timed_out = false;
+        unsigned long long tel_spins = 0, tel_wait = 0, tel_chain = 0, tel_bar = 0;  // telemetry
+
+        auto publish = [&](uint32_t k) {  // LDS tally sums of batch k are complete (barrier passed)
+            if (lane < kRowsPerBatch) {
+                const int par = k & 1;
+                const uint32_t v = lds.tally[par][lane];
+                lds.tally[par][lane] = 0;  // next written two phases later
+                const uint64_t row = batch_row0(k) + lane;
+                if (k < n_local && row < a.n_rows) {
+                    const uint64_t t = v >> 16, m = v & 0xFFFFu;
+                    const uint64_t neff = t - 3 * m;
+                    const unsigned long long add = (1ull << 56) | (m << 28) | neff;
+                    __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+
+        // phase work: publish batch kp, then tables of batch kt (its tally words are polled first,
+        // so the publish and the row-descriptor loads hide under the poll's round trip)
+        auto phase = [&](uint32_t kp, uint32_t kt) {
+            const uint64_t row = batch_row0(kt) + lane;
+            const bool valid = lane < kRowsPerBatch && kt < n_local && row < a.n_rows;
+            unsigned long long x = 0;
+            double beta = 0.0, eaf = 0.0;
+            bool rie = false;
+            const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
+            if (valid) {
+                x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                beta = a.desc[row].beta;
+                eaf = a.desc[row].eaf;
+                rie = a.desc[row].ref_is_effect != 0;
+            }
+            publish(kp);
+            bool ok = !valid || (uint32_t)(x >> 56) == a.P;
+            uint32_t spins = 0;
+            while (!__all(ok) && !timed_out) {
+                ++tel_spins;
+                __builtin_amdgcn_s_sleep(1);
+                if (!ok) {
+                    x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(x >> 56) == a.P;
+                }
+                if ((++spins & 255u) == 0) {
+                    const unsigned int t =
+                        __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t != 0 || spins >= kSpinLimit) {
+                        if (lane == 0)
+                            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                    }
+                }
+            }
+            tel_wait += __builtin_amdgcn_s_memtime() - t_w0;
+            int used = 0;
+            if (lane < kRowsPerBatch) {
+                double v[4] = {0.0, 0.0, 0.0, 0.0};
+                if (valid && ok)
+                    row_lut(a, x, row, beta, eaf, rie, slice == 0 && a.stats != nullptr, v, used);
+                *reinterpret_cast<double2 *>(&lds.lut[lane][0]) = make_double2(v[0], v[1]);
+                *reinterpret_cast<double2 *>(&lds.lut[lane][2]) = make_double2(v[2], v[3]);
+            }
+            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+            // tables: lane = (group g, c2, c3); 16 (c0,c1) entries each, summed in row order
+            const int g = lane >> 4, c2 = lane & 3, c3 = (lane >> 2) & 3;
+            const double l2 = lds.lut[4 * g + 2][c2], l3 = lds.lut[4 * g + 3][c3];
+            double l0[4], l1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                l0[c] = lds.lut[4 * g][c];
+                l1[c] = lds.lut[4 * g + 1][c];
+            }
+            double *tab = lds.table[kt & 1][g];
+#pragma unroll
+            for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+                for (int c0 = 0; c0 < 4; ++c0) {
+                    tab[table_index(c0, c1, c2, c3)] = ((l0[c0] + l1[c1]) + l2) + l3;
+                }
+        };
+
+        __syncthreads();  // #0
+        publish(0);
+        __syncthreads();  // #1
+        phase(1, 0);
+        __syncthreads();  // #2
+        for (uint32_t k = 0; k < n_steps; ++k) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            phase(k + 2, k + 1);
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();  // #(k+3)
+            tel_chain += t1 - t0;
+            tel_bar += __builtin_amdgcn_s_memtime() - t1;
+        }
+        if (slice == 0 && lane == 0 && nloci_local)
+            atomicAdd(a.nloci, (unsigned long long)nloci_local);
+        if (lane == 0 && a.telemetry) {  // summed over workgroups; read by the host for diagnostics
+            atomicAdd(&a.telemetry[0], tel_spins);
+            atomicAdd(&a.telemetry[1], tel_wait);
+            atomicAdd(&a.telemetry[2], tel_chain);
+            atomicAdd(&a.telemetry[3], tel_bar);
+            atomicAdd(&a.telemetry[4], (unsigned long long)n_steps);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- data waves
+    const int dt = tid - 64;
+    const uint32_t col = slice * TD + dt;
+    const bool active = col < a.n_words;
+    const uint32_t voff = col * 4u;
+    const uint32_t row_bytes = a.n_words * 4u;
+    const uint64_t stride_bytes = a.stride_words * 4u;
+
+    double acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+    uint32_t ring[kRing][kRowsPerBatch];
+
+    auto load_batch = [&](uint32_t k, uint32_t(&dst)[kRowsPerBatch]) {
+        const uint64_t row0 = batch_row0(k);
+        const bool in = k < n_local && row0 < a.n_rows;
+        const uint32_t nvalid = in ? (uint32_t)min((uint64_t)kRowsPerBatch, a.n_rows - row0) : 0u;
+        const char *p = reinterpret_cast<const char *>(a.codes) +
+                        (in && !a.dbg_same_rows ? row0 : 0) * stride_bytes;
+#pragma unroll
+        for (int r = 0; r < kRowsPerBatch; ++r) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(p), 0, (uint32_t)r < nvalid ? row_bytes : 0u, 0x00020000);
+            dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0);
+            p += stride_bytes;
+        }
+    };
+
+    // reduce-scatter of four packed row tallies over the wave, then one LDS add per DPP row
+    auto tally_reduce4 = [&](int par, int g, const uint32_t(&tp)[4]) {
+        const bool odd = lane & 1;
+        const uint32_t x0 = odd ? tp[2] : tp[0], y0 = odd ? tp[0] : tp[2];
+        const uint32_t x1 = odd ? tp[3] : tp[1], y1 = odd ? tp[1] : tp[3];
+        const uint32_t b0 = x0 + dpp<kQuadSwap1>(y0);
+        const uint32_t b1 = x1 + dpp<kQuadSwap1>(y1);
+        const bool hi = lane & 2;
+        const uint32_t xx = hi ? b1 : b0, yy = hi ? b0 : b1;
+        uint32_t c = xx + dpp<kQuadSwap2>(yy);
+        c += dpp<kRowShr4>(c);
+        c += dpp<kRowShr8>(c);
+        if ((lane & 12) == 12) {
+            const int r = ((lane & 1) << 1) | ((lane >> 1) & 1);
+            atomicAdd(&lds.tally[par][4 * g + r], c);
+        }
+    };
+
+    auto tally_local = [&](uint32_t k, const uint32_t(&src)[kRowsPerBatch]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t tp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tp[r] = tally_pack(src[4 * g + r]);
+            tally_reduce4(k & 1, g, tp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // accumulate batch k (tables[k&1]) and tally batch k+3 in one instruction stream.  The table
+    // lookups are software-pipelined one chunk (4 lookups) ahead: while chunk c's values are awaited,
+    // chunk c+1 is already queued on the LDS and the wave does a row of tally popcounts.
+    auto accumulate_and_tally = [&](uint32_t k, const uint32_t(&cur)[kRowsPerBatch],
+                                    const uint32_t(&tal)[kRowsPerBatch]) {
+        const double *Tk = &lds.table[k & 1][0][0];
+        const int par = (k + 3) & 1;
+        uint32_t x[2][4];
+        double v[2][4];
+        transpose_fold_4x16(cur[0], cur[1], cur[2], cur[3], x[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[0][q] = Tk[x[0][q] & 0xFFu];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3)
+                transpose_fold_4x16(cur[4 * g + 4], cur[4 * g + 5], cur[4 * g + 6], cur[4 * g + 7],
+                                    x[(g + 1) & 1]);
+            uint32_t tp[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = 4 * g + kk;  // chunk index 0..15
+                // queue chunk c+1
+                if (kk < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[(c + 1) & 1][q] = Tk[g * 256 + ((x[g & 1][q] >> (8 * (kk + 1))) & 0xFFu)];
+                } else if (g < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[(c + 1) & 1][q] = Tk[(g + 1) * 256 + (x[(g + 1) & 1][q] & 0xFFu)];
+                }
+                tp[kk] = tally_pack(tal[c]);  // VALU work while the lookups are in flight
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[c & 1][q];
+                // pin the adds (see fused_kernel): hipcc otherwise sinks them and spills the lookups
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[4 * kk + q]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tally_reduce4(par, g, tp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto step = [&](uint32_t k, uint32_t(&r_cur)[kRowsPerBatch], const uint32_t(&r_tal)[kRowsPerBatch]) {
+        accumulate_and_tally(k, r_cur, r_tal);
+        load_batch(k + 4, r_cur);
+        __syncthreads();  // #(k+3)
+    };
+
+    load_batch(0, ring[0]);
+    load_batch(1, ring[1]);
+    load_batch(2, ring[2]);
+    load_batch(3, ring[3]);
+    tally_local(0, ring[0]);
+    __syncthreads();  // #0
+    tally_local(1, ring[1]);
+    __syncthreads();  // #1
+    tally_local(2, ring[2]);
+    __syncthreads();  // #2
+    for (uint32_t k = 0; k < n_steps; k += kRing) {
+        step(k, ring[0], ring[3]);
+        step(k + 1, ring[1], ring[0]);
+        step(k + 2, ring[2], ring[1]);
+        step(k + 3, ring[3], ring[2]);
+    }
+    if (active) {
+        double *dst = a.part + (uint64_t)team * a.part_team_stride + (uint64_t)col * 16;
+#pragma unroll
+        for (int s = 0; s < 16; s += 2)
+            *reinterpret_cast<double2 *>(dst + s) = make_double2(acc[s], acc[s + 1]);
+    }
 }
 
 // part0[i] += sum_q part[q][i]  (fold the teams' partial scores into chunk 0 of the context)
@@ -381,15 +735,19 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ pa
 
 // ---- host side ------------------------------------------------------------------------------
 template <int T>
-static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedPlan *plan) {
+static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, bool control_wave,
+                           FusedPlan *plan) {
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_kernel<T>, T, 0);
+    hipError_t e = control_wave
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T>, T, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_kernel<T>, T, 0);
     if (e != hipSuccess) return e;
     // the kernel needs 128 VGPRs: 16 waves per CU; never ask for more than that many workgroups
-    per_cu = std::min(per_cu, 1024 / T);
+    per_cu = std::min(per_cu, T == 768 ? 1 : 1024 / T);
     if (per_cu < 1) return hipSuccess;
     const uint64_t capacity = (uint64_t)cus * per_cu;
-    const uint64_t P = (n_words + T - 1) / T;
+    const uint64_t cols = control_wave ? T - 64 : T;  // word columns per workgroup
+    const uint64_t P = (n_words + cols - 1) / cols;
     if (P > capacity || P > 255) return hipSuccess;  // 8-bit arrival count in the tally word
     uint64_t Q = std::min<uint64_t>(capacity / P, n_batches);
     if (Q < 1 || Q > 65535) return hipSuccess;
@@ -397,13 +755,15 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedP
     plan->P = (uint32_t)P;
     plan->Q = (uint32_t)Q;
     plan->n_batches = (uint32_t)n_batches;
-    plan->part_team_stride = P * T * 16;
+    plan->part_team_stride = P * cols * 16;
+    plan->control_wave = control_wave;
     plan->ok = true;
     return hipSuccess;
 }
 
 hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads,
-                      FusedPlan *plan) {
+                      int variant, FusedPlan *plan) {
+    const bool cw = variant != 1;  // 0 = default (control wave), 1 = all-data-waves kernel
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;
     hipDeviceProp_t prop;
@@ -420,9 +780,10 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
     const int *order = want_threads ? order_want : order_default;
     for (int i = 0; i < 3 && !plan->ok; ++i) {
         switch (order[i]) {
-        case 256: e = plan_for<256>(cus, n_words, n_batches, plan); break;
-        case 512: e = plan_for<512>(cus, n_words, n_batches, plan); break;
-        case 1024: e = plan_for<1024>(cus, n_words, n_batches, plan); break;
+        case 256: e = plan_for<256>(cus, n_words, n_batches, cw, plan); break;
+        case 512: e = plan_for<512>(cus, n_words, n_batches, cw, plan); break;
+        case 768: e = plan_for<768>(cus, n_words, n_batches, cw, plan); break;
+        case 1024: e = plan_for<1024>(cus, n_words, n_batches, cw, plan); break;
         default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
@@ -452,10 +813,20 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
     a.part = d_part;
     a.part_team_stride = plan.part_team_stride;
     a.timeout = d_timeout;
+    a.telemetry = reinterpret_cast<unsigned long long *>(d_timeout) + 2;  // same 256-byte block
+    a.dbg_same_rows = getenv("NPS_DEBUG_SAMEROWS") != nullptr;
     void *args[] = {&a};
-    const void *fn = plan.threads == 256   ? (const void *)fused_kernel<256>
-                     : plan.threads == 512 ? (const void *)fused_kernel<512>
-                                           : (const void *)fused_kernel<1024>;
+    const void *fn;
+    if (plan.control_wave)
+        fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256>
+             : plan.threads == 512 ? (const void *)fused_cw_kernel<512>
+             : plan.threads == 768 ? (const void *)fused_cw_kernel<768>
+                                   : (const void *)fused_cw_kernel<1024>;
+    else
+        fn = plan.threads == 256   ? (const void *)fused_kernel<256>
+             : plan.threads == 512 ? (const void *)fused_kernel<512>
+             : plan.threads == 768 ? (const void *)fused_kernel<768>
+                                   : (const void *)fused_kernel<1024>;
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
 }
