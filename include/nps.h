@@ -151,8 +151,9 @@ int nps_push_gt(nps_ctx *ctx, const int32_t *gts, int ploidy, int eaidx, int ref
 int nps_push_ds(nps_ctx *ctx, const float *ds, int ref_is_effect, double beta, double eaf);
 
 /* PRESENT row already in the device layout: ceil(n_samples/16) little-endian uint32, sample i
- * in bits 2*(i%16).. of word i/16, code = effect-allele dosage 0/1/2, 3 = missing; padding
- * bits zero.  `row` is a host pointer. */
+ * in bits 2*(i%16).. of word i/16; codes NPS_CODE_*: 0 = dosage 0, 1 = dosage 1, 3 = dosage 2,
+ * 2 = missing (so that popcount(word) = effect alleles + missing samples); padding bits zero.
+ * `row` is a host pointer. */
 int nps_push_packed(nps_ctx *ctx, const uint32_t *row, int ref_is_effect, double beta, double eaf);
 
 /* Row without genotype data: kind = UNCOVERED / ABSENT / FILTERED.  Replaces the early
@@ -176,6 +177,10 @@ void nps_destroy(nps_ctx *ctx);
 
 /* ---- resident cohort: a packed genotype matrix kept in HBM ------------------------------ */
 #define NPS_FMT_GT2 0  /* 2-bit codes, 16 per uint32, variant-major / sample-minor */
+#define NPS_CODE_DOSAGE0 0u
+#define NPS_CODE_DOSAGE1 1u
+#define NPS_CODE_MISSING 2u
+#define NPS_CODE_DOSAGE2 3u
 #define NPS_FMT_DS32 1 /* float32 dosages, NaN = missing, variant-major / sample-minor */
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,

@@ -49,7 +49,8 @@ struct FusedArgs {
     uint64_t part_team_stride;
     unsigned int *timeout;      // zeroed before the launch
     unsigned long long *telemetry;  // 8 counters (control-wave variant), zeroed before the launch
-    int dbg_same_rows;              // diagnostics only: every batch re-reads rows 0..15 (L2 hits)
+    int dbg_same_rows;              // diagnostics only: bit 0 every batch re-reads rows 0..15 (L2
+                                    // hits), bit 1 skip the accumulation
 };
 
 // ---- DPP helpers --------------------------------------------------------------------------
@@ -63,10 +64,11 @@ constexpr int kQuadSwap2 = 0x4E;  // quad_perm:[2,3,0,1]  lane ^ 2
 constexpr int kRowShr4 = 0x114;
 constexpr int kRowShr8 = 0x118;
 
-// popcount triple of one word, packed (popc(w)+popc(w&0xAAAAAAAA)) << 16 | missing
+// popcounts of one word, packed popc(w) << 16 | missing.  With the codes 00/01/11 = dosage 0/1/2 and
+// 10 = missing, popc(w) = effect alleles + missing samples: five VALU ops per row word.
 static __device__ __forceinline__ uint32_t tally_pack(uint32_t w) {
-    const uint32_t t = __popc(w) + __popc(w & 0xAAAAAAAAu);
-    const uint32_t m = __popc(w & (w >> 1) & 0x55555555u);
+    const uint32_t t = __popc(w);
+    const uint32_t m = __popc((w >> 1) & ~w & 0x55555555u);
     return (t << 16) | m;
 }
 
@@ -158,10 +160,10 @@ static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long
                 imp = a.prm.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
             break;
         }
-        v[0] = 0.0 * beta;
+        v[0] = 0.0 * beta;  // indexed by CODE: 0, 1 = dosage ; 2 = missing ; 3 = dosage 2
         v[1] = 1.0 * beta;
-        v[2] = 2.0 * beta;
-        v[3] = imp * beta;
+        v[2] = imp * beta;
+        v[3] = 2.0 * beta;
     }
     if (write_stats) {
         nps_locus_stat s;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(T, (T >= 1024 ? 4 : T >= 768 ? 3 : 4)) void fused_k
             const uint64_t row = batch_row0(k) + tid;
             if (k < n_local && row < a.n_rows) {
                 const uint64_t t = v >> 16, m = v & 0xFFFFu;
-                const uint64_t neff = t - 3 * m;
+                const uint64_t neff = t - m;
                 const unsigned long long add = (1ull << 56) | (m << 28) | neff;
                 __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -334,29 +336,6 @@ __global__ __launch_bounds__(T, (T >= 1024 ? 4 : T >= 768 ? 3 : 4)) void fused_k
             const double v = ((lds.lut[4 * g][c0] + lds.lut[4 * g + 1][c1]) + lds.lut[4 * g + 2][c2]) +
                              lds.lut[4 * g + 3][c3];
             lds.table[g][table_index(c0, c1, c2, c3)] = v;
-        }
-    };
-
-    // S6
-    auto accumulate = [&](const uint32_t(&src)[kRowsPerBatch]) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint32_t x[4];
-            transpose_fold_4x16(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3], x);
-            const double *Tg = lds.table[g];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += Tg[(x[q] >> (8 * kk)) & 0xFFu];
-                // Pin the four adds here.  Without the opaque use hipcc (ROCm 7.2) sinks the
-                // v_add_f64 of a whole batch below the next batch's barrier and spills the looked-up
-                // values to scratch; with it, four lookups are in flight per wave at a time, which
-                // also bounds the live registers (ring + accumulators already hold 80 of the 128 a
-                // 16-wave-per-CU kernel may use).
-#pragma unroll
-                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[4 * kk + q]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
     };
 
@@ -495,7 +474,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
                 const uint64_t row = batch_row0(k) + lane;
                 if (k < n_local && row < a.n_rows) {
                     const uint64_t t = v >> 16, m = v & 0xFFFFu;
-                    const uint64_t neff = t - 3 * m;
+                    const uint64_t neff = t - m;
                     const unsigned long long add = (1ull << 56) | (m << 28) | neff;
                     __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -609,7 +588,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         const bool in = k < n_local && row0 < a.n_rows;
         const uint32_t nvalid = in ? (uint32_t)min((uint64_t)kRowsPerBatch, a.n_rows - row0) : 0u;
         const char *p = reinterpret_cast<const char *>(a.codes) +
-                        (in && !a.dbg_same_rows ? row0 : 0) * stride_bytes;
+                        (in && !(a.dbg_same_rows & 1) ? row0 : 0) * stride_bytes;
 #pragma unroll
         for (int r = 0; r < kRowsPerBatch; ++r) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -693,7 +672,10 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     };
 
     auto step = [&](uint32_t k, uint32_t(&r_cur)[kRowsPerBatch], const uint32_t(&r_tal)[kRowsPerBatch]) {
-        accumulate_and_tally(k, r_cur, r_tal);
+        if (a.dbg_same_rows & 2)  // diagnostics only: tally without the accumulation
+            tally_local(k + 3, r_tal);
+        else
+            accumulate_and_tally(k, r_cur, r_tal);
         load_batch(k + 4, r_cur);
         __syncthreads();  // #(k+3)
     };
@@ -814,7 +796,7 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
     a.part_team_stride = plan.part_team_stride;
     a.timeout = d_timeout;
     a.telemetry = reinterpret_cast<unsigned long long *>(d_timeout) + 2;  // same 256-byte block
-    a.dbg_same_rows = getenv("NPS_DEBUG_SAMEROWS") != nullptr;
+    a.dbg_same_rows = getenv("NPS_DEBUG_FLAGS") ? atoi(getenv("NPS_DEBUG_FLAGS")) : 0;
     void *args[] = {&a};
     const void *fn;
     if (plan.control_wave)

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
                     code += (((a[k] >> 1) - 1) == eaidx) ? 1u : 0u;
             }
         }
-        if (miss) code = 3;
+        code = miss ? NPS_CODE_MISSING : (code == 2 ? NPS_CODE_DOSAGE2 : code);
     }
     uint32_t sh = code << (2 * (lane & 15));
     sh |= __shfl_xor(sh, 1, 64);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
     sh |= __shfl_xor(sh, 8, 64);
     if ((lane & 15) == 0 && s < n) out_row[s >> 4] = sh;
 
-    uint32_t m = miss ? 1u : 0u, e = miss ? 0u : code, z = 0;
+    uint32_t m = miss ? 1u : 0u, e = miss ? 0u : (code == NPS_CODE_DOSAGE2 ? 2u : code), z = 0;
     group_sum3<4>(m, e, z, red, threadIdx.x);
     if (threadIdx.x == 0 && (m | e))
         atomicAdd(tally, ((unsigned long long)m << 32) | (unsigned long long)e);
@@ -118,16 +118,14 @@ hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, in
 }
 
 // ------------------------------------------------------------------------------------------
-// tally of packed rows.  For a word w of sixteen 2-bit codes (0,1,2 = dosage, 3 = missing):
-//   popc(w)              = het + hom + 2*miss
-//   popc(w & 0xAAAAAAAA) = hom + miss
-//   popc(w & w>>1 & 0x55555555) = miss
-//   neffect = het + 2*hom = popc(w) + popc(w & 0xAAAAAAAA) - 3*miss
-static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint32_t &ch,
-                                                  uint32_t &cm) {
+// tally of packed rows.  For a word w of sixteen 2-bit codes (00 dosage 0, 01 dosage 1, 11 dosage 2,
+// 10 missing):
+//   popc(w)                       = het + 2*hom + miss
+//   popc(w>>1 & ~w & 0x55555555)  = miss
+//   neffect = het + 2*hom = popc(w) - miss
+static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint32_t &cm) {
     cw += __popc(w);
-    ch += __popc(w & 0xAAAAAAAAu);
-    cm += __popc(w & (w >> 1) & 0x55555555u);
+    cm += __popc((w >> 1) & ~w & 0x55555555u);
 }
 
 template <int TPR>  // threads per row: 64 (one wave) or 256 (whole block)
@@ -139,22 +137,22 @@ __global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__res
     constexpr int RPB = 256 / TPR;
     const uint64_t row = (uint64_t)blockIdx.x * RPB + threadIdx.x / TPR;
     const int t = threadIdx.x % TPR;
-    uint32_t cw = 0, ch = 0, cm = 0;
+    uint32_t cw = 0, cm = 0, cz = 0;
     if (row < n_rows) {
         // rows are 256-B aligned and zero padded to a multiple of 64 words, so whole uint4 reads
         // up to n_vec4 = ceil(n_words/4) stay inside the row.
         const uint4 *p = reinterpret_cast<const uint4 *>(codes + row * stride_words);
         for (uint32_t v = t; v < n_vec4; v += TPR) {
             const uint4 q = p[v];
-            tally_word(q.x, cw, ch, cm);
-            tally_word(q.y, cw, ch, cm);
-            tally_word(q.z, cw, ch, cm);
-            tally_word(q.w, cw, ch, cm);
+            tally_word(q.x, cw, cm);
+            tally_word(q.y, cw, cm);
+            tally_word(q.z, cw, cm);
+            tally_word(q.w, cw, cm);
         }
     }
-    group_sum3<TPR / 64>(cw, ch, cm, red, t);
+    group_sum3<TPR / 64>(cw, cm, cz, red, t);
     if (t == 0 && row < n_rows)
-        tally[row] = ((unsigned long long)cm << 32) | (unsigned long long)(cw + ch - 3u * cm);
+        tally[row] = ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm);
 }
 
 hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
@@ -224,10 +222,10 @@ __global__ __launch_bounds__(256) void row_params_kernel(
                         imp = p.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
                     break;
                 }
-                v0 = 0.0 * beta;
+                v0 = 0.0 * beta;  // LUT is indexed by CODE: 0, 1 = dosage ; 2 = missing ; 3 = dosage 2
                 v1 = 1.0 * beta;
-                v2 = 2.0 * beta;
-                v3 = imp * beta;
+                v2 = imp * beta;
+                v3 = 2.0 * beta;
             }
             if (stats) {
                 nps_locus_stat s;
@@ -411,7 +409,7 @@ __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ co
         if (s < n_samples) {
             const uint64_t h = mix64(key + s);
             const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
-            const uint32_t c = ms < tmi ? 3u : (g < tm ? 2u : (g < th ? 1u : 0u));
+            const uint32_t c = ms < tmi ? NPS_CODE_MISSING : (g < tm ? NPS_CODE_DOSAGE2 : (g < th ? 1u : 0u));
             w |= c << (2 * k);
         }
     }

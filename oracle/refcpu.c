@@ -264,7 +264,7 @@ void ref_finish(ref_state *s, double offset, double *scores_out, int64_t *nloci_
 
 /* ------------------------------------------------------------------------- */
 /* Whole-matrix convenience for the synthetic cohorts: rows are 2-bit codes
- * (0/1/2 = effect-allele dosage, 3 = missing), 16 per little-endian uint32, row stride
+ * (0 = dosage 0, 1 = dosage 1, 3 = dosage 2, 2 = missing), 16 per little-endian uint32, row stride
  * `stride_words` -- the build-defined device layout.  Unpacks each row to the
  * bcf_get_genotypes int32 layout and runs the literal per-row path above, so this measures
  * the reference's own passes (decode, tally, impute, accumulate). */
@@ -276,8 +276,8 @@ void ref_codes_to_gt(const uint32_t *row, size_t n, int32_t *gts /* 2n */) {
         switch (c) {
         case 0: a0 = 2; a1 = 2; break;  /* 0/0 */
         case 1: a0 = 2; a1 = 4; break;  /* 0/1 */
-        case 2: a0 = 4; a1 = 4; break;  /* 1/1 */
-        default: a0 = 0; a1 = 0; break; /* ./. */
+        case 3: a0 = 4; a1 = 4; break;  /* 1/1 */
+        default: a0 = 0; a1 = 0; break; /* ./.  (code 2) */
         }
         gts[2 * i] = a0;
         gts[2 * i + 1] = a1;
@@ -414,9 +414,9 @@ unsigned ref_synth_code(uint64_t seed, uint64_t row, uint64_t sample, uint32_t t
                         uint32_t t_hom, uint32_t t_miss) {
     uint64_t h = ref_mix64(ref_mix64(seed ^ (row * 0xD1B54A32D192ED03ull)) + sample);
     uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
-    if (ms < t_miss) return 3u;
-    /* g < t_hom -> 2 ; g < t_het -> 1 ; else 0   (t_hom <= t_het) */
-    return g < t_hom ? 2u : (g < t_het ? 1u : 0u);
+    if (ms < t_miss) return 2u; /* missing */
+    /* g < t_hom -> dosage 2 (code 3) ; g < t_het -> dosage 1 ; else dosage 0   (t_hom <= t_het) */
+    return g < t_hom ? 3u : (g < t_het ? 1u : 0u);
 }
 
 void ref_synth_rows(uint32_t *codes, size_t stride_words, size_t n, size_t row0, size_t nrows,

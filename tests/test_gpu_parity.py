@@ -285,8 +285,8 @@ def test_fused_equals_twopass_large():
         codes = refcpu.synth_rows(n, j, 1, 5, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
         c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
         code = (c[:, 0] + 2 * c[:, 1])[:n]
-        assert int((code == 3).sum()) == int(res[1][0]["nmissing"][j])
-        assert int((code == 1).sum() + 2 * (code == 2).sum()) == int(res[1][0]["neffect"][j])
+        assert int((code == 2).sum()) == int(res[1][0]["nmissing"][j])       # NPS_CODE_MISSING
+        assert int((code == 1).sum() + 2 * (code == 3).sum()) == int(res[1][0]["neffect"][j])
 
 
 def test_resident_mixed_kinds_and_upload():
