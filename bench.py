@@ -106,7 +106,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from nimpress_amd import capi
+    from nimpress_amd import capi, multi
     n, m = args.samples, args.variants
     mode = {"auto": capi.MODE_AUTO, "twopass": capi.MODE_TWOPASS, "fused": capi.MODE_FUSED}[args.mode]
 
@@ -120,7 +120,6 @@ def main():
     sdef = capi.ScoreDef(capi.row_descs(beta, eaf), device=local_rank)
     sc = capi.Scorer(n, capi.make_params(), device=local_rank)
     d_scores = torch.empty(n, dtype=torch.float64, device="cuda")
-    gathered = torch.empty((world, n), dtype=torch.float64, device="cuda") if world > 1 else None
     offset = 0.0
 
     def step():
@@ -128,7 +127,8 @@ def main():
         sc.score_cohort_def(cohort, sdef, 0, mode)
         nloci = sc.finish_device(offset, d_scores.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_scores)
+            # the one real exchange of the path: samples x scores matrix over RCCL (one score per rank)
+            step.matrix = multi.gather_scores(d_scores.view(1, n), world)
         return nloci
 
     def fence():

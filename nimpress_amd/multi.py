@@ -1,0 +1,56 @@
+"""Multi-GPU evaluation: score definitions sharded over ranks, one RCCL all-gather at the end.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+The path shards by score file (BASELINE.json north_star): every rank holds the cohort, evaluates
+its own scores with libnps, and the only exchange is the gather of the samples x scores matrix.
+Nothing here computes scores: `score_fn` does (libnps on a GPU box; the tests pass the oracle).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_scores: int, world: int, rank: int) -> List[int]:
+    """Round-robin assignment: score i goes to rank i % world (balances unequal score sizes a
+    little better than contiguous blocks when files are listed by size)."""
+    return list(range(rank, n_scores, world))
+
+
+def gather_scores(local: torch.Tensor, n_scores: int, group=None) -> torch.Tensor:
+    """local: [k_local, N] float64 scores of this rank's shard (rows in shard order).
+    Returns the full [n_scores, N] matrix on every rank (score order restored)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        assert local.shape[0] == n_scores
+        return local
+    n = local.shape[1]
+    k_max = (n_scores + world - 1) // world
+    send = torch.zeros((k_max, n), dtype=local.dtype, device=local.device)
+    send[: local.shape[0]] = local
+    recv = torch.empty((world, k_max, n), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv.view(world * k_max, n), send, group=group)
+    out = torch.empty((n_scores, n), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_scores, world, r)
+        if idx:
+            out[idx] = recv[r, : len(idx)]
+    assert len(shard_indices(n_scores, world, rank)) == local.shape[0]
+    return out
+
+
+def evaluate_sharded(n_scores: int, n_samples: int,
+                     score_fn: Callable[[int, torch.Tensor], None],
+                     device: torch.device, group=None) -> torch.Tensor:
+    """score_fn(i, out_row) writes the N scores of score definition i into out_row (a float64
+    view on `device`).  Returns the gathered [n_scores, N] matrix."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_indices(n_scores, world, rank)
+    local = torch.empty((len(mine), n_samples), dtype=torch.float64, device=device)
+    for j, i in enumerate(mine):
+        score_fn(i, local[j])
+    return gather_scores(local, n_scores, group)
