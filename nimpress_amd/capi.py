@@ -132,7 +132,8 @@ def device_count() -> int:
 
 
 class Cohort:
-    """A genotype matrix resident in HBM (2-bit codes, variant-major / sample-minor)."""
+    """A genotype matrix resident in HBM, variant-major / sample-minor: 2-bit GT codes (FMT_GT2) or
+    float32 dosages with NaN = missing (FMT_DS32)."""
 
     def __init__(self, n_samples: int, n_rows: int, device: int = 0, fmt: int = FMT_GT2):
         self._h = C.c_void_p()
@@ -150,8 +151,11 @@ class Cohort:
                                         rows.strides[0]))
 
     def download(self, row0: int, nrows: int) -> np.ndarray:
-        width = (self.n_samples + 15) // 16
-        out = np.zeros((nrows, max(width, 1)), dtype=np.uint32)
+        if self.fmt == FMT_DS32:
+            width, dtype = self.n_samples, np.float32
+        else:
+            width, dtype = (self.n_samples + 15) // 16, np.uint32
+        out = np.zeros((nrows, max(width, 1)), dtype=dtype)
         _check(load().nps_cohort_download(self._h, row0, nrows, out.ctypes.data, out.strides[0]))
         return out[:, :width]
 

@@ -1,0 +1,240 @@
+// nps_ds.hip -- FORMAT/DS (float32 dosage) path.  Build-defined extension: the reference decodes GT
+// only (nimpress.nim:367-391); semantics follow the oracle's ref_raw_dosages_ds: one ALT dosage per
+// sample, NaN = missing, effect allele == REF -> dosage = 2 - DS; then tallyAlleles (nim:32-47),
+// the maxmis decision (:565-571), imputation (:417-481) and the accumulation (:639-641) unchanged.
+//
+// 4 bytes per genotype: purely HBM-bound, so the kernels are plain streaming kernels with 16-byte
+// loads.  The accumulation keeps the reference's order (per sample, rows in score-file order, one
+// float64 multiply and one add per row), so for a DS-only score the sums are bit-identical to the
+// reference's; the row tallies use a fixed-shape tree (deterministic, differs from the reference's
+// sequential float64 sum in the last bits only).
+#include "nps_kernels.h"
+
+namespace nps {
+
+static __device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+static __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// one 256-thread block per row
+__global__ __launch_bounds__(256) void ds_tally_kernel(const float *__restrict__ ds,
+                                                       uint64_t stride_f, uint64_t n,
+                                                       const nps_row_desc *__restrict__ desc,
+                                                       uint64_t n_rows, DsTally *__restrict__ out) {
+    __shared__ double s_sum[4];
+    __shared__ uint32_t s_cnt[4];
+    const uint64_t row = blockIdx.x;
+    if (row >= n_rows) return;
+    const bool rie = desc[row].ref_is_effect != 0;
+    const float4 *p = reinterpret_cast<const float4 *>(ds + row * stride_f);
+    const uint64_t n4 = (n + 3) / 4;  // rows are zero padded to a multiple of 64 floats
+    uint32_t cnt = 0;
+    double sum = 0.0;
+    for (uint64_t v = threadIdx.x; v < n4; v += 256) {
+        const float4 q = p[v];
+        const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (v * 4 + k < n) {
+                if (isnan(e[k]))
+                    cnt += 1;
+                else
+                    sum += rie ? 2.0 - (double)e[k] : (double)e[k];
+            }
+        }
+    }
+    sum = wave_sum_f64(sum);
+    cnt = wave_sum_u32(cnt);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[w] = sum;
+        s_cnt[w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DsTally t;
+        t.nmiss = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        t.neff = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+        out[row] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void ds_params_kernel(const DsTally *__restrict__ tally,
+                                                        const nps_row_desc *__restrict__ desc,
+                                                        uint64_t n_rows, uint64_t n_samples,
+                                                        DevParams p, DsRowP *__restrict__ rowp,
+                                                        nps_locus_stat *__restrict__ stats,
+                                                        unsigned long long *__restrict__ nloci) {
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    int used = 0;
+    if (row < n_rows) {
+        const uint64_t nmiss = tally[row].nmiss;
+        const double neff = tally[row].neff;
+        const uint64_t ngen = n_samples - nmiss;
+        const double beta = desc[row].beta, eaf = desc[row].eaf;
+        const bool rie = desc[row].ref_is_effect != 0;
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        DsRowP r;
+        r.beta = beta;
+        r.imp = 0.0;
+        r.cst = 0.0;
+        r.mode = 0;
+        r.rie = rie ? 1 : 0;
+        int reason;
+        const double missingrate = (double)nmiss / (double)n_samples;
+        if (missingrate > p.max_missing_rate) {  // nim:565-571
+            reason = NPS_REASON_MAXMIS;
+            if (p.imp_locus != NPS_LOCUS_IGNORE) {
+                r.cst = p.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                        : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                          : nan;
+                r.mode = 2;
+                used = 1;
+            }
+        } else {  // nim:450-481
+            reason = NPS_REASON_GENOTYPED;
+            used = 1;
+            r.mode = 1;
+            switch (p.imp_sample) {
+            case NPS_SAMPLE_PS: r.imp = eaf * 2.0; break;
+            case NPS_SAMPLE_HOMREF: r.imp = rie ? 2.0 : 0.0; break;
+            case NPS_SAMPLE_FAIL: r.imp = nan; break;
+            default:
+                if ((double)ngen >= p.min_cs)
+                    r.imp = neff / (double)ngen;
+                else
+                    r.imp = p.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
+                break;
+            }
+        }
+        rowp[row] = r;
+        if (stats) {
+            nps_locus_stat s;
+            s.ngenotyped = ngen;
+            s.nmissing = nmiss;
+            s.neffect = neff;
+            s.used = used;
+            s.reason = reason;
+            stats[row] = s;
+        }
+    }
+    const int cnt = __syncthreads_count(used);
+    if (threadIdx.x == 0 && cnt) atomicAdd(nloci, (unsigned long long)cnt);
+}
+
+// one thread = 4 consecutive samples, all rows in order: score += dosage * beta   (nim:639-641)
+__global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restrict__ ds,
+                                                            uint64_t stride_f, uint64_t n,
+                                                            const DsRowP *__restrict__ rowp,
+                                                            uint64_t n_rows,
+                                                            double *__restrict__ part0) {
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
+    const uint64_t i0 = v * 4;
+    if (i0 >= n) return;
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = (i0 + k < n) ? part0[i0 + k] : 0.0;
+    const float4 *p = reinterpret_cast<const float4 *>(ds) + v;
+    const uint64_t stride4 = stride_f / 4;
+    for (uint64_t row = 0; row < n_rows; ++row) {
+        const DsRowP r = rowp[row];  // wave-uniform
+        if (r.mode == 0) continue;
+        const float4 q = p[row * stride4];
+        const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double d;
+            if (r.mode == 2)
+                d = r.cst;
+            else if (isnan(e[k]))
+                d = r.imp;
+            else
+                d = r.rie ? 2.0 - (double)e[k] : (double)e[k];
+            s[k] += d * r.beta;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) part0[i0 + k] = s[k];
+}
+
+// device copy of ref_synth_ds (oracle/refcpu.c)
+static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_ds_kernel(float *__restrict__ ds, uint64_t stride_f,
+                                                       uint64_t n, uint64_t row0, uint64_t seed,
+                                                       const uint32_t *__restrict__ t_het,
+                                                       const uint32_t *__restrict__ t_hom,
+                                                       const uint32_t *__restrict__ t_miss) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r = blockIdx.y;
+    if (i >= n) return;
+    const uint64_t h = mix64(mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull)) + i);
+    const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
+    float d;
+    if (ms < t_miss[r]) {
+        d = __int_as_float(0x7fc00000);
+    } else {
+        const int c = g < t_hom[r] ? 2 : (g < t_het[r] ? 1 : 0);
+        const int noise = (int)((ms >> 8) & 255u) - 128;
+        d = (float)c + (float)noise * (1.0f / 1024.0f);
+        d = d < 0.0f ? 0.0f : (d > 2.0f ? 2.0f : d);
+    }
+    ds[(row0 + r) * stride_f + i] = d;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+hipError_t launch_ds_tally(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
+                           const nps_row_desc *d_desc, uint64_t n_rows, DsTally *d_tally) {
+    if (n_rows == 0) return hipSuccess;
+    if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ds_tally_kernel, dim3((uint32_t)n_rows), dim3(256), 0, st, d_ds, stride_f, n,
+                       d_desc, n_rows, d_tally);
+    return hipGetLastError();
+}
+
+hipError_t launch_ds_params(hipStream_t st, const DsTally *d_tally, const nps_row_desc *d_desc,
+                            uint64_t n_rows, uint64_t n_samples, DevParams p, DsRowP *d_rowp,
+                            nps_locus_stat *d_stats, unsigned long long *d_nloci) {
+    if (n_rows == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ds_params_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st,
+                       d_tally, d_desc, n_rows, n_samples, p, d_rowp, d_stats, d_nloci);
+    return hipGetLastError();
+}
+
+hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
+                                const DsRowP *d_rowp, uint64_t n_rows, double *d_part0) {
+    if (n_rows == 0 || n == 0) return hipSuccess;
+    const uint64_t n4 = (n + 3) / 4;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ds_accumulate_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, st,
+                       d_ds, stride_f, n, d_rowp, n_rows, d_part0);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
+                           uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                           const uint32_t *d_t_hom, const uint32_t *d_t_miss) {
+    if (n_rows == 0 || n == 0) return hipSuccess;
+    if (n_rows > 65535) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_ds_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)n_rows), dim3(256),
+                       0, st, d_ds, stride_f, n, row0, seed, d_t_het, d_t_hom, d_t_miss);
+    return hipGetLastError();
+}
+
+}  // namespace nps

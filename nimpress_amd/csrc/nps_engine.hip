@@ -59,7 +59,8 @@ struct nps_cohort {
 };
 
 struct PendingRow {
-    int32_t batch_idx;  // >= 0: index into the current batch's device stats; -1: host stat
+    int32_t batch_idx;  // >= 0: index into the open GT / DS batch's device stats; -1: host stat
+    int32_t is_ds;      // which open batch batch_idx refers to
     nps_locus_stat host;
 };
 
@@ -86,6 +87,25 @@ struct nps_ctx {
     void *h_arena = nullptr;  // ONE pinned allocation holding h_desc, h_stats and h_raw[]
     hipEvent_t ev_raw[kRawSlots] = {nullptr, nullptr};
     int raw_next = 0;
+
+    // FORMAT/DS streaming batch (allocated on the first nps_push_ds)
+    uint32_t ds_cap = 0, ds_rows = 0;
+    uint64_t ds_stride_f = 0;
+    float *d_ds = nullptr;               // [ds_cap][ds_stride_f]
+    nps_row_desc *d_ds_desc = nullptr;   // [ds_cap]
+    DsTally *d_ds_tally = nullptr;
+    DsRowP *d_ds_rowp = nullptr;
+    nps_locus_stat *d_ds_stats = nullptr;
+    void *h_ds_arena = nullptr;          // pinned: h_ds_desc, h_ds_stats, staging ring
+    nps_row_desc *h_ds_desc = nullptr;
+    nps_locus_stat *h_ds_stats = nullptr;
+    float *h_ds_raw[2] = {nullptr, nullptr};
+    hipEvent_t ev_ds_raw[2] = {nullptr, nullptr};
+    int ds_raw_next = 0;
+    // resident DS runs
+    uint64_t res_ds_cap = 0;
+    DsTally *d_rds_tally = nullptr;
+    DsRowP *d_rds_rowp = nullptr;
 
     // accumulators
     AccumGeom geom{};         // streaming geometry (groups_per_chunk for a full batch)
@@ -231,6 +251,16 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_raw);
     for (int k = 0; k < nps_ctx::kRawSlots; ++k)
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
+    (void)hipFree(c->d_ds);
+    (void)hipFree(c->d_ds_desc);
+    (void)hipFree(c->d_ds_tally);
+    (void)hipFree(c->d_ds_rowp);
+    (void)hipFree(c->d_ds_stats);
+    (void)hipHostFree(c->h_ds_arena);
+    for (int k = 0; k < 2; ++k)
+        if (c->ev_ds_raw[k]) (void)hipEventDestroy(c->ev_ds_raw[k]);
+    (void)hipFree(c->d_rds_tally);
+    (void)hipFree(c->d_rds_rowp);
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_rtally);
@@ -251,6 +281,7 @@ static int zero_state(nps_ctx *c) {
     c->const_sum = 0.0;
     c->host_nloci = 0;
     c->batch_rows = 0;
+    c->ds_rows = 0;
     c->pending.clear();
     c->ready.clear();
     c->ready_cursor = 0;
@@ -400,33 +431,60 @@ static int run_batch(nps_ctx *c) {
         int rc = materialize_resident_stats(c);
         if (rc) return rc;
     }
-    if (c->batch_rows == 0) {
+    if (c->batch_rows == 0 && c->ds_rows == 0) {
         // only host rows pending: move them to ready
         for (auto &p : c->pending) c->ready.push_back(p.host);
         c->pending.clear();
         return NPS_OK;
     }
     const uint32_t rows = c->batch_rows;
-    const uint32_t rows_pad = (rows + 3) / 4 * 4;
-    HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(nps_row_desc) * rows, hipMemcpyHostToDevice,
-                           c->stream));
-    {
-        ProfScope ps(c, P_PARAMS);
-        HIP_TRY(launch_row_params(c->stream, c->d_tally, c->d_desc, rows, rows_pad, c->n,
-                                  dev_params(c->params), c->d_lut, c->d_stats, c->d_nloci));
+    if (rows) {
+        const uint32_t rows_pad = (rows + 3) / 4 * 4;
+        HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(nps_row_desc) * rows,
+                               hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, P_PARAMS);
+            HIP_TRY(launch_row_params(c->stream, c->d_tally, c->d_desc, rows, rows_pad, c->n,
+                                      dev_params(c->params), c->d_lut, c->d_stats, c->d_nloci));
+        }
+        if (c->n) {
+            ProfScope ps(c, P_ACCUM);
+            HIP_TRY(launch_accumulate(c->stream, c->d_codes, c->stride_words, rows, c->d_lut, c->geom,
+                                      c->d_part));
+        }
+        HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(nps_locus_stat) * rows,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * rows, c->stream));
     }
-    if (c->n > 0) {
-        ProfScope ps(c, P_ACCUM);
-        HIP_TRY(launch_accumulate(c->stream, c->d_codes, c->stride_words, rows, c->d_lut, c->geom,
-                                  c->d_part));
+    const uint32_t drows = c->ds_rows;
+    if (drows) {
+        HIP_TRY(hipMemcpyAsync(c->d_ds_desc, c->h_ds_desc, sizeof(nps_row_desc) * drows,
+                               hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, P_TALLY);
+            HIP_TRY(launch_ds_tally(c->stream, c->d_ds, c->ds_stride_f, c->n, c->d_ds_desc, drows,
+                                    c->d_ds_tally));
+        }
+        {
+            ProfScope ps(c, P_PARAMS);
+            HIP_TRY(launch_ds_params(c->stream, c->d_ds_tally, c->d_ds_desc, drows, c->n,
+                                     dev_params(c->params), c->d_ds_rowp, c->d_ds_stats, c->d_nloci));
+        }
+        {
+            ProfScope ps(c, P_ACCUM);
+            HIP_TRY(launch_ds_accumulate(c->stream, c->d_ds, c->ds_stride_f, c->n, c->d_ds_rowp, drows,
+                                         c->d_part));
+        }
+        HIP_TRY(hipMemcpyAsync(c->h_ds_stats, c->d_ds_stats, sizeof(nps_locus_stat) * drows,
+                               hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(nps_locus_stat) * rows,
-                           hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * rows, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (auto &p : c->pending) c->ready.push_back(p.batch_idx >= 0 ? c->h_stats[p.batch_idx] : p.host);
+    for (auto &p : c->pending)
+        c->ready.push_back(p.batch_idx < 0 ? p.host
+                                           : (p.is_ds ? c->h_ds_stats[p.batch_idx] : c->h_stats[p.batch_idx]));
     c->pending.clear();
     c->batch_rows = 0;
+    c->ds_rows = 0;
     return NPS_OK;
 }
 
@@ -447,6 +505,7 @@ static int begin_data_row(nps_ctx *c, int ref_is_effect, double beta, double eaf
 static void commit_data_row(nps_ctx *c, uint32_t slot) {
     PendingRow p;
     p.batch_idx = (int32_t)slot;
+    p.is_ds = 0;
     memset(&p.host, 0, sizeof p.host);
     c->pending.push_back(p);
     c->batch_rows = slot + 1;
@@ -507,10 +566,70 @@ extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effec
     return NPS_OK;
 }
 
+// lazily allocate the DS streaming batch
+static int ensure_ds(nps_ctx *c) {
+    if (c->d_ds) return NPS_OK;
+    c->ds_stride_f = ds_stride_floats(c->n);
+    const uint64_t row_bytes = c->ds_stride_f * 4;
+    uint64_t cap = (64ull << 20) / row_bytes;
+    cap = std::max<uint64_t>(4, std::min<uint64_t>(cap, 1024));
+    c->ds_cap = (uint32_t)cap;
+    HIP_TRY(hipMalloc(&c->d_ds, row_bytes * cap));
+    HIP_TRY(hipMemsetAsync(c->d_ds, 0, row_bytes * cap, c->stream));
+    HIP_TRY(hipMalloc(&c->d_ds_desc, sizeof(nps_row_desc) * cap));
+    HIP_TRY(hipMalloc(&c->d_ds_tally, sizeof(DsTally) * cap));
+    HIP_TRY(hipMalloc(&c->d_ds_rowp, sizeof(DsRowP) * cap));
+    HIP_TRY(hipMalloc(&c->d_ds_stats, sizeof(nps_locus_stat) * cap));
+    auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
+    const size_t sz_desc = up(sizeof(nps_row_desc) * cap), sz_stats = up(sizeof(nps_locus_stat) * cap);
+    const size_t sz_raw = up(sizeof(float) * std::max<uint64_t>(c->n, 1));
+    size_t total = (sz_desc + sz_stats + 2 * sz_raw + 65535) / 65536 * 65536;
+    HIP_TRY(hipHostMalloc(&c->h_ds_arena, total));
+    char *p = (char *)c->h_ds_arena;
+    c->h_ds_desc = (nps_row_desc *)p;
+    p += sz_desc;
+    c->h_ds_stats = (nps_locus_stat *)p;
+    p += sz_stats;
+    for (int k = 0; k < 2; ++k) {
+        c->h_ds_raw[k] = (float *)p;
+        p += sz_raw;
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_ds_raw[k], hipEventDisableTiming));
+    }
+    return NPS_OK;
+}
+
 extern "C" int nps_push_ds(nps_ctx *c, const float *ds, int ref_is_effect, double beta, double eaf) {
-    (void)ds; (void)ref_is_effect; (void)beta; (void)eaf;
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
-    return fail(NPS_E_UNSUPPORTED, "FORMAT/DS path not built yet");
+    if (c->n && !ds) return fail(NPS_E_INVAL, "ds is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_ds(c);
+    if (rc) return rc;
+    if (c->ds_rows == c->ds_cap) {
+        rc = run_batch(c);
+        if (rc) return rc;
+    }
+    const uint32_t slot = c->ds_rows;
+    nps_row_desc &d = c->h_ds_desc[slot];
+    d.beta = beta;
+    d.eaf = eaf;
+    d.kind = NPS_ROW_PRESENT;
+    d.ref_is_effect = ref_is_effect ? 1 : 0;
+    if (c->n) {
+        const int k = c->ds_raw_next;
+        c->ds_raw_next = (k + 1) % 2;
+        HIP_TRY(hipEventSynchronize(c->ev_ds_raw[k]));
+        memcpy(c->h_ds_raw[k], ds, sizeof(float) * c->n);
+        HIP_TRY(hipMemcpyAsync(c->d_ds + (uint64_t)slot * c->ds_stride_f, c->h_ds_raw[k],
+                               sizeof(float) * c->n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_ds_raw[k], c->stream));
+    }
+    PendingRow p;
+    p.batch_idx = (int32_t)slot;
+    p.is_ds = 1;
+    memset(&p.host, 0, sizeof p.host);
+    c->pending.push_back(p);
+    c->ds_rows = slot + 1;
+    return NPS_OK;
 }
 
 extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double beta, double eaf) {
@@ -519,6 +638,7 @@ extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double be
         return fail(NPS_E_INVAL, "kind %d is not a no-data row kind", kind);
     PendingRow p;
     p.batch_idx = -1;
+    p.is_ds = 0;
     host_locus_row(c, kind, ref_is_effect, beta, eaf, &p.host);
     c->pending.push_back(p);
     return NPS_OK;
@@ -608,8 +728,8 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
                                  int format) {
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
-    if (format != NPS_FMT_GT2)
-        return fail(NPS_E_UNSUPPORTED, "cohort format %d not built yet", format);
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32)
+        return fail(NPS_E_INVAL, "unknown cohort format %d", format);
     if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
     int rc = select_device(device);
     if (rc) return rc;
@@ -619,7 +739,8 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     c->format = format;
     c->n_samples = n_samples;
     c->n_rows = n_rows;
-    c->stride_bytes = stride_words_for(n_samples) * 4;
+    c->stride_bytes = format == NPS_FMT_DS32 ? ds_stride_floats(n_samples) * 4
+                                              : stride_words_for(n_samples) * 4;
     const uint64_t bytes = std::max<uint64_t>(c->stride_bytes * n_rows, 256);
     hipError_t e = hipMalloc(&c->d_data, bytes);
     if (e != hipSuccess) {
@@ -661,7 +782,7 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
-    const size_t width = words_for(c->n_samples) * 4;
+    const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
@@ -674,7 +795,7 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
                                    void *host_rows, size_t host_stride) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
-    const size_t width = words_for(c->n_samples) * 4;
+    const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
@@ -699,8 +820,12 @@ extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, ui
     const uint64_t step = 32768;
     for (uint64_t r = 0; e == hipSuccess && r < nrows; r += step) {
         const uint64_t k = std::min(step, nrows - r);
-        e = launch_synth_gt(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
-                            row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
+        if (c->format == NPS_FMT_DS32)
+            e = launch_synth_ds(nullptr, (float *)c->d_data, c->stride_bytes / 4, c->n_samples,
+                                row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
+        else
+            e = launch_synth_gt(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
+                                row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_t);
@@ -829,9 +954,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (co->n_samples != c->n)
         return fail(NPS_E_INVAL, "cohort has %llu samples, context %llu",
                     (unsigned long long)co->n_samples, (unsigned long long)c->n);
-    if (co->format != NPS_FMT_GT2) return fail(NPS_E_UNSUPPORTED, "cohort format not supported");
     if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
+    if (co->format == NPS_FMT_DS32) {
+        if (mode == NPS_MODE_FUSED)
+            return fail(NPS_E_UNSUPPORTED, "the fused kernel handles 2-bit GT cohorts only");
+        mode = NPS_MODE_TWOPASS;
+    }
     HIP_TRY(hipSetDevice(c->device));
     FusedPlan plan;
     if (mode != NPS_MODE_TWOPASS) {
@@ -867,6 +996,44 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     const uint64_t m_pad = (m + 15) / 16 * 16;
     rc = ensure_resident_buffers(c, m_pad);
     if (rc) return rc;
+    if (co->format == NPS_FMT_DS32) {
+        if (m_pad > c->res_ds_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_rds_tally);
+            (void)hipFree(c->d_rds_rowp);
+            c->d_rds_tally = nullptr;
+            c->d_rds_rowp = nullptr;
+            c->res_ds_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_rds_tally, sizeof(DsTally) * m_pad));
+            HIP_TRY(hipMalloc(&c->d_rds_rowp, sizeof(DsRowP) * m_pad));
+            c->res_ds_cap = m_pad;
+        }
+        const uint64_t stride_f = co->stride_bytes / 4;
+        const float *ds = (const float *)co->d_data + cohort_row0 * stride_f;
+        // blocks of ~96 MB: tally reads HBM, the accumulation right behind it hits the Infinity Cache
+        uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
+        if (block_rows == 0) block_rows = std::max<uint64_t>(16, (96ull << 20) / co->stride_bytes);
+        for (uint64_t r0 = 0; r0 < m; r0 += block_rows) {
+            const uint64_t k = std::min(block_rows, m - r0);
+            {
+                ProfScope ps(c, P_TALLY);
+                HIP_TRY(launch_ds_tally(c->stream, ds + r0 * stride_f, stride_f, c->n, def->d_desc + r0,
+                                        k, c->d_rds_tally + r0));
+            }
+            {
+                ProfScope ps(c, P_PARAMS);
+                HIP_TRY(launch_ds_params(c->stream, c->d_rds_tally + r0, def->d_desc + r0, k, c->n,
+                                         dev_params(c->params), c->d_rds_rowp + r0, c->d_rstats + r0,
+                                         c->d_nloci));
+            }
+            {
+                ProfScope ps(c, P_ACCUM);
+                HIP_TRY(launch_ds_accumulate(c->stream, ds + r0 * stride_f, stride_f, c->n,
+                                             c->d_rds_rowp + r0, k, c->d_part));
+            }
+        }
+        return NPS_OK;
+    }
     const uint64_t stride_words = co->stride_bytes / 4;
     const uint32_t *codes = (const uint32_t *)co->d_data + cohort_row0 * stride_words;
     if (plan.ok && c->n) {

@@ -83,4 +83,29 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
 hipError_t launch_fold(hipStream_t st, const double *d_part, uint32_t Q, uint64_t team_stride,
                        uint64_t n_samples, double *d_part0);
 
+// ---- FORMAT/DS float32 path (nps_ds.hip) ---------------------------------------------------------
+struct DsTally {
+    unsigned long long nmiss;
+    double neff;
+};
+struct DsRowP {
+    double beta, imp, cst;
+    int32_t mode;  // 0 dropped, 1 genotyped (imp = value for missing samples), 2 locus constant cst
+    int32_t rie;   // effect allele is REF: dosage = 2 - DS
+};
+static inline uint64_t ds_stride_floats(uint64_t n_samples) {
+    uint64_t w = n_samples ? n_samples : 1;
+    return (w + 63) / 64 * 64;
+}
+hipError_t launch_ds_tally(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
+                           const nps_row_desc *d_desc, uint64_t n_rows, DsTally *d_tally);
+hipError_t launch_ds_params(hipStream_t st, const DsTally *d_tally, const nps_row_desc *d_desc,
+                            uint64_t n_rows, uint64_t n_samples, DevParams p, DsRowP *d_rowp,
+                            nps_locus_stat *d_stats, unsigned long long *d_nloci);
+hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
+                                const DsRowP *d_rowp, uint64_t n_rows, double *d_part0);
+hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
+                           uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                           const uint32_t *d_t_hom, const uint32_t *d_t_miss);
+
 }  // namespace nps

@@ -402,3 +402,101 @@ def test_linearity_property_large():
     dev.close()
     scale = np.sum(np.abs(b1) + np.abs(b2)) / (2 * m)
     assert np.max(np.abs(outs[2] - (outs[0] + outs[1]))) <= 1e-12 * scale * 10
+
+
+# ------------------------------------------------------------------------------------------
+# FORMAT/DS (float32 dosage) path -- build-defined extension, oracle = ref_row_ds
+def make_ds_cohort(n, m, seed, rng):
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.10, m)           # mean 5 %: about half the rows exceed maxmis = 0.05
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    rie = (rng.uniform(size=m) < 0.3).astype(np.int32)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    ds = refcpu.synth_rows_ds(n, 0, m, seed, th, tm, tmi)
+    return dict(n=n, m=m, eaf=eaf, beta=beta, rie=rie, th=th, tm=tm, tmi=tmi, ds=ds, seed=seed)
+
+
+def oracle_ds(co, kw, offset):
+    sc = refcpu.RefScorer(co["n"], refcpu.make_params(**kw))
+    for j in range(co["m"]):
+        sc.row_ds(co["ds"][j], bool(co["rie"][j]), co["beta"][j], co["eaf"][j])
+    scores, nloci = sc.finish(offset)
+    return scores, sc.stats, nloci
+
+
+def assert_ds_stats(gpu_stats, ref_stats):
+    assert len(gpu_stats) == len(ref_stats)
+    for k, (g, r) in enumerate(zip(gpu_stats, ref_stats)):
+        assert int(g["ngenotyped"]) == int(r[0]) and int(g["nmissing"]) == int(r[1]), (k, g, r)
+        # neffect is a float64 sum here: fixed-shape tree on the GPU, sequential in the oracle
+        assert abs(float(g["neffect"]) - float(r[2])) <= 1e-9 * max(1.0, abs(float(r[2]))), (k, g, r)
+        assert int(g["used"]) == int(r[3]) and int(g["reason"]) == int(r[4]), (k, g, r)
+
+
+@pytest.mark.parametrize("pk", [0, 1, 4])
+@pytest.mark.parametrize("shape", [(1, 2), (63, 5), (1000, 40), (5003, 70)])
+def test_ds_streaming_vs_oracle(shape, pk):
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + pk)
+    co = make_ds_cohort(n, m, 99, rng)
+    kw = PARAM_GRID[pk]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for j in range(m):
+        sc.push_ds(co["ds"][j], co["rie"][j], co["beta"][j], co["eaf"][j])
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.3)
+    sc.close()
+    ref_scores, ref_stats, ref_nloci = oracle_ds(co, kw, 0.3)
+    assert nloci == ref_nloci
+    assert_ds_stats(stats, ref_stats)
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+@pytest.mark.parametrize("shape", [(100, 3), (4099, 129), (30000, 500)])
+def test_ds_resident_vs_oracle(shape):
+    n, m = shape
+    rng = np.random.default_rng(n + 3 * m)
+    co = make_ds_cohort(n, m, 2025, rng)
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=100)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_DS32)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    got = dev.download(0, m)
+    assert np.array_equal(got.view(np.uint32) & 0x7fffffff > 0x7f800000, np.isnan(co["ds"]))
+    assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(co["ds"], nan=-1.0))
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]))
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_ds(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert 0 < sum(1 for s in ref_stats if s[4] == 4) < m     # both branches exercised
+    assert_ds_stats(stats, ref_stats)
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+
+
+def test_ds_and_gt_rows_mixed_in_one_score():
+    n = 777
+    rng = np.random.default_rng(4)
+    gt = make_cohort(n, 12, 8, rng, force_missing_rows=False)
+    dsc = make_ds_cohort(n, 9, 9, rng)
+    kw = PARAM_GRID[0]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    ref = refcpu.RefScorer(n, refcpu.make_params(**kw))
+    betas = []
+    for j in range(12):
+        sc.push_packed(gt["codes"][j], gt["rie"][j], gt["beta"][j], gt["eaf"][j])
+        ref.row_gt(refcpu.codes_to_gt(gt["codes"][j], n), 2, 1, bool(gt["rie"][j]), gt["beta"][j], gt["eaf"][j])
+        betas.append(gt["beta"][j])
+        if j < 9:
+            sc.push_ds(dsc["ds"][j], dsc["rie"][j], dsc["beta"][j], dsc["eaf"][j])
+            ref.row_ds(dsc["ds"][j], bool(dsc["rie"][j]), dsc["beta"][j], dsc["eaf"][j])
+            betas.append(dsc["beta"][j])
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    ref_scores, ref_nloci = ref.finish(0.0)
+    assert nloci == ref_nloci and len(stats) == 21
+    assert [int(s["nmissing"]) for s in stats] == [int(s[1]) for s in ref.stats]
+    assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
