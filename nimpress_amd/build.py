@@ -49,9 +49,38 @@ def build_libnps(force: bool = False, verbose: bool = False) -> str:
     return LIBNPS
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+LIBHOST = os.path.join(PKG_DIR, "libnimpress_host.so")
+CLI = os.path.join(PKG_DIR, "nimpress")
+GXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off"]
+
+
+def build_host(force: bool = False, verbose: bool = False) -> List[str]:
+    """The host side above the C-ABI (C++): libnimpress_host.so + the `nimpress` CLI.  Plain g++,
+    links libnps.so (rpath $ORIGIN) and zlib."""
+    build_libnps(force=False, verbose=verbose)
+    gxx = shutil.which("g++") or "g++"
+    srcs = [os.path.join(HOST_DIR, "nimpress_host.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "nimpress_host.hpp"), LIBNPS,
+                   os.path.join(os.path.dirname(PKG_DIR), "include", "nps.h")]
+    link = ["-L" + PKG_DIR, "-lnps", "-lz", "-Wl,-rpath,$ORIGIN"]
+    if force or _stale(LIBHOST, deps):
+        cmd = [gxx] + GXX_FLAGS + ["-shared", "-o", LIBHOST] + srcs + link
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    main_src = os.path.join(HOST_DIR, "main.cpp")
+    if force or _stale(CLI, deps + [main_src]):
+        cmd = [gxx] + GXX_FLAGS + ["-o", CLI, main_src] + srcs + link
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return [LIBHOST, CLI]
+
+
 def build_all(force: bool = False, verbose: bool = False) -> List[str]:
-    """Everything native in this package (currently libnps.so)."""
-    return [build_libnps(force=force, verbose=verbose)]
+    """Everything native in this package: libnps.so (HIP), libnimpress_host.so + nimpress (C++)."""
+    return [build_libnps(force=force, verbose=verbose)] + build_host(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

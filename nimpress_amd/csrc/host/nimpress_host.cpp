@@ -1,0 +1,714 @@
+// nimpress_host.cpp -- see nimpress_host.hpp.  Host-side mirror of the reference module around the
+// libnps C-ABI: parsing, lookup, control flow, warnings, formatting.  No per-sample arithmetic.
+#include "nimpress_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "../../../include/nps.h"
+
+namespace nimpress {
+
+// ------------------------------------------------------------------------------------------
+// small text helpers with Nim stdlib semantics
+static std::string stripTrailing(std::string s) {  // strip(leading = false)
+    while (!s.empty() && (s.back() == ' ' || (s.back() >= '\t' && s.back() <= '\r'))) s.pop_back();
+    return s;
+}
+
+static std::vector<std::string> splitChar(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    size_t a = 0;
+    while (true) {
+        size_t b = s.find(sep, a);
+        if (b == std::string::npos) {
+            out.push_back(s.substr(a));
+            break;
+        }
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+    return out;
+}
+
+// lines as Nim's readLine / lines iterator yields them: terminators LF, CRLF or CR removed; a final
+// unterminated line is a line; a trailing terminator does not create an extra empty line
+static std::vector<std::string> splitLines(const std::string &text) {
+    std::vector<std::string> out;
+    size_t a = 0;
+    const size_t n = text.size();
+    while (a < n) {
+        size_t b = a;
+        while (b < n && text[b] != '\n' && text[b] != '\r') ++b;
+        out.push_back(text.substr(a, b - a));
+        if (b < n && text[b] == '\r' && b + 1 < n && text[b + 1] == '\n') ++b;
+        a = b + 1;
+    }
+    return out;
+}
+
+static double parseFloatNim(const std::string &s) {
+    if (s.empty()) throw std::runtime_error("invalid float: (empty)");
+    errno = 0;
+    char *end = nullptr;
+    const double v = strtod(s.c_str(), &end);
+    if (end == s.c_str() || *end != 0) throw std::runtime_error("invalid float: " + s);
+    return v;
+}
+
+static int64_t parseIntNim(const std::string &s) {
+    if (s.empty()) throw std::runtime_error("invalid integer: (empty)");
+    size_t i = 0;
+    if (s[0] == '+' || s[0] == '-') i = 1;
+    if (i == s.size()) throw std::runtime_error("invalid integer: " + s);
+    for (size_t k = i; k < s.size(); ++k)
+        if (s[k] < '0' || s[k] > '9') throw std::runtime_error("invalid integer: " + s);
+    return strtoll(s.c_str(), nullptr, 10);
+}
+
+static bool readFile(const std::string &path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+std::string formatFloat(double x) {
+    if (std::isnan(x)) return "nan";
+    if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.16g", x);
+    std::string s(buf);
+    if (s.find_first_of(".en") == std::string::npos) s += ".0";
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+bool parseEnum(const std::string &s, ImputeMethodLocus &out) {
+    static const char *names[] = {"ps", "homref", "fail", "ignore"};
+    for (int i = 0; i < 4; ++i)
+        if (s == names[i]) {
+            out = (ImputeMethodLocus)i;
+            return true;
+        }
+    return false;
+}
+bool parseEnum(const std::string &s, ImputeMethodMissing &out) {
+    static const char *names[] = {"homref", "ignore"};
+    for (int i = 0; i < 2; ++i)
+        if (s == names[i]) {
+            out = (ImputeMethodMissing)i;
+            return true;
+        }
+    return false;
+}
+bool parseEnum(const std::string &s, ImputeMethodSample &out) {
+    static const char *names[] = {"ps", "homref", "fail", "int_ps", "int_fail"};
+    for (int i = 0; i < 5; ++i)
+        if (s == names[i]) {
+            out = (ImputeMethodSample)i;
+            return true;
+        }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// ScoreFile  nim:233-254
+bool ScoreFile::open(const std::string &path) {
+    std::string text;
+    if (!readFile(path, text)) return false;
+    const std::vector<std::string> lines = splitLines(text);
+    if (lines.size() < 5) throw std::runtime_error("score file has fewer than 5 header lines: " + path);
+    name = stripTrailing(lines[0]);
+    desc = stripTrailing(lines[1]);
+    cite = stripTrailing(lines[2]);
+    genomever = stripTrailing(lines[3]);
+    offset = parseFloatNim(stripTrailing(lines[4]));
+    entries.clear();
+    for (size_t i = 5; i < lines.size(); ++i) {
+        const std::vector<std::string> parts = splitChar(stripTrailing(lines[i]), '\t');
+        if (parts.size() != 6)  // doAssert lineparts.len == 6, nim:252
+            throw std::runtime_error("score file " + path + " line " + std::to_string(i + 1) +
+                                     ": expected 6 tab-separated fields");
+        ScoreEntry e;
+        e.contig = parts[0];
+        e.pos = parseIntNim(parts[1]);
+        e.refseq = parts[2];
+        e.easeq = parts[3];
+        e.beta = parseFloatNim(parts[4]);
+        e.eaf = parseFloatNim(parts[5]);
+        entries.push_back(std::move(e));
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// GenomeIntervals  nim:278-345
+bool loadBedIntervals(GenomeIntervals &ivals, const std::string &path) {
+    std::string text;
+    if (!readFile(path, text)) return false;
+    ivals.init = false;
+    ivals.contigIntervals.clear();
+    for (const std::string &line : splitLines(text)) {
+        const std::vector<std::string> parts = splitChar(stripTrailing(line), '\t');
+        if (parts.size() < 3) throw std::runtime_error("BED line with fewer than 3 fields: " + line);
+        ivals.contigIntervals[parts[0]].emplace_back(parseIntNim(parts[1]), parseIntNim(parts[2]));
+    }
+    ivals.init = true;
+    return true;
+}
+
+bool isVariantCovered(const ScoreEntry &e, const GenomeIntervals &ivals, std::string *warning) {
+    auto it = ivals.contigIntervals.find(e.contig);
+    if (it == ivals.contigIntervals.end()) {  // nim:325-328
+        if (warning) *warning = "Contig " + e.contig + " not present within the coverage BED file.";
+        return false;
+    }
+    // the reference pre-selects overlapping intervals with lapper (nim:337); the decision is the
+    // containment predicate of nim:310-311
+    for (const auto &iv : it->second)
+        if (iv.first < e.pos && iv.second >= e.stop()) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// VCF reader (text; plain or gzip/BGZF)
+static bool inflateAll(const std::string &in, std::string &out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;  // gzip or zlib header, auto-detected
+    zs.next_in = (Bytef *)in.data();
+    zs.avail_in = (uInt)std::min<size_t>(in.size(), std::numeric_limits<uInt>::max());
+    size_t consumed_total = 0;
+    std::vector<char> buf(1 << 20);
+    out.clear();
+    while (true) {
+        zs.next_out = (Bytef *)buf.data();
+        zs.avail_out = (uInt)buf.size();
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        out.append(buf.data(), buf.size() - zs.avail_out);
+        if (rc == Z_STREAM_END) {
+            // BGZF = concatenated gzip members: continue with the next one if input remains
+            consumed_total = in.size() - zs.avail_in;
+            if (consumed_total >= in.size()) break;
+            if (inflateReset(&zs) != Z_OK) {
+                inflateEnd(&zs);
+                return false;
+            }
+            continue;
+        }
+        if (rc != Z_OK) {
+            inflateEnd(&zs);
+            return false;
+        }
+        if (zs.avail_in == 0 && zs.avail_out != 0) break;  // truncated input: keep what we have
+    }
+    inflateEnd(&zs);
+    return true;
+}
+
+static const int32_t kVectorEnd = (int32_t)0x80000001u;
+
+// one sample's GT subfield -> alleles in the bcf_get_genotypes encoding
+static int encodeGT(const char *p, const char *end, int32_t *out, int cap) {
+    int n = 0;
+    bool phased = false;
+    const char *a = p;
+    while (true) {
+        const char *b = a;
+        while (b < end && *b != '/' && *b != '|') ++b;
+        int32_t v;
+        if (b == a || (b - a == 1 && *a == '.')) {
+            v = 0;  // missing allele
+        } else {
+            long k = 0;
+            for (const char *c = a; c < b; ++c) {
+                if (*c < '0' || *c > '9') throw std::runtime_error("bad GT allele");
+                k = k * 10 + (*c - '0');
+            }
+            v = (int32_t)((k + 1) << 1);
+        }
+        if (phased) v |= 1;
+        if (n < cap) out[n] = v;
+        ++n;
+        if (b >= end) break;
+        phased = *b == '|';
+        a = b + 1;
+    }
+    return n;
+}
+
+bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
+    std::string raw;
+    if (!readFile(path, raw)) return false;
+    std::string text;
+    if (raw.size() >= 2 && (unsigned char)raw[0] == 0x1f && (unsigned char)raw[1] == 0x8b) {
+        if (!inflateAll(raw, text)) return false;
+        raw.clear();
+        raw.shrink_to_fit();
+    } else {
+        text.swap(raw);
+    }
+    if (text.compare(0, 3, "BCF") == 0)
+        throw std::runtime_error("BCF input is not supported by this reader yet (use VCF text / vcf.gz)");
+
+    std::unordered_map<std::string, std::vector<std::pair<int64_t, int64_t>>> wanted;
+    if (keep)
+        for (const ScoreEntry &e : *keep) wanted[e.contig].emplace_back(e.pos, e.stop());
+
+    samples.clear();
+    records.clear();
+    bool have_header = false;
+    size_t a = 0;
+    const size_t n = text.size();
+    std::vector<int32_t> tmp;
+    while (a < n) {
+        size_t b = text.find('\n', a);
+        if (b == std::string::npos) b = n;
+        size_t e = b;
+        if (e > a && text[e - 1] == '\r') --e;  // CRLF (tests/set1.vcf.gz)
+        if (e > a) {
+            const char *L = text.data() + a;
+            const size_t len = e - a;
+            if (L[0] == '#') {
+                if (len > 6 && memcmp(L, "#CHROM", 6) == 0) {
+                    std::vector<std::string> cols = splitChar(std::string(L, len), '\t');
+                    for (size_t k = 9; k < cols.size(); ++k) samples.push_back(cols[k]);
+                    have_header = true;
+                }
+            } else {
+                if (!have_header) throw std::runtime_error("VCF record before the #CHROM header line");
+                // first 9 columns
+                const char *col[10];
+                const char *p = L, *end = L + len;
+                int nc = 0;
+                col[nc++] = p;
+                while (nc < 10 && p < end) {
+                    if (*p == '\t') col[nc++] = p + 1;
+                    ++p;
+                }
+                if (nc < 8) throw std::runtime_error("VCF record with fewer than 8 columns");
+                auto field = [&](int k) {
+                    const char *s = col[k];
+                    const char *t = (k + 1 < nc) ? col[k + 1] - 1 : end;
+                    return std::string(s, t - s);
+                };
+                Variant v;
+                v.contig = field(0);
+                v.pos = parseIntNim(field(1));
+                v.id = field(2);
+                v.ref = field(3);
+                bool want = true;
+                if (keep) {
+                    want = false;
+                    auto it = wanted.find(v.contig);
+                    if (it != wanted.end()) {
+                        const int64_t rend = v.pos + (int64_t)v.ref.size() - 1;
+                        for (const auto &w : it->second)
+                            if (v.pos <= w.second && rend >= w.first) {
+                                want = true;
+                                break;
+                            }
+                    }
+                }
+                if (want) {
+                    const std::string alt = field(4);
+                    if (alt != ".") v.alt = splitChar(alt, ',');
+                    v.filter = field(6);
+                    const size_t ns = samples.size();
+                    if (ns) {
+                        if (nc < 10) throw std::runtime_error("VCF record without sample columns");
+                        const std::vector<std::string> fmt = splitChar(field(8), ':');
+                        int gi = -1;
+                        for (size_t k = 0; k < fmt.size(); ++k)
+                            if (fmt[k] == "GT") gi = (int)k;
+                        if (gi < 0) throw std::runtime_error("VCF record without FORMAT/GT at " + v.contig + ":" + field(1));
+                        const int cap = 8;
+                        tmp.assign(ns * cap, kVectorEnd);
+                        int ploidy = 0;
+                        const char *s = col[9];
+                        for (size_t i = 0; i < ns; ++i) {
+                            const char *t = s;
+                            while (t < end && *t != '\t') ++t;
+                            // gi-th ':' separated subfield of [s,t)
+                            const char *g0 = s;
+                            for (int k = 0; k < gi && g0 < t; ++k) {
+                                while (g0 < t && *g0 != ':') ++g0;
+                                if (g0 < t) ++g0;
+                            }
+                            const char *g1 = g0;
+                            while (g1 < t && *g1 != ':') ++g1;
+                            const int na = encodeGT(g0, g1, &tmp[i * cap], cap);
+                            if (na > cap) throw std::runtime_error("ploidy above 8 is not supported");
+                            ploidy = std::max(ploidy, na);
+                            if (t >= end && i + 1 < ns)
+                                throw std::runtime_error("VCF record with too few sample columns");
+                            s = t + 1;
+                        }
+                        v.ploidy = ploidy;
+                        v.gts.resize(ns * ploidy);
+                        for (size_t i = 0; i < ns; ++i)
+                            for (int k = 0; k < ploidy; ++k) v.gts[i * ploidy + k] = tmp[i * cap + k];
+                    }
+                    records.push_back(std::move(v));
+                }
+            }
+        }
+        a = b + 1;
+    }
+    return have_header;
+}
+
+const Variant *findVariant(const std::string &contig, int64_t pos, const std::string &refseq,
+                           const std::string &easeq, const VCF &vcf) {
+    const int64_t stop = pos + (int64_t)refseq.size() - 1;
+    for (const Variant &v : vcf.records) {  // file order = the order a region query returns
+        if (v.contig != contig) continue;
+        const int64_t vend = v.pos + (int64_t)v.ref.size() - 1;
+        if (v.pos > stop || vend < pos) continue;
+        if (v.ref != refseq) continue;  // nim:359 -- POS itself is never compared
+        if (easeq == refseq) return &v;
+        for (const std::string &a : v.alt)
+            if (a == easeq) return &v;
+    }
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// stats for the AF-mismatch warnings  nim:50-188
+static double lbinom(int64_t n, int64_t k) {
+    return lgamma((double)n + 1.0) - lgamma((double)k + 1.0) - lgamma((double)(n - k) + 1.0);
+}
+
+double dbinom(int64_t x, int64_t n, double p) {
+    if ((x == 0 && p == 0.0) || (x == n && p == 1.0)) return 1.0;
+    return exp(lbinom(n, x) + (double)x * log(p) + (double)(n - x) * log(1.0 - p));
+}
+
+static double betacf(double a, double b, double x) {  // modified Lentz, 100 iterations, eps 3e-7
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0, tiny = 1.0e-30;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 100; ++m) {
+        const double mf = (double)m;
+        double aa = mf * (b - mf) * x / ((qam + 2 * mf) * (a + 2 * mf));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + mf) * (qab + mf) * x / ((a + 2 * mf) * (qap + 2 * mf));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 3.0e-7) return h;
+    }
+    return std::numeric_limits<double>::quiet_NaN();  // not converged (nim:117)
+}
+
+double betai(double a, double b, double x) {
+    if (!(x >= 0.0 && x <= 1.0)) throw std::runtime_error("betai: x outside [0,1]");
+    if (a == 0.0 || b == 0.0) return std::numeric_limits<double>::infinity();
+    if (x == 0.0) return 0.0;
+    if (x == 1.0) return 1.0;
+    const double bt = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log(1.0 - x));
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * betacf(a, b, x) / a;
+    return 1.0 - bt * betacf(b, a, 1.0 - x) / b;
+}
+
+double pbinom(int64_t x, int64_t n, double p) {
+    if (x < 0) return 0.0;
+    if (x == n) return 1.0;
+    return 1.0 - betai((double)x + 1.0, (double)(n - x), p);
+}
+
+double binomTest(int64_t x, int64_t n, double p) {
+    if (p == 0.0) return x == 0 ? 1.0 : 0.0;
+    if (p == 1.0) return x == n ? 1.0 : 0.0;
+    const double probx = dbinom(x, n, p), expected = (double)n * p;
+    if (fabs((double)x / expected - 1.0) < 1.0e-6) return 1.0;
+    const double bound = probx * (1.0 + 1.0e-7);
+    int64_t y = 0;
+    if ((double)x < expected) {
+        for (int64_t xi = (int64_t)ceil(expected); xi <= n; ++xi)
+            if (dbinom(xi, n, p) <= bound) ++y;
+        return pbinom(x, n, p) + (1.0 - pbinom(n - y, n, p));
+    }
+    for (int64_t xi = 0; xi <= (int64_t)floor(expected); ++xi)
+        if (dbinom(xi, n, p) <= bound) ++y;
+    return pbinom(y - 1, n, p) + (1.0 - pbinom(x - 1, n, p));
+}
+
+// ------------------------------------------------------------------------------------------
+void Log::warn(const std::string &m) {
+    lines.push_back("WARN " + m);
+    if (echo) {
+        fputs(lines.back().c_str(), stdout);
+        fputc('\n', stdout);
+    }
+}
+void Log::fatal(const std::string &m) {
+    lines.push_back("FATAL " + m);
+    if (echo) {
+        fputs(lines.back().c_str(), stdout);
+        fputc('\n', stdout);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// computePolygenicScores  nim:592-649 with getImputedDosages' control flow (nim:523-585)
+static void npsCheck(int rc, const char *what) {
+    if (rc != NPS_OK)
+        throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " +
+                                 nps_last_error());
+}
+
+void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreFile,
+                            const VCF &genotypeVcf, bool restrictToCoveredRgns,
+                            const GenomeIntervals &coveredIvals, ImputeMethodLocus imputeMethodLocus,
+                            ImputeMethodMissing imputeMethodMissing,
+                            ImputeMethodSample imputeMethodSample, double maxMissingRate,
+                            double afMismatchPthresh, int64_t minGtForInternalImput,
+                            bool ignoreFilterField, Log &log, int device, uint64_t *nloci_out) {
+    const int64_t nsamples = genotypeVcf.n_samples();
+    nps_params p;
+    p.imp_locus = (int32_t)imputeMethodLocus;
+    p.imp_missing = (int32_t)imputeMethodMissing;
+    p.imp_sample = (int32_t)imputeMethodSample;
+    p.reserved = 0;
+    p.max_missing_rate = maxMissingRate;
+    p.min_cs = minGtForInternalImput;
+    nps_ctx *ctx = nullptr;
+    npsCheck(nps_create(&ctx, device, (uint64_t)nsamples, &p), "nps_create");
+
+    struct Pushed {
+        const ScoreEntry *e;
+        int how;  // 0 = genotyped on the device, else nps_row_kind
+        const Variant *v;
+        std::string pre_warning;  // emitted before the device result is known (coverage contig)
+    };
+    std::vector<Pushed> pushed;
+    pushed.reserve(scoreFile.entries.size());
+    try {
+        for (const ScoreEntry &e : scoreFile.entries) {
+            const int rie = e.refseq == e.easeq ? 1 : 0;
+            Pushed rec{&e, 0, nullptr, ""};
+            if (restrictToCoveredRgns && !isVariantCovered(e, coveredIvals, &rec.pre_warning)) {
+                rec.how = NPS_ROW_UNCOVERED;  // nim:526-531
+                npsCheck(nps_push_locus(ctx, NPS_ROW_UNCOVERED, rie, e.beta, e.eaf), "nps_push_locus");
+            } else {
+                const Variant *v = findVariant(e.contig, e.pos, e.refseq, e.easeq, genotypeVcf);
+                rec.v = v;
+                if (!v) {  // nim:536-551
+                    rec.how = NPS_ROW_ABSENT;
+                    npsCheck(nps_push_locus(ctx, NPS_ROW_ABSENT, rie, e.beta, e.eaf), "nps_push_locus");
+                } else if (!ignoreFilterField && v->filter != "." && v->filter != "PASS") {  // :553
+                    rec.how = NPS_ROW_FILTERED;
+                    npsCheck(nps_push_locus(ctx, NPS_ROW_FILTERED, rie, e.beta, e.eaf), "nps_push_locus");
+                } else {
+                    int eaidx = 0;  // nim:375-379
+                    if (!rie) {
+                        eaidx = -1;
+                        for (size_t k = 0; k < v->alt.size(); ++k)
+                            if (v->alt[k] == e.easeq) {
+                                eaidx = (int)k + 1;
+                                break;
+                            }
+                    }
+                    npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
+                             "nps_push_gt");
+                }
+            }
+            pushed.push_back(std::move(rec));
+        }
+        // per-row results back, in order: emit the reference's warnings
+        std::vector<nps_locus_stat> stats(pushed.size());
+        size_t got = 0;
+        npsCheck(nps_flush(ctx, stats.data(), stats.size(), &got), "nps_flush");
+        if (got != pushed.size()) throw std::runtime_error("nps_flush returned too few rows");
+        for (size_t j = 0; j < pushed.size(); ++j) {
+            const ScoreEntry &e = *pushed[j].e;
+            const nps_locus_stat &st = stats[j];
+            const std::string locus = e.contig + ":" + std::to_string(e.pos);
+            const std::string var = locus + ":" + e.refseq + ":" + e.easeq;
+            if (!pushed[j].pre_warning.empty()) log.warn(pushed[j].pre_warning);
+            switch (pushed[j].how) {
+            case NPS_ROW_UNCOVERED:  // nim:527-530
+                log.warn("Locus " + locus + "-" + std::to_string(e.stop()) +
+                         " is not covered by the sequence coverage BED.  Imputing all dosages at this locus.");
+                break;
+            case NPS_ROW_ABSENT:  // nim:537-541
+                if (!std::isnan(e.eaf) && binomTest(0, nsamples * 2, e.eaf) < afMismatchPthresh)
+                    log.warn("Variant " + var + " cohort EAF is 0 in " + std::to_string(nsamples) +
+                             " samples.  This is highly unlikely given polygenic score EAF of " +
+                             formatFloat(e.eaf));
+                break;
+            case NPS_ROW_FILTERED:  // nim:554-557
+                log.warn("Variant " + var + " has a FILTER flag set (value \"" + pushed[j].v->filter +
+                         "\").  Imputing all dosages at this locus.");
+                break;
+            default:
+                if (st.reason == NPS_REASON_MAXMIS) {  // nim:567-570
+                    const double missingrate = (double)st.nmissing / (double)nsamples;
+                    log.warn("Locus " + locus + "-" + std::to_string(e.stop()) + " has " +
+                             formatFloat(missingrate * 100) +
+                             "% of samples missing a genotype. This exceeds the missingness threshold; "
+                             "imputing all dosages at this locus.");
+                } else {  // nim:573-579
+                    const int64_t nobs = (nsamples - (int64_t)st.nmissing) * 2;
+                    if (!std::isnan(e.eaf) &&
+                        binomTest((int64_t)st.neffect, nobs, e.eaf) < afMismatchPthresh)
+                        log.warn("Variant " + var + " cohort EAF is " +
+                                 formatFloat(st.neffect / (double)nobs) + " in " +
+                                 std::to_string(nsamples) +
+                                 " samples.  This is highly unlikely given polygenic score EAF of " +
+                                 formatFloat(e.eaf));
+                }
+                break;
+            }
+        }
+        scores.assign((size_t)nsamples, 0.0);
+        uint64_t nloci = 0;
+        npsCheck(nps_finish(ctx, scoreFile.offset, scores.data(), &nloci), "nps_finish");
+        if (nloci_out) *nloci_out = nloci;
+    } catch (...) {
+        nps_destroy(ctx);
+        throw;
+    }
+    nps_destroy(ctx);
+}
+
+}  // namespace nimpress
+
+// ------------------------------------------------------------------------------------------
+// C hooks for the Python tests of the host logic (no GPU needed except nh_compute)
+using namespace nimpress;
+
+extern "C" {
+
+static thread_local std::string g_nh_error;
+const char *nh_last_error(void) { return g_nh_error.c_str(); }
+
+// parse a score file: returns number of entries or -1; fills offset; arrays (if non-null) sized cap
+long nh_score_parse(const char *path, double *offset, long cap, long *pos, double *beta, double *eaf,
+                    int *ref_is_effect, char *text_out, long text_cap) {
+    try {
+        ScoreFile sf;
+        if (!sf.open(path)) {
+            g_nh_error = "cannot open";
+            return -1;
+        }
+        if (offset) *offset = sf.offset;
+        std::string text = sf.name + "\n" + sf.desc + "\n" + sf.cite + "\n" + sf.genomever + "\n";
+        for (size_t i = 0; i < sf.entries.size(); ++i) {
+            const ScoreEntry &e = sf.entries[i];
+            if ((long)i < cap) {
+                if (pos) pos[i] = e.pos;
+                if (beta) beta[i] = e.beta;
+                if (eaf) eaf[i] = e.eaf;
+                if (ref_is_effect) ref_is_effect[i] = e.refseq == e.easeq;
+            }
+            text += e.contig + "\t" + e.refseq + "\t" + e.easeq + "\n";
+        }
+        if (text_out && text_cap > 0) {
+            strncpy(text_out, text.c_str(), (size_t)text_cap - 1);
+            text_out[text_cap - 1] = 0;
+        }
+        return (long)sf.entries.size();
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return -2;
+    }
+}
+
+// coverage of every score entry against a BED: out[i] = 0/1; returns n or <0
+long nh_bed_covered(const char *score_path, const char *bed_path, int *out, long cap) {
+    try {
+        ScoreFile sf;
+        GenomeIntervals iv;
+        if (!sf.open(score_path) || !loadBedIntervals(iv, bed_path)) {
+            g_nh_error = "cannot open";
+            return -1;
+        }
+        for (size_t i = 0; i < sf.entries.size() && (long)i < cap; ++i)
+            out[i] = isVariantCovered(sf.entries[i], iv, nullptr) ? 1 : 0;
+        return (long)sf.entries.size();
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return -2;
+    }
+}
+
+// VCF: number of samples / records, and per score entry the found record index (or -1), its eaidx
+// and its GT buffer (flattened, ploidy returned)
+struct nh_vcf {
+    VCF vcf;
+};
+void *nh_vcf_open(const char *path, const char *score_path_or_null) {
+    try {
+        nh_vcf *h = new nh_vcf;
+        ScoreFile sf;
+        const std::vector<ScoreEntry> *keep = nullptr;
+        if (score_path_or_null && sf.open(score_path_or_null)) keep = &sf.entries;
+        if (!h->vcf.open(path, keep)) {
+            delete h;
+            g_nh_error = "cannot open";
+            return nullptr;
+        }
+        return h;
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return nullptr;
+    }
+}
+void nh_vcf_close(void *h) { delete (nh_vcf *)h; }
+long nh_vcf_n_samples(void *h) { return (long)((nh_vcf *)h)->vcf.samples.size(); }
+long nh_vcf_n_records(void *h) { return (long)((nh_vcf *)h)->vcf.records.size(); }
+const char *nh_vcf_sample(void *h, long i) { return ((nh_vcf *)h)->vcf.samples[(size_t)i].c_str(); }
+// returns record index or -1; fills pos, ploidy, filter (copied), gts (cap int32)
+long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const char *ea, long *rec_pos,
+                 int *ploidy, char *filter, long filter_cap, int *gts, long gts_cap) {
+    const VCF &vcf = ((nh_vcf *)h)->vcf;
+    const Variant *v = findVariant(contig, pos, ref, ea, vcf);
+    if (!v) return -1;
+    if (rec_pos) *rec_pos = v->pos;
+    if (ploidy) *ploidy = v->ploidy;
+    if (filter && filter_cap > 0) {
+        strncpy(filter, v->filter.c_str(), (size_t)filter_cap - 1);
+        filter[filter_cap - 1] = 0;
+    }
+    for (size_t i = 0; i < v->gts.size() && (long)i < gts_cap; ++i) gts[i] = v->gts[i];
+    return (long)(v - vcf.records.data());
+}
+
+double nh_dbinom(long x, long n, double p) { return dbinom(x, n, p); }
+double nh_pbinom(long x, long n, double p) { return pbinom(x, n, p); }
+double nh_binom_test(long x, long n, double p) { return binomTest(x, n, p); }
+double nh_betai(double a, double b, double x) { return betai(a, b, x); }
+void nh_format_float(double x, char *out, long cap) {
+    const std::string s = formatFloat(x);
+    strncpy(out, s.c_str(), (size_t)cap - 1);
+    out[cap - 1] = 0;
+}
+
+}  // extern "C"

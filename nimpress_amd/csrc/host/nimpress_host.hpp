@@ -1,0 +1,111 @@
+// nimpress_host.hpp -- host side above the libnps C-ABI, mirroring the reference module's exported
+// interface (src/nimpress.nim; cited as nim:LINE): ScoreFile/open/items (195-254), GenomeIntervals/
+// loadBedIntervals/isVariantCovered (262-345), findVariant (353-364), the three enums (412-414) and
+// computePolygenicScores (592-649).  The reference gets VCF access from hts-nim/htslib; neither is
+// available here, so this file carries a small reader of its own (text VCF, plain or BGZF/gzip).
+//
+// The per-row arithmetic is NOT here: computePolygenicScores hands every located record's
+// bcf_get_genotypes-layout buffer to libnps (HIP) and only keeps the reference's control flow,
+// warnings and output formatting.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace nimpress {
+
+// nim:412-414 (declaration order = the integer values the C-ABI takes)
+enum class ImputeMethodLocus { ps = 0, homref = 1, fail = 2, ignore = 3 };
+enum class ImputeMethodMissing { homref = 0, ignore = 1 };
+enum class ImputeMethodSample { ps = 0, homref = 1, fail = 2, int_ps = 3, int_fail = 4 };
+bool parseEnum(const std::string &s, ImputeMethodLocus &out);
+bool parseEnum(const std::string &s, ImputeMethodMissing &out);
+bool parseEnum(const std::string &s, ImputeMethodSample &out);
+
+// nim:221-231
+struct ScoreEntry {
+    std::string contig;
+    int64_t pos = 0;
+    std::string refseq, easeq;
+    double beta = 0.0, eaf = 0.0;
+    int64_t stop() const { return pos + (int64_t)refseq.size() - 1; }
+};
+
+// nim:195-254: 5 header lines (name, description, citation, genome version, offset) then 6-column
+// TSV rows.  open() returns false when the file cannot be opened; malformed content throws
+// std::runtime_error (the reference asserts / raises).
+struct ScoreFile {
+    std::string name, desc, cite, genomever;
+    double offset = 0.0;
+    std::vector<ScoreEntry> entries;  // file order (the reference's iterator is single-pass)
+    bool open(const std::string &path);
+};
+
+// nim:262-345.  BED: 0-based half-open; a locus is covered iff some interval has
+// start < pos && stop >= pos + len(ref) - 1  (nim:310-311).
+struct GenomeIntervals {
+    bool init = false;
+    std::map<std::string, std::vector<std::pair<int64_t, int64_t>>> contigIntervals;
+};
+bool loadBedIntervals(GenomeIntervals &ivals, const std::string &path);
+bool isVariantCovered(const ScoreEntry &e, const GenomeIntervals &ivals, std::string *warning);
+
+// What the reference reads through hts-nim: one record with its FORMAT/GT in the
+// bcf_get_genotypes layout (n_samples*ploidy int32, (allele+1)<<1|phased, 0 = missing allele,
+// 0x80000001 = vector-end pad).
+struct Variant {
+    std::string contig;
+    int64_t pos = 0;
+    std::string id, ref;
+    std::vector<std::string> alt;
+    std::string filter;  // as written in the file ("." / "PASS" / "a;b")
+    int ploidy = 2;
+    std::vector<int32_t> gts;
+};
+
+struct VCF {
+    std::vector<std::string> samples;
+    std::vector<Variant> records;  // file order
+    // open(): reads the whole file (text VCF, plain or gzip/BGZF; CRLF tolerant).  If `keep` is
+    // non-null only records overlapping one of its loci are retained (memory = loci x samples).
+    bool open(const std::string &path, const std::vector<ScoreEntry> *keep = nullptr);
+    int64_t n_samples() const { return (int64_t)samples.size(); }
+};
+
+// nim:353-364: first record overlapping contig:pos-stop with REF == ref and (ea == ref or ea in ALT).
+const Variant *findVariant(const std::string &contig, int64_t pos, const std::string &refseq,
+                           const std::string &easeq, const VCF &vcf);
+
+// nim:50-188 (only used for the AF-mismatch warnings)
+double dbinom(int64_t x, int64_t n, double p);
+double betai(double a, double b, double x);
+double pbinom(int64_t x, int64_t n, double p);
+double binomTest(int64_t x, int64_t n, double p);
+
+// Nim's `$float` as the reference prints it: "%.16g" plus ".0" when no '.', 'e', 'n', 'i' appears.
+std::string formatFloat(double x);
+
+struct Log {
+    std::vector<std::string> lines;  // "WARN ..." / "FATAL ..." in emission order
+    bool echo = true;                // also print to stdout like Nim's ConsoleLogger
+    void warn(const std::string &m);
+    void fatal(const std::string &m);
+};
+
+// nim:592-649.  Same parameters and meaning; `device` selects the GPU.  Throws std::runtime_error
+// when libnps reports an error (there is no CPU fallback).  nloci_out (optional) = rows used.
+void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreFile,
+                            const VCF &genotypeVcf, bool restrictToCoveredRgns,
+                            const GenomeIntervals &coveredIvals, ImputeMethodLocus imputeMethodLocus,
+                            ImputeMethodMissing imputeMethodMissing,
+                            ImputeMethodSample imputeMethodSample, double maxMissingRate,
+                            double afMismatchPthresh, int64_t minGtForInternalImput,
+                            bool ignoreFilterField, Log &log, int device = 0,
+                            uint64_t *nloci_out = nullptr);
+
+// nim:652-757
+int cliMain(int argc, char **argv);
+
+}  // namespace nimpress

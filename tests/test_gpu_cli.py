@@ -1,0 +1,66 @@
+"""End-to-end runs of the `nimpress` command line (C++ host + libnps on the GPU) on the reference's
+own fixtures: the 13 golden cases of tests/test_set1.nim through the real flags, CLI defaults, and
+the warning text."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import refcpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "nimpress_amd", "nimpress")
+
+
+def run_cli(*flags):
+    r = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), os.path.join(G, "set1.vcf.gz")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    warns = [l for l in r.stdout.splitlines() if l.startswith("WARN ")]
+    rows = [l.split("\t") for l in r.stdout.splitlines() if not l.startswith(("WARN ", "FATAL "))]
+    return [x[0] for x in rows], [float(x[1]) for x in rows], [x[1] for x in rows], warns
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_cli_set1_golden(idx):
+    case = json.load(open(os.path.join(G, "set1_cases.json")))["cases"][idx]
+    flags = ["--imp-locus=" + case["imp_locus"], "--imp-missing=" + case["imp_missing"],
+             "--imp-sample=" + case["imp_sample"], "--maxmis=%r" % case["maxmis"],
+             "--mincs=%d" % case["mincs"], "--afmisp=%r" % case["afmisp"]]
+    if case["restrict_to_covered"]:
+        flags.append("--cov=" + os.path.join(G, "set1.bed"))
+    if case["ignore_filter"]:
+        flags.append("--ignorefilt")
+    names, vals, texts, warns = run_cli(*flags)
+    assert names == ["S1", "S2", "S3", "S4", "S5", "S6"]
+    for got, exp in zip(vals, case["expected"]):
+        assert (exp is None) == bool(np.isnan(got))
+        if exp is not None:
+            assert abs(got - exp) <= 1e-4
+    # text format = the oracle's rendering of the oracle's numbers (they agree to the last digit here)
+    score = refcpu.read_score_file(os.path.join(G, "set1.score"))
+    vcf = refcpu.read_vcf(os.path.join(G, "set1.vcf.gz"))
+    bed = refcpu.read_bed(os.path.join(G, "set1.bed"))
+    ref, _, _ = refcpu.compute_polygenic_scores(score, vcf, case["restrict_to_covered"], bed,
+                                                case["imp_locus"], case["imp_missing"],
+                                                case["imp_sample"], case["maxmis"], case["mincs"],
+                                                case["ignore_filter"])
+    for t, r in zip(texts, ref):
+        assert t == refcpu.format_score(r) or abs(float(t) - r) <= 1e-12
+
+
+def test_cli_defaults_and_warnings():
+    names, vals, texts, warns = run_cli()
+    assert np.allclose(vals, 0.1545, atol=1e-12)
+    # every row is locus-imputed under the defaults; the messages are the reference's (nim:554-570)
+    assert any('has a FILTER flag set (value "FAIL")' in w for w in warns)
+    assert any("1:100-100 has 16.66666666666667% of samples missing a genotype" in w or
+               "1:100-100 has 16.666666666666" in w for w in warns)
+    names, vals, texts, warns = run_cli("--cov", os.path.join(G, "set1.bed"), "--maxmis", "1.0",
+                                        "--imp-sample", "ps", "--afmisp", "1.0")
+    assert np.allclose(vals, [0.081, 0.081, 0.081, 0.1545, 0.006, 0.006], atol=1e-4)
+    assert sum("is not covered by the sequence coverage BED" in w for w in warns) == 3
