@@ -701,6 +701,50 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
     return (long)(v - vcf.records.data());
 }
 
+// whole run (needs a GPU): the reference's main() minus printing.  Returns the number of samples,
+// or < 0 on error (nh_last_error).  scores_out has room for cap doubles; warnings (newline separated)
+// go to log_out.
+long nh_compute(const char *score_path, const char *vcf_path, const char *bed_path_or_null,
+                int imp_locus, int imp_missing, int imp_sample, double maxmis, double afmisp,
+                long mincs, int ignorefilt, int device, double *scores_out, long cap,
+                unsigned long long *nloci_out, char *log_out, long log_cap) {
+    try {
+        ScoreFile sf;
+        if (!sf.open(score_path)) {
+            g_nh_error = std::string("Could not open polygenic score file ") + score_path;
+            return -1;
+        }
+        VCF vcf;
+        if (!vcf.open(vcf_path, &sf.entries)) {
+            g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
+            return -1;
+        }
+        GenomeIntervals cov;
+        const bool restrict = bed_path_or_null != nullptr;
+        Log log;
+        log.echo = false;
+        if (restrict && !loadBedIntervals(cov, bed_path_or_null))
+            log.fatal(std::string("Could not open coverage BED file ") + bed_path_or_null);
+        std::vector<double> scores;
+        uint64_t nloci = 0;
+        computePolygenicScores(scores, sf, vcf, restrict, cov, (ImputeMethodLocus)imp_locus,
+                               (ImputeMethodMissing)imp_missing, (ImputeMethodSample)imp_sample, maxmis,
+                               afmisp, mincs, ignorefilt != 0, log, device, &nloci);
+        if (nloci_out) *nloci_out = nloci;
+        for (size_t i = 0; i < scores.size() && (long)i < cap; ++i) scores_out[i] = scores[i];
+        if (log_out && log_cap > 0) {
+            std::string all;
+            for (const std::string &l : log.lines) all += l + "\n";
+            strncpy(log_out, all.c_str(), (size_t)log_cap - 1);
+            log_out[log_cap - 1] = 0;
+        }
+        return (long)scores.size();
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return -2;
+    }
+}
+
 double nh_dbinom(long x, long n, double p) { return dbinom(x, n, p); }
 double nh_pbinom(long x, long n, double p) { return pbinom(x, n, p); }
 double nh_binom_test(long x, long n, double p) { return binomTest(x, n, p); }

@@ -1,0 +1,55 @@
+"""ctypes binding of the C++ host layer (libnimpress_host.so): the reference's
+computePolygenicScores over real files (.scores + VCF/vcf.gz [+ BED]), with the row loop on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import capi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnimpress_host.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise capi.NpsError(-2, "libnimpress_host.so not built (%s)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.nh_last_error.restype = C.c_char_p
+        L.nh_compute.restype = C.c_long
+        L.nh_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_double, C.c_double, C.c_long, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_long, C.POINTER(C.c_ulonglong), C.c_char_p, C.c_long]
+        L.nh_vcf_open.restype = C.c_void_p
+        L.nh_vcf_open.argtypes = [C.c_char_p, C.c_char_p]
+        L.nh_vcf_close.argtypes = [C.c_void_p]
+        L.nh_vcf_n_samples.restype = C.c_long
+        L.nh_vcf_n_samples.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def compute_polygenic_scores(score_path: str, vcf_path: str, cov: Optional[str] = None,
+                             imp_locus: str = "ps", imp_missing: str = "homref",
+                             imp_sample: str = "int_ps", maxmis: float = 0.05, mincs: int = 100,
+                             afmisp: float = 0.001, ignorefilt: bool = False, device: int = 0,
+                             max_samples: int = 1 << 22) -> Tuple[np.ndarray, int, List[str]]:
+    """nimpress's main() minus the printing (CLI defaults).  Returns (scores, nloci, log lines)."""
+    L = load()
+    scores = np.empty(max_samples, dtype=np.float64)
+    nloci = C.c_ulonglong(0)
+    log = C.create_string_buffer(1 << 20)
+    n = L.nh_compute(score_path.encode(), vcf_path.encode(), cov.encode() if cov else None,
+                     capi.LOCUS[imp_locus], capi.MISSING[imp_missing], capi.SAMPLE[imp_sample],
+                     float(maxmis), float(afmisp), int(mincs), int(ignorefilt), device,
+                     scores.ctypes.data, max_samples, C.byref(nloci), log, len(log))
+    if n < 0:
+        raise capi.NpsError(-3 if n == -2 else -1, L.nh_last_error().decode("utf-8", "replace"))
+    return scores[:n].copy(), int(nloci.value), [l for l in log.value.decode().split("\n") if l]

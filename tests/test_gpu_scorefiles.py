@@ -1,0 +1,106 @@
+"""BASELINE.json configs[1] and [3] at test size: the bundled score definitions (wood height, ~700
+loci, and the other 7 score-format files of the reference tree) evaluated on a synthetic cohort
+written as a BGZF-compatible vcf.gz, through the C++ host + libnps, against the oracle's driver.
+Multi-score evaluation uses nimpress_amd.multi (sharding + gather; world size 1 on this box)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nimpress_amd import host, multi
+from oracle import refcpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+SCORES = sorted(os.path.join(G, "scores", f) for f in os.listdir(os.path.join(G, "scores"))) + \
+    [os.path.join(G, "set1.score")]
+BASES = "ACGT"
+
+
+def write_cohort_vcf(path, score_files, n, seed):
+    """Union of the loci of all score files; HWE genotypes at the row's eaf; a few loci dropped,
+    filtered, multi-allelic, phased or partly missing."""
+    rng = np.random.default_rng(seed)
+    loci = {}
+    for sf in score_files:
+        for e in refcpu.read_score_file(sf).entries:
+            loci.setdefault((e.contig, e.pos, e.refseq), []).append(e)
+    samples = ["P%05d" % i for i in range(n)]
+    lines = ["##fileformat=VCFv4.2", '##FILTER=<ID=LowQual,Description="x">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)]
+    def ckey(k):
+        c = k[0]
+        return (0, int(c)) if c.isdigit() else (1, c), k[1]
+    for j, key in enumerate(sorted(loci, key=ckey)):
+        contig, pos, ref = key
+        es = loci[key]
+        if j % 23 == 5:
+            continue                                   # absent from the VCF
+        alts = sorted({e.easeq for e in es if e.easeq != ref})
+        if not alts:
+            alts = [next(b for b in BASES if b != ref[0])]
+        if j % 17 == 3:
+            alts = alts + [next(b for b in BASES if b not in alts and b != ref[0]) + "T"]
+        eaf = es[0].eaf if es[0].easeq != ref and not np.isnan(es[0].eaf) else 0.2
+        eaf = min(max(eaf, 0.01), 0.99)
+        a1 = (rng.uniform(size=n) < eaf).astype(int)
+        a2 = (rng.uniform(size=n) < eaf).astype(int)
+        miss = rng.uniform(size=n) < (0.3 if j % 11 == 0 else 0.01)
+        sep = "|" if j % 5 == 0 else "/"
+        gts = np.where(miss, "./.", np.char.add(np.char.add(a1.astype(str), sep), a2.astype(str)))
+        filt = "LowQual" if j % 29 == 7 else ("." if j % 2 else "PASS")
+        lines.append("%s\t%d\t.\t%s\t%s\t.\t%s\t.\tGT\t%s" % (contig, pos, ref, ",".join(alts), filt,
+                                                              "\t".join(gts.tolist())))
+    with gzip.open(path, "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+@pytest.fixture(scope="module")
+def cohort_vcf(tmp_path_factory):
+    p = str(tmp_path_factory.mktemp("cohort") / "cohort.vcf.gz")
+    write_cohort_vcf(p, SCORES[:-1], 1500, 20250102)
+    return p
+
+
+def oracle_run(score_path, vcf, **kw):
+    score = refcpu.read_score_file(score_path)
+    return refcpu.compute_polygenic_scores(score, vcf, False, {}, kw.get("imp_locus", "ps"),
+                                           kw.get("imp_missing", "homref"),
+                                           kw.get("imp_sample", "int_ps"), kw.get("maxmis", 0.05),
+                                           kw.get("mincs", 100), kw.get("ignorefilt", False))
+
+
+def test_wood_height_on_synthetic_cohort(cohort_vcf):
+    wood = [s for s in SCORES if "wood-25282103" in s][0]
+    vcf = refcpu.read_vcf(cohort_vcf)
+    for kw in (dict(), dict(imp_locus="homref", imp_missing="ignore", imp_sample="ps", maxmis=0.5,
+                            ignorefilt=True)):
+        scores, nloci, log = host.compute_polygenic_scores(wood, cohort_vcf, afmisp=0.0, **kw)
+        ref, ref_nloci, ref_stats = oracle_run(wood, vcf, **kw)
+        assert nloci == ref_nloci and len(scores) == 1500
+        scale = 1e-12 + np.max(np.abs(ref))
+        assert np.max(np.abs(scores - ref)) <= 1e-6 * scale
+        assert sum(1 for s in ref_stats if s[4] == 2) > 10      # absent loci exercised
+        assert sum(1 for s in ref_stats if s[4] == 4) > 10      # over --maxmis exercised
+
+
+def test_eight_scores_sharded_and_gathered(cohort_vcf):
+    """configs[3]: the 8 score-format files of the reference tree, sharded over ranks (one here),
+    gathered into the samples x scores matrix."""
+    vcf = refcpu.read_vcf(cohort_vcf)
+    files = SCORES[:-1] + [SCORES[0]]          # 7 bundled + one repeated = 8 definitions
+    assert len(files) == 8
+
+    def score_fn(i, out_row):
+        s, _, _ = host.compute_polygenic_scores(files[i], cohort_vcf, afmisp=0.0)
+        out_row.copy_(torch.from_numpy(s))
+
+    full = multi.evaluate_sharded(len(files), len(vcf.samples), score_fn, torch.device("cpu"))
+    for i, f in enumerate(files):
+        ref, _, _ = oracle_run(f, vcf)
+        assert np.allclose(full[i].numpy(), ref, rtol=0, atol=1e-9 + 1e-6 * np.max(np.abs(ref)),
+                           equal_nan=True), f
