@@ -3,11 +3,12 @@
 // sample, NaN = missing, effect allele == REF -> dosage = 2 - DS; then tallyAlleles (nim:32-47),
 // the maxmis decision (:565-571), imputation (:417-481) and the accumulation (:639-641) unchanged.
 //
-// 4 bytes per genotype: purely HBM-bound, so the kernels are plain streaming kernels with 16-byte
-// loads.  The accumulation keeps the reference's order (per sample, rows in score-file order, one
-// float64 multiply and one add per row), so for a DS-only score the sums are bit-identical to the
-// reference's; the row tallies use a fixed-shape tree (deterministic, differs from the reference's
-// sequential float64 sum in the last bits only).
+// 4 bytes per genotype: purely HBM-bound, so the kernels are plain streaming kernels.  Per sample the
+// accumulation does the reference's operations (float64 multiply, then add, rows in score-file
+// order inside a row chunk; chunks are combined in fixed order); the row tallies use a fixed-shape
+// tree.  Both are deterministic and differ from the reference's sequential sums in the last bits.
+#include <algorithm>
+
 #include "nps_kernels.h"
 
 namespace nps {
@@ -37,8 +38,7 @@ __global__ __launch_bounds__(256) void ds_tally_kernel(const float *__restrict__
     const uint64_t n4 = (n + 3) / 4;  // rows are zero padded to a multiple of 64 floats
     uint32_t cnt = 0;
     double sum = 0.0;
-    for (uint64_t v = threadIdx.x; v < n4; v += 256) {
-        const float4 q = p[v];
+    auto take = [&](const float4 q, uint64_t v) {
         const float e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -49,7 +49,17 @@ __global__ __launch_bounds__(256) void ds_tally_kernel(const float *__restrict__
                     sum += rie ? 2.0 - (double)e[k] : (double)e[k];
             }
         }
+    };
+    // 8 independent 16-byte loads in flight per thread (the per-thread sum order stays v-ascending)
+    uint64_t v = threadIdx.x;
+    for (; v + 7 * 256 < n4; v += 8 * 256) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = p[v + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) take(q[u], v + u * 256);
     }
+    for (; v < n4; v += 256) take(p[v], v);
     sum = wave_sum_f64(sum);
     cnt = wave_sum_u32(cnt);
     const int w = threadIdx.x >> 6;
@@ -129,40 +139,46 @@ __global__ __launch_bounds__(256) void ds_params_kernel(const DsTally *__restric
     if (threadIdx.x == 0 && cnt) atomicAdd(nloci, (unsigned long long)cnt);
 }
 
-// one thread = 4 consecutive samples, all rows in order: score += dosage * beta   (nim:639-641)
+// one thread = one sample x one chunk of rows, rows in order: score += dosage * beta (nim:639-641).
+// grid.y row chunks add into separate partial-score planes (combined in fixed order by
+// finish_kernel), so that a 200 000-sample cohort still fills the chip.
 __global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restrict__ ds,
                                                             uint64_t stride_f, uint64_t n,
-                                                            const DsRowP *__restrict__ rowp,
-                                                            uint64_t n_rows,
-                                                            double *__restrict__ part0) {
-    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
-    const uint64_t i0 = v * 4;
-    if (i0 >= n) return;
-    double s[4];
+                                                            const DsRowP *__restrict__ rowp_all,
+                                                            uint64_t n_rows_all,
+                                                            uint64_t rows_per_chunk,
+                                                            double *__restrict__ part,
+                                                            uint64_t part_chunk_stride) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r_begin = (uint64_t)blockIdx.y * rows_per_chunk;
+    if (i >= n || r_begin >= n_rows_all) return;
+    const uint64_t n_rows = min(rows_per_chunk, n_rows_all - r_begin);
+    const DsRowP *rowp = rowp_all + r_begin;
+    double *part0 = part + (uint64_t)blockIdx.y * part_chunk_stride;
+    double s = part0[i];
+    const float *p = ds + r_begin * stride_f + i;
+    auto apply = [&](const DsRowP &r, const float e) {
+        if (r.mode == 0) return;
+        double d;
+        if (r.mode == 2)
+            d = r.cst;
+        else if (isnan(e))
+            d = r.imp;
+        else
+            d = r.rie ? 2.0 - (double)e : (double)e;
+        s += d * r.beta;
+    };
+    // 16 rows of loads in flight per thread; the adds stay in row order
+    uint64_t row = 0;
+    for (; row + 16 <= n_rows; row += 16) {
+        float q[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = (i0 + k < n) ? part0[i0 + k] : 0.0;
-    const float4 *p = reinterpret_cast<const float4 *>(ds) + v;
-    const uint64_t stride4 = stride_f / 4;
-    for (uint64_t row = 0; row < n_rows; ++row) {
-        const DsRowP r = rowp[row];  // wave-uniform
-        if (r.mode == 0) continue;
-        const float4 q = p[row * stride4];
-        const float e[4] = {q.x, q.y, q.z, q.w};
+        for (int u = 0; u < 16; ++u) q[u] = p[(row + u) * stride_f];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            double d;
-            if (r.mode == 2)
-                d = r.cst;
-            else if (isnan(e[k]))
-                d = r.imp;
-            else
-                d = r.rie ? 2.0 - (double)e[k] : (double)e[k];
-            s[k] += d * r.beta;
-        }
+        for (int u = 0; u < 16; ++u) apply(rowp[row + u], q[u]);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + k < n) part0[i0 + k] = s[k];
+    for (; row < n_rows; ++row) apply(rowp[row], p[row * stride_f]);
+    part0[i] = s;
 }
 
 // device copy of ref_synth_ds (oracle/refcpu.c)
@@ -217,12 +233,15 @@ hipError_t launch_ds_params(hipStream_t st, const DsTally *d_tally, const nps_ro
 }
 
 hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
-                                const DsRowP *d_rowp, uint64_t n_rows, double *d_part0) {
+                                const DsRowP *d_rowp, uint64_t n_rows, double *d_part,
+                                uint32_t n_chunks, uint64_t part_chunk_stride) {
     if (n_rows == 0 || n == 0) return hipSuccess;
-    const uint64_t n4 = (n + 3) / 4;
+    if (n_chunks == 0 || n_chunks > 65535 || part_chunk_stride < n) return hipErrorInvalidValue;
+    const uint64_t rows_per_chunk = std::max<uint64_t>(16, (n_rows + n_chunks - 1) / n_chunks);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ds_accumulate_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, st,
-                       d_ds, stride_f, n, d_rowp, n_rows, d_part0);
+    hipLaunchKernelGGL(ds_accumulate_kernel, dim3((uint32_t)((n + 255) / 256), n_chunks), dim3(256), 0,
+                       st, d_ds, stride_f, n, d_rowp, n_rows, rows_per_chunk, d_part,
+                       part_chunk_stride);
     return hipGetLastError();
 }
 

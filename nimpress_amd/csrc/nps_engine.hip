@@ -473,7 +473,7 @@ static int run_batch(nps_ctx *c) {
         {
             ProfScope ps(c, P_ACCUM);
             HIP_TRY(launch_ds_accumulate(c->stream, c->d_ds, c->ds_stride_f, c->n, c->d_ds_rowp, drows,
-                                         c->d_part));
+                                         c->d_part, c->n_chunks, c->geom.part_chunk_stride));
         }
         HIP_TRY(hipMemcpyAsync(c->h_ds_stats, c->d_ds_stats, sizeof(nps_locus_stat) * drows,
                                hipMemcpyDeviceToHost, c->stream));
@@ -1010,9 +1010,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         const uint64_t stride_f = co->stride_bytes / 4;
         const float *ds = (const float *)co->d_data + cohort_row0 * stride_f;
-        // blocks of ~96 MB: tally reads HBM, the accumulation right behind it hits the Infinity Cache
+        // launches of >= 2048 rows keep every CU busy in both kernels (one workgroup per row in the
+        // tally; samples x row chunks in the accumulation)
         uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
-        if (block_rows == 0) block_rows = std::max<uint64_t>(16, (96ull << 20) / co->stride_bytes);
+        if (block_rows == 0) block_rows = std::max<uint64_t>(2048, (256ull << 20) / co->stride_bytes);
         for (uint64_t r0 = 0; r0 < m; r0 += block_rows) {
             const uint64_t k = std::min(block_rows, m - r0);
             {
@@ -1029,7 +1030,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             {
                 ProfScope ps(c, P_ACCUM);
                 HIP_TRY(launch_ds_accumulate(c->stream, ds + r0 * stride_f, stride_f, c->n,
-                                             c->d_rds_rowp + r0, k, c->d_part));
+                                             c->d_rds_rowp + r0, k, c->d_part, c->n_chunks,
+                                             c->geom.part_chunk_stride));
             }
         }
         return NPS_OK;
