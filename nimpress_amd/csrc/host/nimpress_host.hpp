@@ -68,6 +68,7 @@ struct Variant {
 struct VCF {
     std::vector<std::string> samples;
     std::vector<Variant> records;  // file order
+    bool indexed = false;          // records were fetched through the tabix index
     // open(): reads the whole file (text VCF, plain or gzip/BGZF; CRLF tolerant).  If `keep` is
     // non-null only records overlapping one of its loci are retained (memory = loci x samples).
     bool open(const std::string &path, const std::vector<ScoreEntry> *keep = nullptr);
@@ -82,7 +83,8 @@ const Variant *findVariant(const std::string &contig, int64_t pos, const std::st
 double dbinom(int64_t x, int64_t n, double p);
 double betai(double a, double b, double x);
 double pbinom(int64_t x, int64_t n, double p);
-double binomTest(int64_t x, int64_t n, double p);
+double binomTest(int64_t x, int64_t n, double p);      // literal enumeration, O(n)
+double binomTestFast(int64_t x, int64_t n, double p);  // same value by bisection, O(log n)
 
 // Nim's `$float` as the reference prints it: "%.16g" plus ".0" when no '.', 'e', 'n', 'i' appears.
 std::string formatFloat(double x);

@@ -35,6 +35,8 @@ def host():
     L.nh_vcf_close.argtypes = [C.c_void_p]
     L.nh_vcf_n_samples.restype = C.c_long
     L.nh_vcf_n_samples.argtypes = [C.c_void_p]
+    L.nh_vcf_indexed.restype = C.c_int
+    L.nh_vcf_indexed.argtypes = [C.c_void_p]
     L.nh_vcf_n_records.restype = C.c_long
     L.nh_vcf_n_records.argtypes = [C.c_void_p]
     L.nh_vcf_sample.restype = C.c_char_p
@@ -43,7 +45,7 @@ def host():
     L.nh_vcf_find.argtypes = [C.c_void_p, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p,
                               C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_char_p, C.c_long,
                               C.c_void_p, C.c_long]
-    for f in ("nh_dbinom", "nh_pbinom", "nh_binom_test"):
+    for f in ("nh_dbinom", "nh_pbinom", "nh_binom_test", "nh_binom_test_fast"):
         getattr(L, f).restype = C.c_double
         getattr(L, f).argtypes = [C.c_long, C.c_long, C.c_double]
     L.nh_betai.restype = C.c_double
@@ -111,6 +113,8 @@ def test_vcf_reader_and_find_variant_match_oracle(host):
         assert h, host.nh_last_error()
         assert [host.nh_vcf_sample(h, i).decode() for i in range(host.nh_vcf_n_samples(h))] == ref_vcf.samples
         assert host.nh_vcf_n_records(h) == (7 if keep is None else 6)   # 1:50 is not a score locus
+        # with the score loci known, the reference's own .tbi (written by htslib's tabix) is used
+        assert host.nh_vcf_indexed(h) == (0 if keep is None else 1)
         for e in score.entries:
             rec = refcpu.find_variant(ref_vcf, e)
             pos, ploidy = C.c_long(), C.c_int()
@@ -194,3 +198,168 @@ def test_cli_surface():
     assert r.returncode == 1
     r = subprocess.run([CLI, "onlyone"], capture_output=True, text=True)
     assert r.returncode == 1 and r.stdout.startswith("Usage:")
+
+
+# ------------------------------------------------------------------------------------------
+# BGZF + tabix writer (test-side) to exercise multi-block random access
+import struct
+import zlib
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + comp + struct.pack("<II", zlib.crc32(data), len(data)))
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def write_bgzf_vcf_with_tbi(path, header_lines, records):
+    """records: list of (contig, pos, ref, line) sorted by contig order of appearance, pos."""
+    out = bytearray()
+    buf = bytearray()
+    voffs = []
+
+    def flush():
+        nonlocal buf
+        if buf:
+            out.extend(_bgzf_block(bytes(buf)))
+            buf = bytearray()
+
+    def add_line(txt):
+        nonlocal buf
+        data = txt.encode() + b"\n"
+        start = (len(out) << 16) | len(buf)
+        i = 0
+        while i < len(data):
+            room = 0xff00 - len(buf)
+            if room == 0:
+                flush()
+                room = 0xff00
+            buf.extend(data[i:i + room])
+            i += room
+        if len(buf) >= 0xff00:
+            flush()
+        end = (len(out) << 16) | len(buf)
+        return start, end
+
+    for h in header_lines:
+        add_line(h)
+    contigs = []
+    index = {}
+    for contig, pos, ref, line in records:
+        vs, ve = add_line(line)
+        if contig not in index:
+            contigs.append(contig)
+            index[contig] = ({}, {})
+        bins, lin = index[contig]
+        beg, end = pos - 1, pos - 1 + len(ref)
+        bins.setdefault(_reg2bin(beg, end), []).append((vs, ve))
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            lin[w] = min(lin.get(w, vs), vs)
+    flush()
+    out.extend(_bgzf_block(b""))
+    open(path, "wb").write(bytes(out))
+    names = b"".join(c.encode() + b"\0" for c in contigs)
+    t = bytearray(b"TBI\1" + struct.pack("<8i", len(contigs), 2, 1, 2, 0, ord("#"), 0, len(names)) + names)
+    for c in contigs:
+        bins, lin = index[c]
+        t += struct.pack("<i", len(bins))
+        for b, chunks in bins.items():
+            merged = [(chunks[0][0], chunks[-1][1])]
+            t += struct.pack("<Ii", b, len(merged))
+            for vs, ve in merged:
+                t += struct.pack("<QQ", vs, ve)
+        nw = max(lin) + 1 if lin else 0
+        t += struct.pack("<i", nw)
+        last = 0
+        for w in range(nw):
+            last = lin.get(w, last)
+            t += struct.pack("<Q", last)
+    tb = bytearray()
+    for i in range(0, len(t), 0xff00):
+        tb += _bgzf_block(bytes(t[i:i + 0xff00]))
+    tb += _bgzf_block(b"")
+    open(path + ".tbi", "wb").write(bytes(tb))
+
+
+def test_tabix_random_access_multi_block(host, tmp_path):
+    rng = np.random.default_rng(12)
+    n = 3000                       # ~12 kB per line, several lines per 64 kB block, lines span blocks
+    samples = ["Q%d" % i for i in range(n)]
+    header = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)]
+    recs = []
+    for contig in ("1", "2", "X"):
+        pos = 1000
+        for _ in range(120):
+            pos += int(rng.integers(1, 60000))
+            ref = "A" if rng.uniform() < 0.8 else "ACG"
+            g = rng.integers(0, 2, size=(n, 2))
+            gts = "\t".join("%d/%d" % (a, b) for a, b in g)
+            recs.append((contig, pos, ref, "%s\t%d\t.\t%s\tG\t.\tPASS\t.\tGT\t%s" % (contig, pos, ref, gts)))
+    vcf_path = str(tmp_path / "big.vcf.gz")
+    write_bgzf_vcf_with_tbi(vcf_path, header, recs)
+    # a score file hitting 40 random records (+ 5 loci that are absent)
+    pick = rng.choice(len(recs), 40, replace=False)
+    lines = ["t", "", "", "x", "0.0"]
+    for k in pick:
+        c, pos, ref, _ = recs[k]
+        lines.append("%s\t%d\t%s\tG\t0.1\t0.2" % (c, pos, ref))
+    for j in range(5):
+        lines.append("2\t%d\tA\tG\t0.1\t0.2" % (7 + j))
+    score_path = str(tmp_path / "s.score")
+    open(score_path, "w").write("\n".join(lines))
+    results = []
+    for no_index in (False, True):
+        if no_index:
+            os.environ["NIMPRESS_NO_INDEX"] = "1"
+        try:
+            h = host.nh_vcf_open(vcf_path.encode(), score_path.encode())
+            assert h, host.nh_last_error()
+            assert host.nh_vcf_indexed(h) == (0 if no_index else 1)
+            assert host.nh_vcf_n_samples(h) == n
+            got = []
+            gts = np.zeros(2 * n, np.int32)
+            for ln in lines[5:]:
+                c, pos, ref, ea, _, _ = ln.split("\t")
+                rp, pl = C.c_long(), C.c_int()
+                idx = host.nh_vcf_find(h, c.encode(), int(pos), ref.encode(), ea.encode(), C.byref(rp),
+                                       C.byref(pl), None, 0, gts.ctypes.data, 2 * n)
+                got.append((idx >= 0, rp.value if idx >= 0 else -1, gts.copy() if idx >= 0 else None))
+            results.append((host.nh_vcf_n_records(h), got))
+            host.nh_vcf_close(h)
+        finally:
+            os.environ.pop("NIMPRESS_NO_INDEX", None)
+    assert results[0][0] == results[1][0] == 40
+    for a, b in zip(results[0][1], results[1][1]):
+        assert a[0] == b[0] and a[1] == b[1]
+        if a[0]:
+            assert np.array_equal(a[2], b[2])
+    assert sum(1 for a in results[0][1] if a[0]) == 40
+
+
+def test_fast_binom_test_equals_enumeration(host):
+    """the O(log n) two-sided binomial test used for the AF-mismatch warnings must give the p-value of
+    the reference's O(n) enumeration (oracle: ref_binom_test), incl. large cohorts and both tails"""
+    rng = np.random.default_rng(2024)
+    cases = [(0, 12, 0.3), (12, 12, 0.3), (0, 2 * 500_000, 0.01), (7, 10, 0.95), (3, 6, 0.5)]
+    for _ in range(1500):
+        n = int(rng.choice([6, 12, 50, 200, 2000, 20000, 200000, 1000000]))
+        p = float(rng.choice([rng.uniform(0.001, 0.999), rng.uniform(0.0005, 0.05), 0.5]))
+        x = int(np.clip(rng.binomial(n, p) + rng.integers(-3, 4) * max(1, int(np.sqrt(n * p * (1 - p)))), 0, n))
+        cases.append((x, n, p))
+    for x, n, p in cases:
+        ref = refcpu.binom_test(x, n, p)
+        got = host.nh_binom_test_fast(x, n, p)
+        if np.isnan(ref):
+            assert np.isnan(got), (x, n, p)
+        else:
+            assert got == ref or abs(got - ref) <= 1e-12 * max(abs(ref), 1e-300), (x, n, p, got, ref)
