@@ -964,8 +964,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     HIP_TRY(hipSetDevice(c->device));
     FusedPlan plan;
     if (mode != NPS_MODE_TWOPASS) {
-        HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0),
-                           (int)env_u64("NPS_FUSED_VARIANT", 0), &plan));
+        HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0), &plan));
         if (const char *e = getenv("NPS_DISABLE_FUSED"))
             if (*e == '1' && mode == NPS_MODE_AUTO) plan.ok = false;
         if (!plan.ok && mode == NPS_MODE_FUSED && c->n && def->m)
@@ -1072,10 +1071,9 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 (void)hipStreamSynchronize(c->stream);
                 (void)hipMemcpy(t, (char *)c->d_timeout + 16, sizeof t, hipMemcpyDeviceToHost);
                 const double wg = (double)plan.P * plan.Q, st = t[4] ? (double)t[4] : 1.0;
-                fprintf(stderr, "[nps] fused P=%u Q=%u T=%u cw=%d: per step per WG: spins %.2f, poll wait "
+                fprintf(stderr, "[nps] fused P=%u Q=%u T=%u: per step per WG: spins %.2f, poll wait "
                         "%.0f cyc, control chain %.0f cyc, barrier wait %.0f cyc (steps/WG %.0f)\n",
-                        plan.P, plan.Q, plan.threads, (int)plan.control_wave, t[0] / st, t[1] / st,
-                        t[2] / st, t[3] / st, st / wg);
+                        plan.P, plan.Q, plan.threads, t[0] / st, t[1] / st, t[2] / st, t[3] / st, st / wg);
             }
             return NPS_OK;
         }

@@ -6,21 +6,26 @@
 // keep its float64 partial score on chip across ALL rows.  A two-kernel design reads the matrix
 // twice.  This kernel reads it once:
 //
-//   * grid = Q teams x P workgroups, all co-resident (cooperative launch, <= 1 per CU).
-//     Workgroup (q,p) owns the sample slice [p*T*16, (p+1)*T*16) -- one 16-sample word column per
-//     thread, 16 float64 accumulators per thread -- and the row batches b = q, q+Q, q+2Q, ...
+//   * grid = Q teams x P workgroups, all co-resident (cooperative launch, one workgroup per CU).
+//     Workgroup (q,p) owns the sample slice [p*960*16, (p+1)*960*16) -- one 16-sample word column
+//     and 16 float64 accumulators per data thread -- and the row batches b = q, q+Q, q+2Q, ...
 //     (16 rows = 4 groups per batch).
-//   * per batch: 16 coalesced dword loads per thread into a 3-deep REGISTER ring; partial tallies
-//     by popcount + DPP reduce-scatter + LDS add; one 64-bit agent-scope atomic add per row
-//     publishes (arrivals<<56 | nmiss<<28 | neffect); the batch is consumed one ring step later:
-//     one wave polls the 16 tally words until all P slices have arrived, 16 lanes derive the rows'
-//     LUTs, the workgroup builds four 256-entry float64 tables in LDS, and every thread does one
-//     ds_read_b64 + one v_add_f64 per FOUR genotypes straight from its ring registers.
-//   * inter-workgroup traffic is 8-byte agent-scope atomics on both sides (an `sc1` form measured
-//     valid on gfx950, MI355X_MICROARCH.md "Valid forms"); every spin is bounded and sets a
-//     timeout word instead of hanging.
+//   * data waves (15 of 16), per batch: 16 coalesced row loads through per-row buffer descriptors
+//     into a 4-deep REGISTER ring; partial tallies of the batch three ahead (popcount + DPP
+//     reduce-scatter + LDS add) interleaved with the accumulation of the current batch: one
+//     ds_read_b64 + one v_add_f64 per FOUR genotypes from 256-entry float64 tables in LDS.
+//   * control wave (wave 0, carries no samples), concurrently: publishes the workgroup's partial
+//     tallies with one 64-bit agent-scope atomic per row (arrivals<<56 | nmiss<<28 | neffect), polls
+//     the tally words of the batch published one phase earlier until all P slices have arrived,
+//     derives the 16 row LUTs and writes the next batch's four tables into the other LDS buffer.
+//   * one workgroup barrier per batch.  Inter-workgroup traffic is 8-byte agent-scope atomics on
+//     both sides (an `sc1` form measured valid on gfx950, MI355X_MICROARCH.md "Valid forms"); every
+//     spin is bounded and sets a timeout word instead of hanging.
 //
 // HBM traffic = the matrix once (+ 8 B of atomics per row per slice, + row descriptors).
+// The kernel sits at the knee of three limits (PMC: VALU busy 74 %, LDS busy 68 %, HBM 4.96 TB/s in
+// a tally-only build), and at the register limit of 4 waves/SIMD: keep `ScratchSize` at 0 -- a
+// 32-byte spill costs 28 % (diagnostics are therefore template parameters, not run-time flags).
 #include <algorithm>
 #include <cstdlib>
 
@@ -113,17 +118,6 @@ static __device__ __forceinline__ void transpose_fold_4x16(uint32_t w0, uint32_t
     x[3] = bfi(m4, lo >> 4, ho);   // samples 3,7,11,15
 }
 
-// LDS layout (bytes)
-//   [0, 8192)        float64 tables, 4 groups x 256 entries (table_index order)
-//   [8192, 8704)     row LUTs of the batch being consumed, 16 rows x 4 float64
-//   [8704, 8832)     partial tallies, 2 parities x 16 rows x uint32
-struct __attribute__((aligned(16))) FusedLds {
-    double table[4][256];
-    double lut[kRowsPerBatch][4];
-    uint32_t tally[2][kRowsPerBatch];
-    uint32_t pad[4];
-};
-
 // Row LUT from a complete tally word: the maxmis decision (nimpress.nim:565-571), the locus constant
 // (:417-447) or the sample imputation value (:450-481).  One lane per row.
 static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long long x, uint64_t row,
@@ -176,254 +170,8 @@ static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long
     }
 }
 
-// Per workgroup and batch k (16 rows), two barriers:
-//   S1  issue the 16 row loads of batch k+2 (register ring) ; wave 0 issues the poll of batch k
-//   S2  partial tallies of batch k+1 (popcounts, DPP reduce-scatter, LDS adds)
-//       wave 0: poll result of batch k (its latency hid under S2) -> 16 row LUTs -> LDS
-//   --- barrier X
-//   S4  16 lanes publish batch k+1 (one 64-bit agent-scope atomic per row);
-//       every thread builds its share of the four 256-entry tables of batch k
-//   --- barrier Y
-//   S6  accumulate batch k from the ring registers: ds_read_b64 + v_add_f64 per 4 genotypes
-template <int T>
-__global__ __launch_bounds__(T, (T >= 1024 ? 4 : T >= 768 ? 3 : 4)) void fused_kernel(const FusedArgs a) {
-    static_assert(T % 64 == 0 && T >= 64 && T <= 1024, "workgroup size");
-    __shared__ FusedLds lds;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint32_t team = blockIdx.y;   // grid = (P slices, Q teams)
-    const uint32_t slice = blockIdx.x;
-    const uint32_t col = slice * T + tid;
-    const bool active = col < a.n_words;
-    const uint32_t voff = col * 4u;     // byte offset inside a row; rows are < 4 GB
-    const uint32_t row_bytes = a.n_words * 4u;
-    const uint64_t stride_bytes = a.stride_words * 4u;
-    // local batch k of this team is global batch team + k*Q
-    const uint32_t n_local = a.n_batches > team ? (a.n_batches - team + a.Q - 1) / a.Q : 0;
-
-    if (tid < 2 * kRowsPerBatch) (&lds.tally[0][0])[tid] = 0;
-    __syncthreads();
-
-    double acc[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = 0.0;
-    uint32_t ring[3][kRowsPerBatch];
-    uint32_t nloci_local = 0;  // meaningful in wave 0 of slice 0
-    bool timed_out = false;    // wave 0 only: stop waiting once any bounded wait has expired
-    unsigned long long polled = 0;  // wave 0, lanes 0..15: tally word of "my" row of batch k
-
-    // first row of local batch k (batches past the end get a row index >= n_rows)
-    auto batch_row0 = [&](uint32_t k) -> uint64_t {
-        return (uint64_t)(team + (uint64_t)k * a.Q) * kRowsPerBatch;
-    };
-
-    // One buffer descriptor per row (wave-uniform, in SGPRs): the hardware range check returns 0
-    // for columns past the end of a row and for rows past the end of the matrix, so the loads need
-    // no per-lane predication and no 64-bit per-lane addresses.
-    auto load_batch = [&](uint32_t k, uint32_t(&dst)[kRowsPerBatch]) {
-        const uint64_t row0 = batch_row0(k);
-        const bool in = k < n_local && row0 < a.n_rows;
-        const uint32_t nvalid = in ? (uint32_t)min((uint64_t)kRowsPerBatch, a.n_rows - row0) : 0u;
-        const char *p = reinterpret_cast<const char *>(a.codes) + (in ? row0 : 0) * stride_bytes;
-#pragma unroll
-        for (int r = 0; r < kRowsPerBatch; ++r) {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(p), 0, (uint32_t)r < nvalid ? row_bytes : 0u, 0x00020000);
-            dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0);
-            p += stride_bytes;
-        }
-    };
-
-    // S2: partial tally of this workgroup's slice (batches past the end hold zeros)
-    auto tally_local = [&](uint32_t k, const uint32_t(&src)[kRowsPerBatch]) {
-        const int par = k & 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t a0 = tally_pack(src[4 * g + 0]), a1 = tally_pack(src[4 * g + 1]);
-            const uint32_t a2 = tally_pack(src[4 * g + 2]), a3 = tally_pack(src[4 * g + 3]);
-            // reduce-scatter over lane^1: even lanes keep rows 0,1 ; odd lanes rows 2,3
-            const bool odd = lane & 1;
-            const uint32_t x0 = odd ? a2 : a0, y0 = odd ? a0 : a2;
-            const uint32_t x1 = odd ? a3 : a1, y1 = odd ? a1 : a3;
-            const uint32_t b0 = x0 + dpp<kQuadSwap1>(y0);
-            const uint32_t b1 = x1 + dpp<kQuadSwap1>(y1);
-            // lane^2: (lane&2)==0 keeps b0, else b1
-            const bool hi = lane & 2;
-            const uint32_t x = hi ? b1 : b0, y = hi ? b0 : b1;
-            uint32_t c = x + dpp<kQuadSwap2>(y);
-            // sum over lanes congruent mod 4 within each 16-lane DPP row
-            c += dpp<kRowShr4>(c);
-            c += dpp<kRowShr8>(c);
-            // lanes 12..15 of each DPP row hold the row totals; lane&3 -> row: 0,2,1,3
-            if ((lane & 12) == 12) {
-                const int r = ((lane & 1) << 1) | ((lane >> 1) & 1);
-                atomicAdd(&lds.tally[par][4 * g + r], c);
-            }
-        }
-    };
-
-    // S4 (after barrier X): lanes 0..15 publish the workgroup's partial tallies of batch k
-    auto publish = [&](uint32_t k) {
-        if (tid < kRowsPerBatch) {
-            const int par = k & 1;
-            const uint32_t v = lds.tally[par][tid];
-            lds.tally[par][tid] = 0;  // next used two batches later, several barriers away
-            const uint64_t row = batch_row0(k) + tid;
-            if (k < n_local && row < a.n_rows) {
-                const uint64_t t = v >> 16, m = v & 0xFFFFu;
-                const uint64_t neff = t - m;
-                const unsigned long long add = (1ull << 56) | (m << 28) | neff;
-                __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-
-    // S1 (wave 0): start reading the tally words of batch k; the result is looked at after S2
-    auto poll_issue = [&](uint32_t k) {
-        if (tid < kRowsPerBatch) {
-            const uint64_t row = batch_row0(k) + tid;
-            polled = (k < n_local && row < a.n_rows)
-                         ? __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0ull;
-        }
-    };
-
-    // end of S2 (wave 0): wait until all P slices of every row of batch k have arrived, then derive
-    // the 16 row LUTs.  A bounded wait that expires sets the timeout word (the host reports
-    // NPS_E_TIMEOUT and discards the scores); later waits in every workgroup then fall through at
-    // once, so the grid always drains.
-    auto poll_finish_lut = [&](uint32_t k) {
-        if (tid < 64) {
-            const uint64_t row = batch_row0(k) + lane;
-            const bool valid = lane < kRowsPerBatch && k < n_local && row < a.n_rows;
-            bool ok = !valid || (uint32_t)(polled >> 56) == a.P;
-            uint32_t spins = 0;
-            while (!__all(ok) && !timed_out) {
-                __builtin_amdgcn_s_sleep(2);
-                if (!ok) {
-                    polled = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (uint32_t)(polled >> 56) == a.P;
-                }
-                if ((++spins & 255u) == 0) {
-                    const unsigned int t =
-                        __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t != 0 || spins >= kSpinLimit) {
-                        if (lane == 0)
-                            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        timed_out = true;
-                    }
-                }
-            }
-            int used = 0;
-            if (lane < kRowsPerBatch) {
-                double v[4] = {0.0, 0.0, 0.0, 0.0};
-                if (valid && ok)
-                    row_lut(a, polled, row, a.desc[row].beta, a.desc[row].eaf,
-                            a.desc[row].ref_is_effect != 0, slice == 0 && a.stats != nullptr, v, used);
-                *reinterpret_cast<double2 *>(&lds.lut[lane][0]) = make_double2(v[0], v[1]);
-                *reinterpret_cast<double2 *>(&lds.lut[lane][2]) = make_double2(v[2], v[3]);
-            }
-            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
-        }
-    };
-
-    // S4: tables of the batch whose LUTs are in LDS (entry order: table_index)
-    auto build_tables = [&]() {
-#pragma unroll
-        for (int i = tid; i < 4 * 256; i += T) {
-            const int g = i >> 8, e = i & 255;
-            const int c0 = e & 3, c1 = (e >> 2) & 3, c2 = (e >> 4) & 3, c3 = e >> 6;
-            const double v = ((lds.lut[4 * g][c0] + lds.lut[4 * g + 1][c1]) + lds.lut[4 * g + 2][c2]) +
-                             lds.lut[4 * g + 3][c3];
-            lds.table[g][table_index(c0, c1, c2, c3)] = v;
-        }
-    };
-
-    // S6+S2 merged: accumulate batch k (LDS-bound: table lookups) and tally batch k+2 (VALU-bound:
-    // popcounts + DPP) in ONE instruction stream, a row of tally work behind every four lookups, so
-    // that all 16 waves of the CU issue a uniform LDS/VALU mix instead of queueing on the LDS in one
-    // phase and on the VALU in the next.
-    auto accumulate_and_tally = [&](const uint32_t(&cur)[kRowsPerBatch], uint32_t k_tal,
-                                    const uint32_t(&tal)[kRowsPerBatch]) {
-        const int par = k_tal & 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint32_t x[4];
-            transpose_fold_4x16(cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], x);
-            const double *Tg = lds.table[g];
-            uint32_t tp[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = Tg[(x[q] >> (8 * kk)) & 0xFFu];
-                tp[kk] = tally_pack(tal[4 * g + kk]);  // VALU work while the lookups are in flight
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[4 * kk + q]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const bool odd = lane & 1;
-            const uint32_t x0 = odd ? tp[2] : tp[0], y0 = odd ? tp[0] : tp[2];
-            const uint32_t x1 = odd ? tp[3] : tp[1], y1 = odd ? tp[1] : tp[3];
-            const uint32_t b0 = x0 + dpp<kQuadSwap1>(y0);
-            const uint32_t b1 = x1 + dpp<kQuadSwap1>(y1);
-            const bool hi = lane & 2;
-            const uint32_t xx = hi ? b1 : b0, yy = hi ? b0 : b1;
-            uint32_t c = xx + dpp<kQuadSwap2>(yy);
-            c += dpp<kRowShr4>(c);
-            c += dpp<kRowShr8>(c);
-            if ((lane & 12) == 12) {
-                const int r = ((lane & 1) << 1) | ((lane >> 1) & 1);
-                atomicAdd(&lds.tally[par][4 * g + r], c);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // One pipeline step: consume batch k (ring slot r_cur) while tallying batch k+2 (slot r_tal),
-    // then refill slot r_cur with batch k+3.
-    auto step = [&](uint32_t k, uint32_t(&r_cur)[kRowsPerBatch], const uint32_t(&r_tal)[kRowsPerBatch]) {
-        __syncthreads();     // X: LUTs of batch k and the LDS tally sums of batch k+1 are complete
-        publish(k + 1);
-        build_tables();
-        __syncthreads();     // Y: tables of batch k ready
-        poll_issue(k + 1);   // wave 0: its latency hides under the work below
-        accumulate_and_tally(r_cur, k + 2, r_tal);
-        load_batch(k + 3, r_cur);
-        poll_finish_lut(k + 1);
-    };
-
-    // prologue: batches 0..2 loading, batch 0 tallied + published, batch 1 tallied, LUTs of batch 0
-    load_batch(0, ring[0]);
-    load_batch(1, ring[1]);
-    load_batch(2, ring[2]);
-    tally_local(0, ring[0]);
-    __syncthreads();
-    publish(0);
-    poll_issue(0);
-    tally_local(1, ring[1]);
-    poll_finish_lut(0);
-    // batches past the end (k >= n_local, only in the last ring turn) run through unchanged: their
-    // loads return zeros, nothing is published or waited for, LUTs are zero: +0.0 to every score
-    for (uint32_t k = 0; k < n_local; k += 3) {
-        step(k, ring[0], ring[2]);
-        step(k + 1, ring[1], ring[0]);
-        step(k + 2, ring[2], ring[1]);
-    }
-
-    if (active) {
-        double *dst = a.part + (uint64_t)team * a.part_team_stride + (uint64_t)col * 16;
-#pragma unroll
-        for (int s = 0; s < 16; s += 2)
-            *reinterpret_cast<double2 *>(dst + s) = make_double2(acc[s], acc[s + 1]);
-    }
-    if (slice == 0 && tid == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Control-wave variant.  Same data path, but wave 0 of every workgroup carries no samples: it does
+// The kernel.  Wave 0 of every workgroup (the control wave) carries no samples: it does
 // everything that is serial per batch -- publishing the workgroup's partial tallies, waiting for the
 // other slices, the 16 row LUTs (two float64 divisions each) and the four 256-entry tables -- while
 // the other T/64-1 waves accumulate the previous batch.  One barrier per batch, tables double
@@ -434,7 +182,7 @@ struct __attribute__((aligned(16))) FusedCwLds {
     uint32_t tally[2][kRowsPerBatch];
 };
 
-template <int T>
+template <int T, int DBG>  // DBG: diagnostics build (bit 0 re-read rows 0..15, bit 1 skip accumulation)
 __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     static_assert(T % 64 == 0 && T >= 128 && T <= 1024, "workgroup size");
     constexpr int TD = T - 64;  // data threads
@@ -588,7 +336,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         const bool in = k < n_local && row0 < a.n_rows;
         const uint32_t nvalid = in ? (uint32_t)min((uint64_t)kRowsPerBatch, a.n_rows - row0) : 0u;
         const char *p = reinterpret_cast<const char *>(a.codes) +
-                        (in && !(a.dbg_same_rows & 1) ? row0 : 0) * stride_bytes;
+                        (in && !(DBG & 1) ? row0 : 0) * stride_bytes;
 #pragma unroll
         for (int r = 0; r < kRowsPerBatch; ++r) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -672,7 +420,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     };
 
     auto step = [&](uint32_t k, uint32_t(&r_cur)[kRowsPerBatch], const uint32_t(&r_tal)[kRowsPerBatch]) {
-        if (a.dbg_same_rows & 2)  // diagnostics only: tally without the accumulation
+        if (DBG & 2)  // diagnostics only: tally without the accumulation
             tally_local(k + 3, r_tal);
         else
             accumulate_and_tally(k, r_cur, r_tal);
@@ -717,18 +465,15 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ pa
 
 // ---- host side ------------------------------------------------------------------------------
 template <int T>
-static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, bool control_wave,
-                           FusedPlan *plan) {
+static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedPlan *plan) {
     int per_cu = 0;
-    hipError_t e = control_wave
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T>, T, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_kernel<T>, T, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T, 0>, T, 0);
     if (e != hipSuccess) return e;
     // the kernel needs 128 VGPRs: 16 waves per CU; never ask for more than that many workgroups
     per_cu = std::min(per_cu, T == 768 ? 1 : 1024 / T);
     if (per_cu < 1) return hipSuccess;
     const uint64_t capacity = (uint64_t)cus * per_cu;
-    const uint64_t cols = control_wave ? T - 64 : T;  // word columns per workgroup
+    const uint64_t cols = T - 64;  // word columns per workgroup (wave 0 is the control wave)
     const uint64_t P = (n_words + cols - 1) / cols;
     if (P > capacity || P > 255) return hipSuccess;  // 8-bit arrival count in the tally word
     uint64_t Q = std::min<uint64_t>(capacity / P, n_batches);
@@ -738,14 +483,12 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, bool c
     plan->Q = (uint32_t)Q;
     plan->n_batches = (uint32_t)n_batches;
     plan->part_team_stride = P * cols * 16;
-    plan->control_wave = control_wave;
     plan->ok = true;
     return hipSuccess;
 }
 
 hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads,
-                      int variant, FusedPlan *plan) {
-    const bool cw = variant != 1;  // 0 = default (control wave), 1 = all-data-waves kernel
+                      FusedPlan *plan) {
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;
     hipDeviceProp_t prop;
@@ -762,10 +505,10 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
     const int *order = want_threads ? order_want : order_default;
     for (int i = 0; i < 3 && !plan->ok; ++i) {
         switch (order[i]) {
-        case 256: e = plan_for<256>(cus, n_words, n_batches, cw, plan); break;
-        case 512: e = plan_for<512>(cus, n_words, n_batches, cw, plan); break;
-        case 768: e = plan_for<768>(cus, n_words, n_batches, cw, plan); break;
-        case 1024: e = plan_for<1024>(cus, n_words, n_batches, cw, plan); break;
+        case 256: e = plan_for<256>(cus, n_words, n_batches, plan); break;
+        case 512: e = plan_for<512>(cus, n_words, n_batches, plan); break;
+        case 768: e = plan_for<768>(cus, n_words, n_batches, plan); break;
+        case 1024: e = plan_for<1024>(cus, n_words, n_batches, plan); break;
         default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
@@ -799,16 +542,16 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
     a.dbg_same_rows = getenv("NPS_DEBUG_FLAGS") ? atoi(getenv("NPS_DEBUG_FLAGS")) : 0;
     void *args[] = {&a};
     const void *fn;
-    if (plan.control_wave)
-        fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256>
-             : plan.threads == 512 ? (const void *)fused_cw_kernel<512>
-             : plan.threads == 768 ? (const void *)fused_cw_kernel<768>
-                                   : (const void *)fused_cw_kernel<1024>;
+    const int dbg = a.dbg_same_rows & 3;
+    if (dbg && plan.threads == 1024)  // diagnostics builds exist for T = 1024 only
+        fn = dbg == 1   ? (const void *)fused_cw_kernel<1024, 1>
+             : dbg == 2 ? (const void *)fused_cw_kernel<1024, 2>
+                        : (const void *)fused_cw_kernel<1024, 3>;
     else
-        fn = plan.threads == 256   ? (const void *)fused_kernel<256>
-             : plan.threads == 512 ? (const void *)fused_kernel<512>
-             : plan.threads == 768 ? (const void *)fused_kernel<768>
-                                   : (const void *)fused_kernel<1024>;
+        fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256, 0>
+             : plan.threads == 512 ? (const void *)fused_cw_kernel<512, 0>
+             : plan.threads == 768 ? (const void *)fused_cw_kernel<768, 0>
+                                   : (const void *)fused_cw_kernel<1024, 0>;
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
 }

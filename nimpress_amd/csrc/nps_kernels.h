@@ -69,11 +69,10 @@ struct FusedPlan {
     uint32_t P = 0, Q = 0; // slices per team, teams
     uint32_t n_batches = 0;
     uint64_t part_team_stride = 0;  // doubles per team in the partial-score buffer
-    bool control_wave = false;      // kernel variant (nps_fused.hip)
 };
 // want_threads: 0 = default, else 256 / 512 / 1024
 hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads,
-                      int variant, FusedPlan *plan);
+                      FusedPlan *plan);
 // d_tally: [plan.n_batches*16] zeroed; d_part: [Q*part_team_stride]; d_timeout: zeroed word
 hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d_codes,
                         uint64_t stride_words, uint64_t n_samples, uint64_t n_rows,
