@@ -54,7 +54,7 @@ struct nps_cohort {
     int device = 0;
     int format = NPS_FMT_GT2;
     uint64_t n_samples = 0, n_rows = 0;
-    uint64_t stride_bytes = 0;  // per row
+    uint64_t stride_bytes = 0;  // per row (GT2: rows are interleaved in groups of 4, a group is 4*stride_bytes)
     void *d_data = nullptr;
 };
 
@@ -74,7 +74,8 @@ struct nps_ctx {
 
     // streaming batch
     uint32_t batch_cap = 0, batch_rows = 0;
-    uint32_t *d_codes = nullptr;            // [batch_cap][stride_words]
+    uint32_t *d_codes = nullptr;            // [batch_cap/4 groups][stride_words][4] (interleaved)
+    uint32_t *d_rowtmp = nullptr;           // one contiguous packed row (nps_push_packed staging)
     unsigned long long *d_tally = nullptr;  // [batch_cap]
     nps_row_desc *d_desc = nullptr;         // [batch_cap]
     nps_row_desc *h_desc = nullptr;         // pinned [batch_cap]
@@ -243,6 +244,7 @@ static void free_ctx(nps_ctx *c) {
         (void)hipEventDestroy(s.b);
     }
     (void)hipFree(c->d_codes);
+    (void)hipFree(c->d_rowtmp);
     (void)hipFree(c->d_tally);
     (void)hipFree(c->d_desc);
     (void)hipHostFree(c->h_arena);
@@ -333,6 +335,7 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CTX_TRY(hipMalloc(&c->d_codes, row_bytes * c->batch_cap));
     CTX_TRY(hipMemsetAsync(c->d_codes, 0, row_bytes * c->batch_cap, c->stream));
+    CTX_TRY(hipMalloc(&c->d_rowtmp, row_bytes));
     CTX_TRY(hipMalloc(&c->d_tally, sizeof(unsigned long long) * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_desc, sizeof(nps_row_desc) * c->batch_cap));
     {
@@ -536,7 +539,8 @@ extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
         ProfScope ps(c, P_DECODE);
         HIP_TRY(launch_decode_gt(c->stream, c->d_raw, c->n, ploidy, eaidx,
-                                 c->d_codes + (uint64_t)slot * c->stride_words, c->d_tally + slot));
+                                 c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4, slot & 3,
+                                 c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;
@@ -551,16 +555,17 @@ extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effec
     int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
     if (rc) return rc;
     if (c->n) {
-        uint32_t *dst = c->d_codes + (uint64_t)slot * c->stride_words;
         const int k = c->raw_next;
         c->raw_next = (k + 1) % nps_ctx::kRawSlots;
         HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
         memcpy(c->h_raw[k], row, sizeof(uint32_t) * c->n_words);
-        HIP_TRY(hipMemcpyAsync(dst, c->h_raw[k], sizeof(uint32_t) * c->n_words,
+        HIP_TRY(hipMemcpyAsync(c->d_rowtmp, c->h_raw[k], sizeof(uint32_t) * c->n_words,
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
         ProfScope ps(c, P_TALLY);
-        HIP_TRY(launch_tally_packed(c->stream, dst, c->stride_words, c->n, 1, c->d_tally + slot));
+        HIP_TRY(launch_tally_scatter_row(c->stream, c->d_rowtmp, c->n,
+                                         c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
+                                         slot & 3, c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;
@@ -741,7 +746,8 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     c->n_rows = n_rows;
     c->stride_bytes = format == NPS_FMT_DS32 ? ds_stride_floats(n_samples) * 4
                                               : stride_words_for(n_samples) * 4;
-    const uint64_t bytes = std::max<uint64_t>(c->stride_bytes * n_rows, 256);
+    const uint64_t rows_alloc = format == NPS_FMT_GT2 ? (n_rows + 3) / 4 * 4 : n_rows;
+    const uint64_t bytes = std::max<uint64_t>(c->stride_bytes * rows_alloc, 256);
     hipError_t e = hipMalloc(&c->d_data, bytes);
     if (e != hipSuccess) {
         delete c;
@@ -778,6 +784,35 @@ static int check_range(const nps_cohort *c, uint64_t row0, uint64_t nrows) {
     return NPS_OK;
 }
 
+// GT2 rows <-> the group-interleaved device layout, through a host buffer of whole groups
+static int gt2_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void *host_rows,
+                        size_t host_stride, bool to_device) {
+    const uint64_t n_words = words_for(c->n_samples), sw = c->stride_bytes / 4;
+    if (row0 & 3) return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
+    const uint64_t chunk_groups = std::max<uint64_t>(1, (64ull << 20) / (sw * 16));
+    std::vector<uint32_t> buf;
+    for (uint64_t r = 0; r < nrows; r += chunk_groups * 4) {
+        const uint64_t k = std::min<uint64_t>(chunk_groups * 4, nrows - r);  // rows in this chunk
+        const uint64_t groups = (k + 3) / 4;
+        char *dev = (char *)c->d_data + ((row0 + r) >> 2) * sw * 16;
+        buf.assign(groups * sw * 4, 0u);
+        if (!to_device)
+            HIP_TRY(hipMemcpy(buf.data(), dev, groups * sw * 16, hipMemcpyDeviceToHost));
+        for (uint64_t j = 0; j < k; ++j) {
+            uint32_t *hrow = (uint32_t *)((char *)host_rows + (r + j) * host_stride);
+            uint32_t *g = buf.data() + (j >> 2) * sw * 4 + (j & 3);
+            if (to_device)
+                for (uint64_t w = 0; w < n_words; ++w) g[w * 4] = hrow[w];
+            else
+                for (uint64_t w = 0; w < n_words; ++w) hrow[w] = g[w * 4];
+        }
+        // rows of a last partial group that are not part of this upload become zero
+        if (to_device)
+            HIP_TRY(hipMemcpy(dev, buf.data(), groups * sw * 16, hipMemcpyHostToDevice));
+    }
+    return NPS_OK;
+}
+
 extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
@@ -786,6 +821,8 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->format == NPS_FMT_GT2)
+        return gt2_transfer(c, row0, nrows, const_cast<void *>(host_rows), host_stride, true);
     HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
                         host_stride, width, nrows, hipMemcpyHostToDevice));
     return NPS_OK;
@@ -799,6 +836,7 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->format == NPS_FMT_GT2) return gt2_transfer(c, row0, nrows, host_rows, host_stride, false);
     HIP_TRY(hipMemcpy2D(host_rows, host_stride, (const char *)c->d_data + row0 * c->stride_bytes,
                         c->stride_bytes, width, nrows, hipMemcpyDeviceToHost));
     return NPS_OK;
@@ -811,6 +849,8 @@ extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, ui
     if (rc) return rc;
     if (nrows == 0) return NPS_OK;
     if (!t_het || !t_hom || !t_miss) return fail(NPS_E_INVAL, "threshold arrays are NULL");
+    if (c->format == NPS_FMT_GT2 && (row0 & 3))
+        return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t *d_t = nullptr;
     HIP_TRY(hipMalloc(&d_t, sizeof(uint32_t) * 3 * nrows));
@@ -1035,8 +1075,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         return NPS_OK;
     }
+    if (cohort_row0 & 3)
+        return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     const uint64_t stride_words = co->stride_bytes / 4;
-    const uint32_t *codes = (const uint32_t *)co->d_data + cohort_row0 * stride_words;
+    const uint32_t *codes = (const uint32_t *)co->d_data + (cohort_row0 >> 2) * stride_words * 4;
     if (plan.ok && c->n) {
         // fused single-read path
         const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
@@ -1092,8 +1134,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         const uint64_t k_pad = (k + 3) / 4 * 4;  // only the last block can be ragged
         {
             ProfScope ps(c, P_TALLY);
-            HIP_TRY(launch_tally_packed(c->stream, codes + r0 * stride_words, stride_words, c->n, k,
-                                        c->d_rtally + r0));
+            HIP_TRY(launch_tally_packed(c->stream, codes + (r0 >> 2) * stride_words * 4, stride_words,
+                                        c->n, k, c->d_rtally + r0));
         }
         {
             ProfScope ps(c, P_PARAMS);
@@ -1106,7 +1148,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             const uint32_t groups = (uint32_t)(k_pad / 4);
             g.groups_per_chunk = std::max(1u, (groups + g.n_chunks - 1) / g.n_chunks);
             ProfScope ps(c, P_ACCUM);
-            HIP_TRY(launch_accumulate(c->stream, codes + r0 * stride_words, stride_words, k,
+            HIP_TRY(launch_accumulate(c->stream, codes + (r0 >> 2) * stride_words * 4, stride_words, k,
                                       c->d_rlut + r0 * 4, g, c->d_part));
         }
     }

@@ -322,27 +322,36 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     const int dt = tid - 64;
     const uint32_t col = slice * TD + dt;
     const bool active = col < a.n_words;
-    const uint32_t voff = col * 4u;
+    const uint32_t voff = col * 16u;            // byte offset of the thread's column inside a group
     const uint32_t row_bytes = a.n_words * 4u;
-    const uint64_t stride_bytes = a.stride_words * 4u;
+    const uint64_t group_bytes = a.stride_words * 16u;
 
     double acc[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.0;
     uint32_t ring[kRing][kRowsPerBatch];
 
+    // One buffer descriptor per row GROUP (wave-uniform, in SGPRs) and one 16-byte load per thread
+    // and group: the thread's word column of the group's four rows.  The hardware range check
+    // returns 0 for columns past the end of a row and for groups past the end of the matrix, so the
+    // loads need no per-lane predication and no 64-bit per-lane addresses.
     auto load_batch = [&](uint32_t k, uint32_t(&dst)[kRowsPerBatch]) {
         const uint64_t row0 = batch_row0(k);
         const bool in = k < n_local && row0 < a.n_rows;
-        const uint32_t nvalid = in ? (uint32_t)min((uint64_t)kRowsPerBatch, a.n_rows - row0) : 0u;
+        // groups of this batch that hold at least one row of the matrix
+        const uint32_t ngroups = in ? (uint32_t)((min((uint64_t)kRowsPerBatch, a.n_rows - row0) + 3) / 4) : 0u;
         const char *p = reinterpret_cast<const char *>(a.codes) +
-                        (in && !(DBG & 1) ? row0 : 0) * stride_bytes;
+                        (in && !(DBG & 1) ? (row0 >> 2) : 0) * group_bytes;
 #pragma unroll
-        for (int r = 0; r < kRowsPerBatch; ++r) {
+        for (int g = 0; g < 4; ++g) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(p), 0, (uint32_t)r < nvalid ? row_bytes : 0u, 0x00020000);
-            dst[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0);
-            p += stride_bytes;
+                const_cast<char *>(p), 0, (uint32_t)g < ngroups ? row_bytes * 4u : 0u, 0x00020000);
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            dst[4 * g + 0] = q[0];
+            dst[4 * g + 1] = q[1];
+            dst[4 * g + 2] = q[2];
+            dst[4 * g + 3] = q[3];
+            p += group_bytes;
         }
     };
 
@@ -375,41 +384,29 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         }
     };
 
-    // accumulate batch k (tables[k&1]) and tally batch k+3 in one instruction stream.  The table
-    // lookups are software-pipelined one chunk (4 lookups) ahead: while chunk c's values are awaited,
-    // chunk c+1 is already queued on the LDS and the wave does a row of tally popcounts.
+    // accumulate batch k (tables[k&1]) and tally batch k+3 in ONE instruction stream: a row of tally
+    // popcounts behind every four table lookups, so that all data waves of the CU issue a uniform
+    // LDS/VALU mix instead of queueing on the LDS in one phase and on the VALU in the next.
     auto accumulate_and_tally = [&](uint32_t k, const uint32_t(&cur)[kRowsPerBatch],
                                     const uint32_t(&tal)[kRowsPerBatch]) {
-        const double *Tk = &lds.table[k & 1][0][0];
         const int par = (k + 3) & 1;
-        uint32_t x[2][4];
-        double v[2][4];
-        transpose_fold_4x16(cur[0], cur[1], cur[2], cur[3], x[0]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[0][q] = Tk[x[0][q] & 0xFFu];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g < 3)
-                transpose_fold_4x16(cur[4 * g + 4], cur[4 * g + 5], cur[4 * g + 6], cur[4 * g + 7],
-                                    x[(g + 1) & 1]);
+            uint32_t x[4];
+            transpose_fold_4x16(cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], x);
+            const double *Tg = lds.table[k & 1][g];
             uint32_t tp[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int c = 4 * g + kk;  // chunk index 0..15
-                // queue chunk c+1
-                if (kk < 3) {
+                double v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[(c + 1) & 1][q] = Tk[g * 256 + ((x[g & 1][q] >> (8 * (kk + 1))) & 0xFFu)];
-                } else if (g < 3) {
+                for (int q = 0; q < 4; ++q) v[q] = Tg[(x[q] >> (8 * kk)) & 0xFFu];
+                tp[kk] = tally_pack(tal[4 * g + kk]);  // VALU work while the lookups are in flight
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[(c + 1) & 1][q] = Tk[(g + 1) * 256 + (x[(g + 1) & 1][q] & 0xFFu)];
-                }
-                tp[kk] = tally_pack(tal[c]);  // VALU work while the lookups are in flight
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[c & 1][q];
-                // pin the adds (see fused_kernel): hipcc otherwise sinks them and spills the lookups
+                for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[q];
+                // Pin the four adds here.  Without the opaque use hipcc (ROCm 7.2) sinks the
+                // v_add_f64 of a whole batch below the next barrier and spills the looked-up values
+                // to scratch; with it, four lookups are in flight per wave at a time.
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[4 * kk + q]));
                 __builtin_amdgcn_sched_barrier(0);

@@ -8,9 +8,17 @@
 
 namespace nps {
 
-// Device layout of a packed GT row (DESIGN.md "Data layout"): ceil(N/16) uint32, row stride padded
-// to 64 words (256 B).  Tally word per row: (nmissing << 32) | neffect.
+// Device layout of the packed GT matrix (DESIGN.md "Data layout"): 2-bit codes, 16 samples per
+// uint32 word (word column c = samples 16c..16c+15).  Rows are stored in GROUPS OF FOUR, interleaved
+// at word granularity: word (row, c) lives at uint32 index ((row/4)*stride_words + c)*4 + row%4, so
+// the four rows a thread needs for one table lookup group are ONE 16-byte load and a wave reads
+// 1 KiB contiguously.  stride_words = word columns per group, padded to 64 (a group is a multiple
+// of 1 KiB); padding words and the rows that pad the last group are zero.
+// Tally word per row (two-pass path): (nmissing << 32) | neffect.
 constexpr uint32_t kStrideAlignWords = 64;
+static inline uint64_t g4_word_index(uint64_t row, uint64_t col, uint64_t stride_words) {
+    return ((row >> 2) * stride_words + col) * 4 + (row & 3);
+}
 
 static inline uint64_t words_for(uint64_t n_samples) { return (n_samples + 15) / 16; }
 static inline uint64_t stride_words_for(uint64_t n_samples) {
@@ -25,13 +33,20 @@ struct DevParams {
     double min_cs;  // compared in double, nimpress.nim:471
 };
 
-// raw bcf_get_genotypes buffer (device copy) -> packed row + tally (atomic add into *tally)
+// raw bcf_get_genotypes buffer (device copy) -> row `row_in_group` of the group at d_group (group
+// interleaved layout) + tally (atomic add into *tally)
 hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
-                            uint32_t *d_row, unsigned long long *d_tally);
+                            uint32_t *d_group, int row_in_group, unsigned long long *d_tally);
 
-// tally of packed rows [0,n_rows): tally[row] = (nmiss<<32)|neff   (direct store)
+// tally of rows [0,n_rows) of a group-interleaved matrix (d_codes = first group):
+// tally[row] = (nmiss<<32)|neff   (direct store)
 hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
                                uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally);
+
+// a plain (contiguous) packed row: tally it and scatter it into row `row_in_group` of a group
+hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
+                                    uint32_t *d_group, int row_in_group,
+                                    unsigned long long *d_tally);
 
 // per-row decision + LUT {0b,1b,2b,imp*b} (or the locus constant); rows [n_rows, n_rows_pad) get a
 // zero LUT.  Adds the number of used rows to *d_nloci.

@@ -13,6 +13,8 @@
 // 256-entry float64 table in LDS, T[c0|c1<<2|c2<<4|c3<<6] = ((l0[c0]+l1[c1])+l2[c2])+l3[c3] with
 // l_r[c] = LUT of row r (0*b, 1*b, 2*b, imputed*b), transposes four 16-sample words into sixteen
 // byte indices with 16 bit-field ops, and does one ds_read_b64 + one v_add_f64 per FOUR genotypes.
+#include <algorithm>
+
 #include "nps_kernels.h"
 
 namespace nps {
@@ -60,7 +62,8 @@ static __device__ __forceinline__ void group_sum3(uint32_t &a, uint32_t &b, uint
 // nimpress.nim:385-390).
 template <int PLOIDY>
 __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restrict__ gts, uint64_t n,
-                                                        int eaidx, uint32_t *__restrict__ out_row,
+                                                        int eaidx, uint32_t *__restrict__ out_group,
+                                                        int row_in_group,
                                                         unsigned long long *__restrict__ tally) {
     __shared__ uint32_t red[4 * 3];
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
     sh |= __shfl_xor(sh, 2, 64);
     sh |= __shfl_xor(sh, 4, 64);
     sh |= __shfl_xor(sh, 8, 64);
-    if ((lane & 15) == 0 && s < n) out_row[s >> 4] = sh;
+    if ((lane & 15) == 0 && s < n) out_group[(s >> 4) * 4 + row_in_group] = sh;
 
     uint32_t m = miss ? 1u : 0u, e = miss ? 0u : (code == NPS_CODE_DOSAGE2 ? 2u : code), z = 0;
     group_sum3<4>(m, e, z, red, threadIdx.x);
@@ -101,17 +104,17 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
 }
 
 hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
-                            uint32_t *d_row, unsigned long long *d_tally) {
+                            uint32_t *d_group, int row_in_group, unsigned long long *d_tally) {
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     if (ploidy == 2)
         hipLaunchKernelGGL(decode_gt_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
-                           eaidx, d_row, d_tally);
+                           eaidx, d_group, row_in_group, d_tally);
     else if (ploidy == 1)
         hipLaunchKernelGGL(decode_gt_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
-                           eaidx, d_row, d_tally);
+                           eaidx, d_group, row_in_group, d_tally);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -128,50 +131,78 @@ static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint
     cm += __popc((w >> 1) & ~w & 0x55555555u);
 }
 
-template <int TPR>  // threads per row: 64 (one wave) or 256 (whole block)
+// grid = (row groups, column chunks of 1024 words); every block adds its part of the four row
+// tallies with one 64-bit integer atomic per row (exact, order independent); `tally` must be zero
 __global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__restrict__ codes,
-                                                           uint64_t stride_words, uint32_t n_vec4,
+                                                           uint64_t stride_words, uint32_t n_words,
                                                            uint64_t n_rows,
                                                            unsigned long long *__restrict__ tally) {
     __shared__ uint32_t red[4 * 3];
-    constexpr int RPB = 256 / TPR;
-    const uint64_t row = (uint64_t)blockIdx.x * RPB + threadIdx.x / TPR;
-    const int t = threadIdx.x % TPR;
-    uint32_t cw = 0, cm = 0, cz = 0;
-    if (row < n_rows) {
-        // rows are 256-B aligned and zero padded to a multiple of 64 words, so whole uint4 reads
-        // up to n_vec4 = ceil(n_words/4) stay inside the row.
-        const uint4 *p = reinterpret_cast<const uint4 *>(codes + row * stride_words);
-        for (uint32_t v = t; v < n_vec4; v += TPR) {
-            const uint4 q = p[v];
-            tally_word(q.x, cw, cm);
-            tally_word(q.y, cw, cm);
-            tally_word(q.z, cw, cm);
-            tally_word(q.w, cw, cm);
+    const uint64_t grp = blockIdx.x;
+    const uint32_t c0 = blockIdx.y * 1024u;
+    uint32_t cw[4] = {0, 0, 0, 0}, cm[4] = {0, 0, 0, 0};
+    const uint4 *p = reinterpret_cast<const uint4 *>(codes) + grp * stride_words;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t c = c0 + u * 256 + threadIdx.x;
+        if (c < n_words) {
+            const uint4 q = p[c];  // the same 16 samples of the group's four rows
+            tally_word(q.x, cw[0], cm[0]);
+            tally_word(q.y, cw[1], cm[1]);
+            tally_word(q.z, cw[2], cm[2]);
+            tally_word(q.w, cw[3], cm[3]);
         }
     }
-    group_sum3<TPR / 64>(cw, cm, cz, red, t);
-    if (t == 0 && row < n_rows)
-        tally[row] = ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t a = cw[r], b = cm[r], z = 0;
+        __syncthreads();  // `red` is reused per row
+        group_sum3<4>(a, b, z, red, threadIdx.x);
+        const uint64_t row = grp * 4 + r;
+        if (threadIdx.x == 0 && row < n_rows && (a | b))
+            atomicAdd(&tally[row], ((unsigned long long)b << 32) | (unsigned long long)(a - b));
+    }
 }
 
 hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
                                uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally) {
     if (n_rows == 0) return hipSuccess;
     const uint64_t n_words = words_for(n_samples);
-    const uint32_t n_vec4 = (uint32_t)((n_words + 3) / 4);
-    if (n_words >= 1024) {
-        if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
-        (void)hipGetLastError();  // drop any stale sticky error: report this launch only
-        hipLaunchKernelGGL(tally_packed_kernel<256>, dim3((uint32_t)n_rows), dim3(256), 0, st,
-                           d_codes, stride_words, n_vec4, n_rows, d_tally);
-    } else {
-        const uint64_t blocks = (n_rows + 3) / 4;
-        if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-        (void)hipGetLastError();  // drop any stale sticky error: report this launch only
-        hipLaunchKernelGGL(tally_packed_kernel<64>, dim3((uint32_t)blocks), dim3(256), 0, st,
-                           d_codes, stride_words, n_vec4, n_rows, d_tally);
+    const uint64_t n_groups = (n_rows + 3) / 4;
+    const uint64_t chunks = std::max<uint64_t>(1, (n_words + 1023) / 1024);
+    if (n_groups > 0x7fffffffull || chunks > 65535) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_tally, 0, sizeof(unsigned long long) * n_rows, st);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();  // drop any stale sticky error: report this launch only
+    hipLaunchKernelGGL(tally_packed_kernel, dim3((uint32_t)n_groups, (uint32_t)chunks), dim3(256), 0,
+                       st, d_codes, stride_words, (uint32_t)n_words, n_rows, d_tally);
+    return hipGetLastError();
+}
+
+// one contiguous packed row (nps_push_packed staging): tally + scatter into the interleaved batch
+__global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *__restrict__ row,
+                                                                uint32_t n_words,
+                                                                uint32_t *__restrict__ out_group,
+                                                                int row_in_group,
+                                                                unsigned long long *__restrict__ tally) {
+    __shared__ uint32_t red[4 * 3];
+    uint32_t cw = 0, cm = 0, cz = 0;
+    for (uint32_t c = threadIdx.x; c < n_words; c += 256) {
+        const uint32_t w = row[c];
+        tally_word(w, cw, cm);
+        out_group[(uint64_t)c * 4 + row_in_group] = w;
     }
+    group_sum3<4>(cw, cm, cz, red, threadIdx.x);
+    if (threadIdx.x == 0) *tally = ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm);
+}
+
+hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
+                                    uint32_t *d_group, int row_in_group,
+                                    unsigned long long *d_tally) {
+    const uint64_t n_words = words_for(n_samples);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tally_scatter_row_kernel, dim3(1), dim3(256), 0, st, d_row, (uint32_t)n_words,
+                       d_group, row_in_group, d_tally);
     return hipGetLastError();
 }
 
@@ -297,13 +328,17 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
         const uint32_t ng = min((uint32_t)kGps, g_end - g0);
         uint32_t w[kGps][4];
 #pragma unroll
-        for (int gg = 0; gg < kGps; ++gg)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint64_t row = (uint64_t)(g0 + gg) * 4 + r;
-                w[gg][r] = (active && gg < (int)ng && row < n_rows) ? codes[row * stride_words + col]
-                                                                   : 0u;
-            }
+        for (int gg = 0; gg < kGps; ++gg) {
+            // one 16-byte load = the thread's word column of the group's four rows (rows past
+            // n_rows inside the last group have a zero LUT, whatever the buffer holds there)
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (active && gg < (int)ng)
+                q = reinterpret_cast<const uint4 *>(codes)[(uint64_t)(g0 + gg) * stride_words + col];
+            w[gg][0] = q.x;
+            w[gg][1] = q.y;
+            w[gg][2] = q.z;
+            w[gg][3] = q.w;
+        }
         // table for entry `tid` of each group of this stage (two LDS buffers -> one barrier/stage)
 #pragma unroll
         for (int gg = 0; gg < kGps; ++gg) {
@@ -393,27 +428,38 @@ static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 
 __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ codes,
                                                        uint64_t stride_words, uint64_t n_samples,
-                                                       uint32_t n_words, uint64_t row0, uint64_t seed,
+                                                       uint32_t n_words, uint64_t row0, uint64_t n_rows,
+                                                       uint64_t seed,
                                                        const uint32_t *__restrict__ t_het,
                                                        const uint32_t *__restrict__ t_hom,
                                                        const uint32_t *__restrict__ t_miss) {
     const uint32_t word = blockIdx.x * 256 + threadIdx.x;
-    const uint64_t r = blockIdx.y;
+    const uint64_t g = blockIdx.y;  // group index relative to row0 (row0 is a multiple of 4)
     if (word >= n_words) return;
-    const uint64_t key = mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull));
-    const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
-    uint32_t w = 0;
+    uint32_t out[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint64_t s = (uint64_t)word * 16 + k;
-        if (s < n_samples) {
-            const uint64_t h = mix64(key + s);
-            const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
-            const uint32_t c = ms < tmi ? NPS_CODE_MISSING : (g < tm ? NPS_CODE_DOSAGE2 : (g < th ? 1u : 0u));
-            w |= c << (2 * k);
+    for (int rr = 0; rr < 4; ++rr) {
+        const uint64_t r = g * 4 + rr;  // row relative to row0 = index into the threshold arrays
+        if (r < n_rows) {
+            const uint64_t key = mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull));
+            const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint64_t s = (uint64_t)word * 16 + k;
+                if (s < n_samples) {
+                    const uint64_t h = mix64(key + s);
+                    const uint32_t gq = (uint32_t)h, ms = (uint32_t)(h >> 32);
+                    const uint32_t c = ms < tmi ? NPS_CODE_MISSING
+                                                : (gq < tm ? NPS_CODE_DOSAGE2 : (gq < th ? 1u : 0u));
+                    w |= c << (2 * k);
+                }
+            }
+            out[rr] = w;
         }
     }
-    codes[(row0 + r) * stride_words + word] = w;
+    reinterpret_cast<uint4 *>(codes)[((row0 >> 2) + g) * stride_words + word] =
+        make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
@@ -422,12 +468,12 @@ hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_wo
                            const uint32_t *d_t_miss) {
     const uint64_t n_words = words_for(n_samples);
     if (n_rows == 0 || n_words == 0) return hipSuccess;
-    // grid.y <= 65535: caller splits larger row ranges
-    if (n_rows > 65535) return hipErrorInvalidValue;
+    const uint64_t n_groups = (n_rows + 3) / 4;
+    if ((row0 & 3) || n_groups > 65535) return hipErrorInvalidValue;  // caller splits row ranges
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
-    hipLaunchKernelGGL(synth_gt_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)n_rows),
+    hipLaunchKernelGGL(synth_gt_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)n_groups),
                        dim3(256), 0, st, d_codes, stride_words, n_samples, (uint32_t)n_words, row0,
-                       seed, d_t_het, d_t_hom, d_t_miss);
+                       n_rows, seed, d_t_het, d_t_hom, d_t_miss);
     return hipGetLastError();
 }
 
