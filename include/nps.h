@@ -48,7 +48,7 @@ typedef enum nps_status {
     NPS_E_HIP = -3,         /* a HIP runtime call failed */
     NPS_E_NOMEM = -4,       /* host or device allocation failed */
     NPS_E_STATE = -5,       /* call not valid in the current state */
-    NPS_E_UNSUPPORTED = -6, /* e.g. ploidy > 2 on the 2-bit path */
+    NPS_E_UNSUPPORTED = -6, /* e.g. ploidy > 8 */
     NPS_E_TIMEOUT = -7      /* an in-kernel bounded wait expired (fused kernel) */
 } nps_status;
 
@@ -142,7 +142,10 @@ int nps_create(nps_ctx **out, int device, uint64_t n_samples, const nps_params *
  * `genotypes(variant.format, gts)` iterates, nimpress.nim:381-384): n_samples*ploidy int32,
  * allele a encoded (a+1)<<1|phased, missing allele 0, vector-end pad 0x80000001.
  * eaidx: 0 = REF, k = ALT[k-1] (nimpress.nim:375-379).  Replaces getRawDosages ..
- * `scores[i] += dosages[i]*beta` for this row (nimpress.nim:561-583, 639-641). */
+ * `scores[i] += dosages[i]*beta` for this row (nimpress.nim:561-583, 639-641).
+ * ploidy 1..2 rows go to the 2-bit matrix; ploidy 3..8 rows (dosage may exceed 2, the reference
+ * counts every allele, nimpress.nim:385-390) are decoded on the device into a float dosage row
+ * and scored with the DS kernels.  ploidy > 8: NPS_E_UNSUPPORTED. */
 int nps_push_gt(nps_ctx *ctx, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
                 double beta, double eaf);
 

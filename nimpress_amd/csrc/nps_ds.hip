@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ds_tally_kernel(const float *__restrict__
     __shared__ uint32_t s_cnt[4];
     const uint64_t row = blockIdx.x;
     if (row >= n_rows) return;
-    const bool rie = desc[row].ref_is_effect != 0;
+    const bool rie = desc[row].ref_is_effect == 1;  // bit 1 set: the row already counts the effect allele
     const float4 *p = reinterpret_cast<const float4 *>(ds + row * stride_f);
     const uint64_t n4 = (n + 3) / 4;  // rows are zero padded to a multiple of 64 floats
     uint32_t cnt = 0;
@@ -89,14 +89,15 @@ __global__ __launch_bounds__(256) void ds_params_kernel(const DsTally *__restric
         const double neff = tally[row].neff;
         const uint64_t ngen = n_samples - nmiss;
         const double beta = desc[row].beta, eaf = desc[row].eaf;
-        const bool rie = desc[row].ref_is_effect != 0;
+        const bool rie = (desc[row].ref_is_effect & 1) != 0;       // homref imputation value
+        const bool flip = desc[row].ref_is_effect == 1;            // dosage = 2 - DS
         const double nan = __longlong_as_double(0x7ff8000000000000ll);
         DsRowP r;
         r.beta = beta;
         r.imp = 0.0;
         r.cst = 0.0;
         r.mode = 0;
-        r.rie = rie ? 1 : 0;
+        r.rie = flip ? 1 : 0;
         int reason;
         const double missingrate = (double)nmiss / (double)n_samples;
         if (missingrate > p.max_missing_rate) {  // nim:565-571
@@ -179,6 +180,36 @@ __global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restr
     }
     for (; row < n_rows; ++row) apply(rowp[row], p[row * stride_f]);
     part0[i] = s;
+}
+
+// FORMAT/GT with ploidy > 2 (dosage can exceed 2, nimpress.nim:385-390): decoded to a float dosage
+// row on the device and scored through the DS path.  Same allele rules as decode_gt_kernel.
+__global__ __launch_bounds__(256) void decode_gt_to_ds_kernel(const int32_t *__restrict__ gts,
+                                                              uint64_t n, int ploidy, int eaidx,
+                                                              float *__restrict__ out) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    int cnt = 0;
+    bool miss = false;
+    for (int k = 0; k < ploidy; ++k) {
+        const int32_t a = gts[s * (uint64_t)ploidy + k];
+        if (a >= 0) {
+            if (a < 2)
+                miss = true;
+            else
+                cnt += ((a >> 1) - 1) == eaidx;
+        }
+    }
+    out[s] = miss ? __int_as_float(0x7fc00000) : (float)cnt;
+}
+
+hipError_t launch_decode_gt_to_ds(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy,
+                                  int eaidx, float *d_out) {
+    if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(decode_gt_to_ds_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
+                       d_gts, n, ploidy, eaidx, d_out);
+    return hipGetLastError();
 }
 
 // device copy of ref_synth_ds (oracle/refcpu.c)

@@ -108,6 +108,9 @@ struct nps_ctx {
     DsTally *d_rds_tally = nullptr;
     DsRowP *d_rds_rowp = nullptr;
 
+    int32_t *d_poly = nullptr;  // raw GT staging for ploidy > 2
+    size_t poly_cap = 0;
+
     // accumulators
     AccumGeom geom{};         // streaming geometry (groups_per_chunk for a full batch)
     uint32_t n_chunks = 1;
@@ -254,6 +257,7 @@ static void free_ctx(nps_ctx *c) {
     for (int k = 0; k < nps_ctx::kRawSlots; ++k)
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
     (void)hipFree(c->d_ds);
+    (void)hipFree(c->d_poly);
     (void)hipFree(c->d_ds_desc);
     (void)hipFree(c->d_ds_tally);
     (void)hipFree(c->d_ds_rowp);
@@ -514,17 +518,61 @@ static void commit_data_row(nps_ctx *c, uint32_t slot) {
     c->batch_rows = slot + 1;
 }
 
+static int ensure_ds(nps_ctx *c);
+
+// ploidy > 2: the dosage can exceed 2, which the 2-bit codes cannot hold (nimpress is documented as
+// diploid-specific, README.md:158, but its loop counts any number of alleles, nim:385-390).  The
+// record is decoded on the device into a float dosage row and scored through the DS path.
+static int push_gt_polyploid(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
+                             double beta, double eaf) {
+    int rc = ensure_ds(c);
+    if (rc) return rc;
+    if (c->ds_rows == c->ds_cap) {
+        rc = run_batch(c);
+        if (rc) return rc;
+    }
+    const uint32_t slot = c->ds_rows;
+    nps_row_desc &d = c->h_ds_desc[slot];
+    d.beta = beta;
+    d.eaf = eaf;
+    d.kind = NPS_ROW_PRESENT;
+    // the decoded row already counts the effect allele: flag bit 1 tells the DS kernels not to apply
+    // the 2 - DS transform, bit 0 still selects the homref imputation value (nim:435-438)
+    d.ref_is_effect = (ref_is_effect ? 1 : 0) | 2;
+    if (c->n) {
+        const size_t bytes = sizeof(int32_t) * (size_t)ploidy * c->n;
+        if (bytes > c->poly_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_poly);
+            c->d_poly = nullptr;
+            c->poly_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_poly, bytes));
+            c->poly_cap = bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_poly, gts, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // pageable source: the caller may reuse it on return
+        ProfScope ps(c, P_DECODE);
+        HIP_TRY(launch_decode_gt_to_ds(c->stream, c->d_poly, c->n, ploidy, eaidx,
+                                       c->d_ds + (uint64_t)slot * c->ds_stride_f));
+    }
+    PendingRow p;
+    p.batch_idx = (int32_t)slot;
+    p.is_ds = 1;
+    memset(&p.host, 0, sizeof p.host);
+    c->pending.push_back(p);
+    c->ds_rows = slot + 1;
+    return NPS_OK;
+}
+
 extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
                            double beta, double eaf) {
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
     if (c->n && !gts) return fail(NPS_E_INVAL, "gts is NULL");
     if (ploidy < 1) return fail(NPS_E_INVAL, "ploidy %d < 1", ploidy);
-    if (ploidy > 2)
-        return fail(NPS_E_UNSUPPORTED,
-                    "ploidy %d: the 2-bit GT path holds dosages 0..2 (nimpress is diploid-specific, "
-                    "README.md:158)", ploidy);
+    if (ploidy > 8) return fail(NPS_E_UNSUPPORTED, "ploidy %d > 8", ploidy);
     if (eaidx < 0) return fail(NPS_E_INVAL, "eaidx %d < 0 (nimpress.nim:380 doAssert)", eaidx);
     HIP_TRY(hipSetDevice(c->device));
+    if (ploidy > 2) return push_gt_polyploid(c, gts, ploidy, eaidx, ref_is_effect, beta, eaf);
     uint32_t slot;
     int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
     if (rc) return rc;

@@ -119,6 +119,8 @@ hipError_t launch_ds_params(hipStream_t st, const DsTally *d_tally, const nps_ro
 hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
                                 const DsRowP *d_rowp, uint64_t n_rows, double *d_part,
                                 uint32_t n_chunks, uint64_t part_chunk_stride);
+hipError_t launch_decode_gt_to_ds(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy,
+                                  int eaidx, float *d_out);
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
                            uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss);

@@ -367,7 +367,7 @@ def test_nan_eaf_and_fail_propagation():
 def test_bad_arguments_are_errors_not_aborts():
     sc = capi.Scorer(4, capi.make_params())
     with pytest.raises(capi.NpsError) as ei:
-        sc.push_gt(np.zeros(12, np.int32), 3, 1, False, 0.1, 0.1)     # ploidy 3
+        sc.push_gt(np.zeros(36, np.int32), 9, 1, False, 0.1, 0.1)     # ploidy 9
     assert ei.value.status == -6
     with pytest.raises(capi.NpsError):
         sc.push_locus(0, False, 0.1, 0.1)                              # PRESENT is not a no-data kind
@@ -499,4 +499,34 @@ def test_ds_and_gt_rows_mixed_in_one_score():
     ref_scores, ref_nloci = ref.finish(0.0)
     assert nloci == ref_nloci and len(stats) == 21
     assert [int(s["nmissing"]) for s in stats] == [int(s[1]) for s in ref.stats]
+    assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
+
+
+def test_polyploid_gt_rows():
+    """ploidy 3 and 4: dosages up to the ploidy (nimpress.nim:385-390 counts every allele); decoded on
+    the device into a float dosage row, mixed with diploid rows in one score"""
+    n = 301
+    rng = np.random.default_rng(33)
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.2, mincs=10)
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    ref = refcpu.RefScorer(n, refcpu.make_params(**kw))
+    betas = []
+    saw_high = False
+    for j, ploidy in enumerate([3, 2, 4, 3, 2, 4, 1]):
+        eaidx = int(rng.integers(0, 3))
+        alle = rng.integers(-1, 3, size=(n, ploidy))
+        saw_high |= bool(((alle == eaidx).sum(axis=1) > 2).any())
+        alle[rng.uniform(size=n) < (0.5 if j == 3 else 0.04)] = -1
+        gts = (((alle + 1) << 1) | rng.integers(0, 2, size=(n, ploidy))).astype(np.int32)
+        beta, eaf = float(rng.normal(0, 0.1)), float(rng.uniform(0.1, 0.5))
+        sc.push_gt(gts.ravel(), ploidy, eaidx, eaidx == 0, beta, eaf)
+        ref.row_gt(gts.ravel(), ploidy, eaidx, eaidx == 0, beta, eaf)
+        betas.append(beta)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.2)
+    sc.close()
+    ref_scores, ref_nloci = ref.finish(0.2)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, ref.stats)
+    assert saw_high                                             # dosages above 2 occurred
     assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
