@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=500_000, help="cohort size N (default: config 3)")
     ap.add_argument("--variants", type=int, default=1_000_000, help="score rows M (default: config 3)")
     ap.add_argument("--mode", choices=["auto", "twopass", "fused"], default="auto")
+    ap.add_argument("--format", choices=["gt", "ds"], default="gt",
+                    help="gt: 2-bit packed GT matrix (the headline, config 3); ds: float32 FORMAT/DS "
+                         "matrix (config 5 shape: pass --samples 200000 and as many --variants as fit HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20250103)
@@ -113,8 +116,11 @@ def main():
     # synthetic cohort, generated on the device; identical on every rank (same seed)
     _, eaf, miss = synth_score(m, args.seed)
     t_het, t_hom, t_miss = hwe_thresholds(eaf, miss)
-    cohort = capi.Cohort(n, m, device=local_rank)
-    cohort.synth(0, args.seed, t_het, t_hom, t_miss)
+    is_ds = args.format == "ds"
+    cohort = capi.Cohort(n, m, fmt=capi.FMT_DS32 if is_ds else capi.FMT_GT2, device=local_rank)
+    for r0 in range(0, m, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
+        r1 = min(m, r0 + (1 << 15))
+        cohort.synth(r0, args.seed, t_het[r0:r1], t_hom[r0:r1], t_miss[r0:r1])
     # this rank's score definition: its own betas (score files sharded across GPUs)
     beta = np.round(np.random.default_rng(args.seed + 1000 + rank).normal(0.0, 0.02, m), 4)
     sdef = capi.ScoreDef(capi.row_descs(beta, eaf), device=local_rank)
@@ -162,7 +168,7 @@ def main():
         value = world * genotypes_per_step * args.steps / elapsed
         # algorithmic bytes per step: one read of the matrix + per-row
         # params + one write of the scores
-        alg_bytes = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
+        alg_bytes = (4 * m * n if is_ds else m * ((n + 15) // 16) * 4) + 40 * m + 8 * n
         kern_ms = {"tally": prof.ms_tally, "params": prof.ms_params,
                    "accumulate": prof.ms_accumulate, "fused": prof.ms_fused,
                    "finish": prof.ms_reduce}
@@ -186,8 +192,11 @@ def main():
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic %d-variant PRS on %d-sample 2-bit GT matrix resident in "
-                                   "HBM (BASELINE.json configs[2]), CLI-default imputation flags"
+            "config": {"workload": ("synthetic %d-variant PRS on %d-sample float32 FORMAT/DS matrix "
+                                    "resident in HBM (BASELINE.json configs[4] shape, rows limited to "
+                                    "what fits one GPU), CLI-default imputation flags" if is_ds else
+                                    "synthetic %d-variant PRS on %d-sample 2-bit GT matrix resident in "
+                                    "HBM (BASELINE.json configs[2]), CLI-default imputation flags")
                                    % (m, n),
                        "samples": n, "variants": m, "nloci": int(nloci),
                        "mode": args.mode, "parallelism": "score-sharded x%d + RCCL all-gather" % world
@@ -202,7 +211,7 @@ def main():
                                                "accumulate": prof.n_accumulate / steps,
                                                "fused": prof.n_fused / steps}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_ds:
             out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)
         print(json.dumps(out))
     if world > 1:

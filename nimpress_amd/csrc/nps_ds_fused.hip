@@ -1,0 +1,449 @@
+// nps_ds_fused.hip -- single-read kernel for a resident FORMAT/DS (float32 dosage) cohort.
+//
+// Same problem and same structure as nps_fused.hip (the 2-bit GT kernel): tallyAlleles
+// (nimpress.nim:32-47) needs the whole row before any of its samples can be accumulated
+// (:565-571, :470-477), the accumulation (:639-641) wants every sample's float64 partial on chip
+// across all rows.  The two-pass DS kernels (nps_ds.hip) read the 4 B/genotype matrix twice; this
+// kernel reads it once:
+//
+//   * cooperative grid = Q teams x P workgroups (one per CU).  Workgroup (q,p) owns 7 680 samples
+//     (8 per data thread: two float4 columns 256 samples apart, so every wave instruction reads
+//     1 KiB contiguously) and the row batches q, q+Q, ... (2 rows per batch).
+//   * 15 data waves: 5-deep register ring of batches; per phase they accumulate batch k in the
+//     reference's own order and operations (row after row, float64 `dosage * beta` then `+=`,
+//     not fused), tally batch k+4 (NaN count by wave ballot, dosage sum by a fixed-shape tree) and
+//     refill the ring.
+//   * control wave: combines the waves' partial tallies in fixed order, stores the workgroup's
+//     partial dosage sum to psum[row][slice] (sc1 store, drained) and then signals with one 64-bit
+//     agent-scope atomic (arrivals<<56 | nmissing); two phases later it polls the row's word until
+//     all P slices have arrived, adds the P partial sums (sc1 loads) in fixed order -- deterministic,
+//     and derives the row's parameters for the data waves.  One workgroup barrier per batch.
+//
+// Semantics are the build-defined DS extension of the oracle (ref_raw_dosages_ds): NaN = missing,
+// effect allele == REF -> dosage = 2 - DS.  The row's dosage sum is formed as sum(DS) and turned into
+// 2*ngenotyped - sum(DS) for such rows (the two-pass kernel adds 2 - DS per sample); both differ
+// from the oracle's sequential sum in the last bits only (test bar 1e-9 relative).
+#include <algorithm>
+#include <cstdlib>
+
+#include "nps_kernels.h"
+
+namespace nps {
+
+constexpr int kDsRows = 2;     // rows per batch
+constexpr int kDsPerThread = 8;
+constexpr int kDsRing = 5;     // batches in flight per data thread
+constexpr int kDsThreads = 1024;
+constexpr int kDsDataThreads = kDsThreads - 64;
+constexpr uint32_t kDsSliceSamples = kDsDataThreads * kDsPerThread;  // 7 680
+constexpr uint32_t kDsSpinLimit = 1u << 20;
+
+struct DsFusedArgs {
+    const float *ds;
+    uint64_t stride_f;
+    uint64_t n_rows;
+    uint64_t n_samples;
+    uint32_t n_batches;
+    uint32_t P, Q;
+    const nps_row_desc *desc;
+    DevParams prm;
+    unsigned long long *tally;  // [n_rows], zeroed: arrivals << 56 | nmissing
+    double *psum;               // [n_rows][P]: sum of the non-missing DS values of one slice
+    nps_locus_stat *stats;
+    unsigned long long *nloci;
+    double *part;  // [Q][part_team_stride]
+    uint64_t part_team_stride;
+    unsigned int *timeout;
+};
+
+struct DsRowLds {
+    double beta, imp;  // imp: value of a missing sample (mode 1) or of every sample (mode 2)
+    int32_t mode;      // 0 dropped (beta = imp = 0), 1 genotyped, 2 locus constant
+    int32_t flip;      // dosage = 2 - DS
+};
+struct __attribute__((aligned(16))) DsFusedLds {
+    double wsum[2][kDsRows][16];
+    uint32_t wcnt[2][kDsRows][16];
+    DsRowLds rowp[2][kDsRows];
+};
+
+static __device__ __forceinline__ double wave_tree_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // lane 0
+}
+// wave sum by DPP (row_shr 1,2,4,8, then row_bcast15 / row_bcast31): fixed order, total in lane 63.
+// Two v_mov_b32_dpp + one v_add_f64 per stage, ~100 cycles of dependent latency per row instead of
+// the ~1 500 of a ds_bpermute tree.
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+static __device__ __forceinline__ double wave_dpp_sum(double v) {
+    v += dpp_f64<0x111, 0xF>(v);  // row_shr:1 (lanes without a source add +0.0)
+    v += dpp_f64<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_f64<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_f64<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_f64<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;                     // lane 63
+}
+static __device__ __forceinline__ double uniform_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedArgs a) {
+    constexpr int R = kDsRows, D = kDsRing;
+    __shared__ DsFusedLds lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t team = blockIdx.y, slice = blockIdx.x;
+    const uint32_t n_local = a.n_batches > team ? (a.n_batches - team + a.Q - 1) / a.Q : 0;
+    const uint32_t n_steps = (n_local + D - 1) / D * D;
+
+    auto batch_row0 = [&](uint32_t k) -> uint64_t { return (uint64_t)(team + (uint64_t)k * a.Q) * R; };
+
+    // Barrier #j closes the phase in which the data waves tallied batch j.
+    //   data waves, phase k (between #(k+3) and #(k+4)): accumulate batch k with rowp[k&1], tally
+    //       batch k+4, refill the ring slot of batch k with batch k+5
+    //   control wave, same phase: publish batch k+3; parameters of batch k+1 (its tallies were
+    //       published by every slice two phases ago) -> rowp[(k+1)&1]
+    if (wave == 0) {
+        // ------------------------------------------------------------------ control wave
+        uint32_t nloci_local = 0;
+        bool timed_out = false;
+
+        auto publish = [&](uint32_t k) {
+            if (lane < R) {
+                const int par = k & 1;
+                double s = 0.0;
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int w = 1; w < 16; ++w) {  // fixed order
+                    s += lds.wsum[par][lane][w];
+                    cnt += lds.wcnt[par][lane][w];
+                }
+                const uint64_t row = batch_row0(k) + lane;
+                if (k < n_local && row < a.n_rows) {
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.psum[row * a.P + slice]),
+                                       (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    // the sc1 (write-through) store is drained before the arrival is added: the
+                    // fence-free hand-off MI355X_MICROARCH.md lists as measured valid on gfx950 (one
+                    // lane signals for its own 8-byte sc1 store; the consumer's polling wave loads the
+                    // bytes with sc1 loads after its poll matched).  An agent-scope release/acquire
+                    // pair instead costs 1.7-6.5 us per phase (buffer_wbl2 / buffer_inv).
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&a.tally[row], (1ull << 56) | (unsigned long long)cnt,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+
+        auto params = [&](uint32_t kt) {
+            const uint64_t row = batch_row0(kt) + lane;
+            const bool valid = lane < R && kt < n_local && row < a.n_rows;
+            unsigned long long x = 0;
+            double beta = 0.0, eaf = 0.0;
+            int rflags = 0;
+            if (valid) {
+                x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                beta = a.desc[row].beta;
+                eaf = a.desc[row].eaf;
+                rflags = a.desc[row].ref_is_effect;
+            }
+            bool ok = !valid || (uint32_t)(x >> 56) == a.P;
+            uint32_t spins = 0;
+            while (!__all(ok) && !timed_out) {
+                __builtin_amdgcn_s_sleep(1);
+                if (!ok) {
+                    x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(x >> 56) == a.P;
+                }
+                if ((++spins & 255u) == 0) {
+                    const unsigned int t =
+                        __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t != 0 || spins >= kDsSpinLimit) {
+                        if (lane == 0)
+                            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        timed_out = true;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");  // the loads below stay behind the matched poll
+            // the P partial sums of each row, added in fixed order by the whole wave
+            double mysum = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t row_r = batch_row0(kt) + r;
+                const bool have = kt < n_local && row_r < a.n_rows && !timed_out;
+                double v = 0.0;
+                if (have) {
+                    for (uint32_t i = lane; i < a.P; i += 64)
+                        v += __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<unsigned long long *>(&a.psum[row_r * a.P + i]),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                const double tot = uniform_f64(wave_tree_sum(v));
+                if (lane == r) mysum = tot;
+            }
+            int used = 0;
+            if (lane < R) {
+                DsRowLds rp;
+                rp.beta = 0.0;
+                rp.imp = 0.0;
+                rp.mode = 0;
+                rp.flip = rflags == 1;  // bit 1 set: the row already counts the effect allele
+                if (valid && ok) {
+                    const bool rie = (rflags & 1) != 0;  // homref imputation value
+                    const uint64_t nmiss = x & ((1ull << 56) - 1);
+                    const uint64_t ngen = a.n_samples - nmiss;
+                    const double neff = rp.flip ? 2.0 * (double)ngen - mysum : mysum;
+                    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+                    int reason;
+                    const double missingrate = (double)nmiss / (double)a.n_samples;
+                    if (missingrate > a.prm.max_missing_rate) {  // nim:565-571
+                        reason = NPS_REASON_MAXMIS;
+                        if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
+                            const double c = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                                             : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                                                   : nan;
+                            rp.imp = c;  // every sample gets the locus constant
+                            rp.mode = 2;
+                            used = 1;
+                        }
+                    } else {  // nim:450-481
+                        reason = NPS_REASON_GENOTYPED;
+                        used = 1;
+                        rp.mode = 1;
+                        switch (a.prm.imp_sample) {
+                        case NPS_SAMPLE_PS: rp.imp = eaf * 2.0; break;
+                        case NPS_SAMPLE_HOMREF: rp.imp = rie ? 2.0 : 0.0; break;
+                        case NPS_SAMPLE_FAIL: rp.imp = nan; break;
+                        default:
+                            if ((double)ngen >= a.prm.min_cs)
+                                rp.imp = neff / (double)ngen;
+                            else
+                                rp.imp = a.prm.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
+                            break;
+                        }
+                    }
+                    if (slice == 0 && a.stats != nullptr) {
+                        nps_locus_stat s;
+                        s.ngenotyped = ngen;
+                        s.nmissing = nmiss;
+                        s.neffect = neff;
+                        s.used = used;
+                        s.reason = reason;
+                        a.stats[row] = s;
+                    }
+                }
+                if (rp.mode != 0) rp.beta = beta;  // a dropped row adds imp * beta = 0 * 0
+                lds.rowp[kt & 1][lane] = rp;
+            }
+            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+        };
+
+        __syncthreads();  // #0
+        publish(0);
+        __syncthreads();  // #1
+        publish(1);
+        __syncthreads();  // #2
+        publish(2);
+        params(0);
+        __syncthreads();  // #3
+        for (uint32_t k = 0; k < n_steps; ++k) {
+            publish(k + 3);
+            params(k + 1);
+            __syncthreads();  // #(k+4)
+        }
+        if (slice == 0 && lane == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- data waves
+    // samples of this thread: s0 + 0..3 and s0 + 256 + 0..3
+    const uint32_t s0 = slice * kDsSliceSamples + (uint32_t)(wave - 1) * 512u + (uint32_t)lane * 4u;
+    const uint32_t voff = s0 * 4u;
+    // clamp so that the descriptor range (bytes of one row) stays below 4 GiB
+    const uint32_t row_bytes = (uint32_t)min(a.n_samples * 4ull, 0xfffffff0ull);
+    const uint64_t stride_bytes = a.stride_f * 4ull;
+
+    double acc[kDsPerThread];
+#pragma unroll
+    for (int s = 0; s < kDsPerThread; ++s) acc[s] = 0.0;
+    float ring[D][R * kDsPerThread];
+
+    auto load_batch = [&](uint32_t k, float(&dst)[R * kDsPerThread]) {
+        const uint64_t row0 = batch_row0(k);
+        const char *p = reinterpret_cast<const char *>(a.ds) + (k < n_local ? row0 : 0) * stride_bytes;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool in = k < n_local && row0 + r < a.n_rows;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(p), 0, in ? row_bytes : 0u, 0x00020000);
+            const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                dst[r * 8 + s] = __uint_as_float(qa[s]);
+                dst[r * 8 + 4 + s] = __uint_as_float(qb[s]);
+            }
+            p += stride_bytes;
+        }
+    };
+
+    // partial tally of a batch: NaN count of the wave by ballot (SALU), dosage sum by a fixed tree
+    auto tally = [&](uint32_t k, const float(&src)[R * kDsPerThread]) {
+        const int par = k & 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t cnt = 0;
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < kDsPerThread; ++e) {
+                const float v = src[r * 8 + e];
+                const bool nan = v != v;
+                cnt += (uint32_t)__popcll(__ballot(nan));
+                s += (double)(nan ? 0.0f : v);
+                if ((e & 3) == 3) {
+                    asm volatile("" : "+v"(s));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            s = wave_dpp_sum(s);
+            if (lane == 63) {
+                lds.wsum[par][r][wave] = s;
+                lds.wcnt[par][r][wave] = cnt;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // score += dosage * beta, row after row (nimpress.nim:639-641).  Branch-free: dosage =
+    // c0 + sgn * DS with (c0, sgn) = (0, 1) or (2, -1) -- one rounding, equal to DS and 2 - DS -- and
+    // the row's `all` flag (locus constant, or dropped row with beta = imp = 0) ORed into the NaN mask.
+    auto accumulate = [&](uint32_t k, const float(&cur)[R * kDsPerThread]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const DsRowLds &rp = lds.rowp[k & 1][r];
+            const double beta = uniform_f64(rp.beta), imp = uniform_f64(rp.imp);
+            const bool all = __builtin_amdgcn_readfirstlane(rp.mode) != 1;
+            const bool flip = __builtin_amdgcn_readfirstlane(rp.flip) != 0;
+            const double c0 = flip ? 2.0 : 0.0, sgn = flip ? -1.0 : 1.0;
+#pragma unroll
+            for (int e = 0; e < kDsPerThread; ++e) {
+                const float v = cur[r * 8 + e];
+                const double d = (v != v) || all ? imp : __fma_rn((double)v, sgn, c0);
+                acc[e] += d * beta;
+                if (e & 1) {  // two elements at a time: keeps the converted values out of the ring's way
+                    asm volatile("" : "+v"(acc[e - 1]), "+v"(acc[e]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+
+    auto step = [&](uint32_t k, float(&r_cur)[R * kDsPerThread], const float(&r_tal)[R * kDsPerThread]) {
+        accumulate(k, r_cur);
+        tally(k + 4, r_tal);
+        load_batch(k + 5, r_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // #(k+4)
+    };
+
+    load_batch(0, ring[0]);
+    load_batch(1, ring[1]);
+    load_batch(2, ring[2]);
+    load_batch(3, ring[3]);
+    load_batch(4, ring[4]);
+    tally(0, ring[0]);
+    __syncthreads();  // #0
+    tally(1, ring[1]);
+    __syncthreads();  // #1
+    tally(2, ring[2]);
+    __syncthreads();  // #2
+    tally(3, ring[3]);
+    __syncthreads();  // #3
+    for (uint32_t k = 0; k < n_steps; k += D) {
+        step(k, ring[0], ring[4]);
+        step(k + 1, ring[1], ring[0]);
+        step(k + 2, ring[2], ring[1]);
+        step(k + 3, ring[3], ring[2]);
+        step(k + 4, ring[4], ring[3]);
+    }
+    double *dst = a.part + (uint64_t)team * a.part_team_stride;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t s = (uint64_t)s0 + 256u * h;
+        if (s < a.n_samples) {  // part_team_stride is padded: whole groups of 4 can be written
+            *reinterpret_cast<double2 *>(dst + s) = make_double2(acc[4 * h], acc[4 * h + 1]);
+            *reinterpret_cast<double2 *>(dst + s + 2) = make_double2(acc[4 * h + 2], acc[4 * h + 3]);
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan) {
+    *plan = FusedPlan{};
+    if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 30)) return hipSuccess;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    const int cus = prop.multiProcessorCount;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel, kDsThreads, 0);
+    if (e != hipSuccess) return e;
+    if (cus < 1 || per_cu < 1) return hipSuccess;
+    const uint64_t P = (n_samples + kDsSliceSamples - 1) / kDsSliceSamples;
+    const uint64_t n_batches = (n_rows + kDsRows - 1) / kDsRows;
+    if (P > (uint64_t)cus || P > 255 || n_batches > 0xfffffff0ull) return hipSuccess;
+    uint64_t Q = std::min<uint64_t>((uint64_t)cus / P, n_batches);
+    if (const char *env = getenv("NPS_FUSED_MAXQ"))
+        if (atoi(env) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(env));
+    if (Q < 1 || Q > 65535) return hipSuccess;
+    plan->threads = kDsThreads;
+    plan->P = (uint32_t)P;
+    plan->Q = (uint32_t)Q;
+    plan->n_batches = (uint32_t)n_batches;
+    plan->part_team_stride = P * kDsSliceSamples;
+    plan->ok = true;
+    return hipSuccess;
+}
+
+hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
+                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
+                           DevParams prm, unsigned long long *d_tally, double *d_psum,
+                           nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
+                           unsigned int *d_timeout) {
+    DsFusedArgs a;
+    a.ds = d_ds;
+    a.stride_f = stride_f;
+    a.n_rows = n_rows;
+    a.n_samples = n_samples;
+    a.n_batches = plan.n_batches;
+    a.P = plan.P;
+    a.Q = plan.Q;
+    a.desc = d_desc;
+    a.prm = prm;
+    a.tally = d_tally;
+    a.psum = d_psum;
+    a.stats = d_stats;
+    a.nloci = d_nloci;
+    a.part = d_part;
+    a.part_team_stride = plan.part_team_stride;
+    a.timeout = d_timeout;
+    void *args[] = {&a};
+    // cooperative launch: the runtime rejects a grid that cannot be fully resident
+    return hipLaunchCooperativeKernel((const void *)ds_fused_kernel, dim3(plan.P, plan.Q),
+                                      dim3(plan.threads), args, 0, st);
+}
+
+}  // namespace nps

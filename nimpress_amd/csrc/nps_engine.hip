@@ -107,6 +107,8 @@ struct nps_ctx {
     uint64_t res_ds_cap = 0;
     DsTally *d_rds_tally = nullptr;
     DsRowP *d_rds_rowp = nullptr;
+    double *d_rds_psum = nullptr;  // fused DS kernel: per (row, slice) partial dosage sums
+    uint64_t psum_cap = 0;
 
     int32_t *d_poly = nullptr;  // raw GT staging for ploidy > 2
     size_t poly_cap = 0;
@@ -267,6 +269,7 @@ static void free_ctx(nps_ctx *c) {
         if (c->ev_ds_raw[k]) (void)hipEventDestroy(c->ev_ds_raw[k]);
     (void)hipFree(c->d_rds_tally);
     (void)hipFree(c->d_rds_rowp);
+    (void)hipFree(c->d_rds_psum);
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_rtally);
@@ -1044,15 +1047,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                     (unsigned long long)co->n_samples, (unsigned long long)c->n);
     if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
-    if (co->format == NPS_FMT_DS32) {
-        if (mode == NPS_MODE_FUSED)
-            return fail(NPS_E_UNSUPPORTED, "the fused kernel handles 2-bit GT cohorts only");
-        mode = NPS_MODE_TWOPASS;
-    }
     HIP_TRY(hipSetDevice(c->device));
     FusedPlan plan;
     if (mode != NPS_MODE_TWOPASS) {
-        HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0), &plan));
+        if (co->format == NPS_FMT_DS32)
+            HIP_TRY(ds_fused_plan(c->device, c->n, def->m, &plan));
+        else
+            HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0), &plan));
         if (const char *e = getenv("NPS_DISABLE_FUSED"))
             if (*e == '1' && mode == NPS_MODE_AUTO) plan.ok = false;
         if (!plan.ok && mode == NPS_MODE_FUSED && c->n && def->m)
@@ -1097,6 +1098,50 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         const uint64_t stride_f = co->stride_bytes / 4;
         const float *ds = (const float *)co->d_data + cohort_row0 * stride_f;
+        if (plan.ok && c->n) {
+            // fused single-read path
+            const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
+            if (need > c->part_fused_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                (void)hipFree(c->d_part_fused);
+                c->d_part_fused = nullptr;
+                c->part_fused_cap = 0;
+                HIP_TRY(hipMalloc(&c->d_part_fused, sizeof(double) * need));
+                c->part_fused_cap = need;
+            }
+            const uint64_t need_psum = m * plan.P;
+            if (need_psum > c->psum_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                (void)hipFree(c->d_rds_psum);
+                c->d_rds_psum = nullptr;
+                c->psum_cap = 0;
+                HIP_TRY(hipMalloc(&c->d_rds_psum, sizeof(double) * need_psum));
+                c->psum_cap = need_psum;
+            }
+            HIP_TRY(hipMemsetAsync(c->d_rtally, 0, sizeof(unsigned long long) * m_pad, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_timeout, 0, 256, c->stream));
+            hipError_t fe;
+            {
+                ProfScope ps(c, P_FUSED);
+                fe = launch_ds_fused(c->stream, plan, ds, stride_f, c->n, m, def->d_desc,
+                                     dev_params(c->params), c->d_rtally, c->d_rds_psum, c->d_rstats,
+                                     c->d_nloci, c->d_part_fused, c->d_timeout);
+            }
+            if (fe == hipSuccess) {
+                {
+                    ProfScope ps(c, P_REDUCE);
+                    HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n,
+                                        c->d_part));
+                }
+                HIP_TRY(hipMemcpyAsync(&c->h_timeout, c->d_timeout, sizeof(unsigned int),
+                                       hipMemcpyDeviceToHost, c->stream));
+                c->timeout_check = true;
+                return NPS_OK;
+            }
+            (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
+            if (mode == NPS_MODE_FUSED || fe != hipErrorCooperativeLaunchTooLarge)
+                return fail(NPS_E_HIP, "fused DS kernel launch failed: %s", hipGetErrorString(fe));
+        }
         // launches of >= 2048 rows keep every CU busy in both kernels (one workgroup per row in the
         // tally; samples x row chunks in the accumulation)
         uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);

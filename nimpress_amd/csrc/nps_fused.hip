@@ -474,6 +474,8 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedP
     const uint64_t P = (n_words + cols - 1) / cols;
     if (P > capacity || P > 255) return hipSuccess;  // 8-bit arrival count in the tally word
     uint64_t Q = std::min<uint64_t>(capacity / P, n_batches);
+    if (const char *e = getenv("NPS_FUSED_MAXQ"))  // diagnostics: fewer teams = fewer CUs in use
+        if (atoi(e) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(e));
     if (Q < 1 || Q > 65535) return hipSuccess;
     plan->threads = T;
     plan->P = (uint32_t)P;

@@ -119,6 +119,14 @@ hipError_t launch_ds_params(hipStream_t st, const DsTally *d_tally, const nps_ro
 hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
                                 const DsRowP *d_rowp, uint64_t n_rows, double *d_part,
                                 uint32_t n_chunks, uint64_t part_chunk_stride);
+// single-read kernel for a resident DS cohort (nps_ds_fused.hip); plan.threads/P/Q as for the GT kernel.
+// d_tally: [n_rows] zeroed; d_psum: [n_rows * plan.P]; d_part: [Q*part_team_stride]
+hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan);
+hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
+                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
+                           DevParams prm, unsigned long long *d_tally, double *d_psum,
+                           nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
+                           unsigned int *d_timeout);
 hipError_t launch_decode_gt_to_ds(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy,
                                   int eaidx, float *d_out);
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,

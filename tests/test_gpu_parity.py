@@ -452,8 +452,12 @@ def test_ds_streaming_vs_oracle(shape, pk):
     assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
 
 
-@pytest.mark.parametrize("shape", [(100, 3), (4099, 129), (30000, 500)])
-def test_ds_resident_vs_oracle(shape):
+@pytest.mark.parametrize("mode", ["twopass", "fused"])
+@pytest.mark.parametrize("shape", [(100, 3), (1, 1), (4099, 129), (7681, 11), (30000, 500), (15361, 2001)])
+def test_ds_resident_vs_oracle(shape, mode):
+    """resident FORMAT/DS cohort: the two-pass kernels and the single-read fused kernel (2 rows per
+    batch, 7 680 samples per workgroup: the shapes cover ragged batches, an almost empty last slice
+    and more row batches than teams)"""
     n, m = shape
     rng = np.random.default_rng(n + 3 * m)
     co = make_ds_cohort(n, m, 2025, rng)
@@ -464,14 +468,16 @@ def test_ds_resident_vs_oracle(shape):
     assert np.array_equal(got.view(np.uint32) & 0x7fffffff > 0x7f800000, np.isnan(co["ds"]))
     assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(co["ds"], nan=-1.0))
     sc = capi.Scorer(n, capi.make_params(**kw))
-    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0,
+                    capi.MODE_FUSED if mode == "fused" else capi.MODE_TWOPASS)
     stats = sc.flush()
     scores, nloci = sc.finish(0.0)
     sc.close()
     dev.close()
     ref_scores, ref_stats, ref_nloci = oracle_ds(co, kw, 0.0)
     assert nloci == ref_nloci
-    assert 0 < sum(1 for s in ref_stats if s[4] == 4) < m     # both branches exercised
+    if m >= 100:
+        assert 0 < sum(1 for s in ref_stats if s[4] == 4) < m     # both branches exercised
     assert_ds_stats(stats, ref_stats)
     assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
 
@@ -530,3 +536,27 @@ def test_polyploid_gt_rows():
     assert_stats_equal(stats, ref.stats)
     assert saw_high                                             # dosages above 2 occurred
     assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
+
+
+@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
+def test_ds_fused_all_imputation_modes(pk):
+    """every imputation combination through the single-read DS kernel, with a row offset"""
+    n, m, row0 = 9000, 64, 6
+    rng = np.random.default_rng(500 + pk)
+    co = make_ds_cohort(n, m + row0, 4242, rng)
+    kw = PARAM_GRID[pk]
+    dev = capi.Cohort(n, m + row0, fmt=capi.FMT_DS32)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"][row0:], co["eaf"][row0:], None, co["rie"][row0:]),
+                    row0, capi.MODE_FUSED)
+    stats = sc.flush()
+    scores, nloci = sc.finish(-0.5)
+    sc.close()
+    dev.close()
+    sub = dict(co, m=m, ds=co["ds"][row0:], beta=co["beta"][row0:], eaf=co["eaf"][row0:],
+               rie=co["rie"][row0:])
+    ref_scores, ref_stats, ref_nloci = oracle_ds(sub, kw, -0.5)
+    assert nloci == ref_nloci
+    assert_ds_stats(stats, ref_stats)
+    assert rel_err(scores, ref_scores, sub["beta"], max(nloci, 1)) <= REL_TOL
