@@ -120,52 +120,41 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
         uint32_t nloci_local = 0;
         bool timed_out = false;
 
-        auto publish = [&](uint32_t k) {
-            if (lane < R) {
-                const int par = k & 1;
-                double s = 0.0;
-                uint32_t cnt = 0;
-#pragma unroll
-                for (int w = 1; w < 16; ++w) {  // fixed order
-                    s += lds.wsum[par][lane][w];
-                    cnt += lds.wcnt[par][lane][w];
-                }
-                const uint64_t row = batch_row0(k) + lane;
-                if (k < n_local && row < a.n_rows) {
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.psum[row * a.P + slice]),
-                                       (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    // the sc1 (write-through) store is drained before the arrival is added: the
-                    // fence-free hand-off MI355X_MICROARCH.md lists as measured valid on gfx950 (one
-                    // lane signals for its own 8-byte sc1 store; the consumer's polling wave loads the
-                    // bytes with sc1 loads after its poll matched).  An agent-scope release/acquire
-                    // pair instead costs 1.7-6.5 us per phase (buffer_wbl2 / buffer_inv).
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(&a.tally[row], (1ull << 56) | (unsigned long long)cnt,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        // One phase of the control wave costs ONE memory round trip: the loads of the partial sums
+        // of batch k+1 (whose arrival word matched a phase ago), the poll of batch k+2 and the
+        // publication of batch k+3 are issued back to back and drained by one s_waitcnt.
+        struct Polled {  // lanes < R: one row each
+            unsigned long long x;
+            double beta, eaf;
+            int rflags;
+            bool valid, ok;
         };
 
-        auto params = [&](uint32_t kt) {
+        auto poll_issue = [&](uint32_t kt) -> Polled {
+            Polled q;
             const uint64_t row = batch_row0(kt) + lane;
-            const bool valid = lane < R && kt < n_local && row < a.n_rows;
-            unsigned long long x = 0;
-            double beta = 0.0, eaf = 0.0;
-            int rflags = 0;
-            if (valid) {
-                x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                beta = a.desc[row].beta;
-                eaf = a.desc[row].eaf;
-                rflags = a.desc[row].ref_is_effect;
+            q.valid = lane < R && kt < n_local && row < a.n_rows;
+            q.x = 0;
+            q.beta = q.eaf = 0.0;
+            q.rflags = 0;
+            if (q.valid) {
+                q.x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.beta = a.desc[row].beta;
+                q.eaf = a.desc[row].eaf;
+                q.rflags = a.desc[row].ref_is_effect;
             }
-            bool ok = !valid || (uint32_t)(x >> 56) == a.P;
+            q.ok = false;
+            return q;
+        };
+        auto poll_finish = [&](uint32_t kt, Polled &q) {  // spins until all P slices have arrived
+            const uint64_t row = batch_row0(kt) + lane;
+            q.ok = !q.valid || (uint32_t)(q.x >> 56) == a.P;
             uint32_t spins = 0;
-            while (!__all(ok) && !timed_out) {
+            while (!__all(q.ok) && !timed_out) {
                 __builtin_amdgcn_s_sleep(1);
-                if (!ok) {
-                    x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (uint32_t)(x >> 56) == a.P;
+                if (!q.ok) {
+                    q.x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q.ok = (uint32_t)(q.x >> 56) == a.P;
                 }
                 if ((++spins & 255u) == 0) {
                     const unsigned int t =
@@ -177,33 +166,72 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
                     }
                 }
             }
-            asm volatile("" ::: "memory");  // the loads below stay behind the matched poll
-            // the P partial sums of each row, added in fixed order by the whole wave
-            double mysum = 0.0;
+            asm volatile("" ::: "memory");  // loads of the handed-off sums stay behind the matched poll
+        };
+
+        // the P partial sums of each row of batch kt (poll matched): sc1 loads, lane i takes slices
+        // i, i+64, ...
+        auto psum_issue = [&](uint32_t kt, double(&v)[R]) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t row_r = batch_row0(kt) + r;
-                const bool have = kt < n_local && row_r < a.n_rows && !timed_out;
-                double v = 0.0;
-                if (have) {
+                v[r] = 0.0;
+                if (kt < n_local && row_r < a.n_rows && !timed_out)
                     for (uint32_t i = lane; i < a.P; i += 64)
-                        v += __longlong_as_double((long long)__hip_atomic_load(
+                        v[r] += __longlong_as_double((long long)__hip_atomic_load(
                             reinterpret_cast<unsigned long long *>(&a.psum[row_r * a.P + i]),
                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        };
+
+        // partial tallies of batch k (its LDS sums are complete): sc1 store of the dosage sum, drained,
+        // then the arrival.  This is the fence-free hand-off MI355X_MICROARCH.md lists as measured
+        // valid on gfx950 (one lane signals for its own 8-byte sc1 store; the consumer's polling wave
+        // loads the bytes with sc1 loads after its poll matched); an agent-scope release/acquire pair
+        // instead costs 1.7-6.5 us per phase (buffer_wbl2 / buffer_inv).
+        auto publish = [&](uint32_t k) {
+            double s = 0.0;
+            uint32_t cnt = 0;
+            const uint64_t row = batch_row0(k) + lane;
+            const bool valid = lane < R && k < n_local && row < a.n_rows;
+            if (lane < R) {
+                const int par = k & 1;
+#pragma unroll
+                for (int w = 1; w < 16; ++w) {  // fixed order
+                    s += lds.wsum[par][lane][w];
+                    cnt += lds.wcnt[par][lane][w];
                 }
-                const double tot = uniform_f64(wave_tree_sum(v));
+                if (valid)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.psum[row * a.P + slice]),
+                                       (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also lands every load issued before
+            if (valid)
+                __hip_atomic_fetch_add(&a.tally[row], (1ull << 56) | (unsigned long long)cnt,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        // row parameters of batch kt from its complete tally words and partial sums
+        auto params = [&](uint32_t kt, const Polled &q, double(&v)[R]) {
+            double mysum = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double tot = uniform_f64(wave_tree_sum(v[r]));
                 if (lane == r) mysum = tot;
             }
             int used = 0;
             if (lane < R) {
+                const uint64_t row = batch_row0(kt) + lane;
                 DsRowLds rp;
                 rp.beta = 0.0;
                 rp.imp = 0.0;
                 rp.mode = 0;
-                rp.flip = rflags == 1;  // bit 1 set: the row already counts the effect allele
-                if (valid && ok) {
-                    const bool rie = (rflags & 1) != 0;  // homref imputation value
-                    const uint64_t nmiss = x & ((1ull << 56) - 1);
+                rp.flip = q.rflags == 1;  // bit 1 set: the row already counts the effect allele
+                if (q.valid && q.ok) {
+                    const double beta = q.beta, eaf = q.eaf;
+                    const bool rie = (q.rflags & 1) != 0;  // homref imputation value
+                    const uint64_t nmiss = q.x & ((1ull << 56) - 1);
                     const uint64_t ngen = a.n_samples - nmiss;
                     const double neff = rp.flip ? 2.0 * (double)ngen - mysum : mysum;
                     const double nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -212,11 +240,10 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
                     if (missingrate > a.prm.max_missing_rate) {  // nim:565-571
                         reason = NPS_REASON_MAXMIS;
                         if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
-                            const double c = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
-                                             : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
-                                                                                   : nan;
-                            rp.imp = c;  // every sample gets the locus constant
-                            rp.mode = 2;
+                            rp.imp = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                                     : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                                           : nan;
+                            rp.mode = 2;  // every sample gets the locus constant
                             used = 1;
                         }
                     } else {  // nim:450-481
@@ -235,6 +262,7 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
                             break;
                         }
                     }
+                    if (rp.mode != 0) rp.beta = beta;  // a dropped row adds imp * beta = 0 * 0
                     if (slice == 0 && a.stats != nullptr) {
                         nps_locus_stat s;
                         s.ngenotyped = ngen;
@@ -245,23 +273,32 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
                         a.stats[row] = s;
                     }
                 }
-                if (rp.mode != 0) rp.beta = beta;  // a dropped row adds imp * beta = 0 * 0
                 lds.rowp[kt & 1][lane] = rp;
             }
             nloci_local += (uint32_t)__popcll(__ballot(used != 0));
         };
 
+        double v[R];
         __syncthreads();  // #0
         publish(0);
         __syncthreads();  // #1
         publish(1);
         __syncthreads();  // #2
         publish(2);
-        params(0);
+        Polled cur = poll_issue(0);
+        poll_finish(0, cur);
+        psum_issue(0, v);
+        params(0, cur, v);
+        cur = poll_issue(1);
+        poll_finish(1, cur);
         __syncthreads();  // #3
         for (uint32_t k = 0; k < n_steps; ++k) {
-            publish(k + 3);
-            params(k + 1);
+            psum_issue(k + 1, v);             // batch k+1: arrival word matched a phase ago
+            Polled nxt = poll_issue(k + 2);   // batch k+2: published by every slice a phase ago
+            publish(k + 3);                   // drains the loads above with its own store
+            poll_finish(k + 2, nxt);
+            params(k + 1, cur, v);
+            cur = nxt;
             __syncthreads();  // #(k+4)
         }
         if (slice == 0 && lane == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
@@ -281,23 +318,24 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
     for (int s = 0; s < kDsPerThread; ++s) acc[s] = 0.0;
     float ring[D][R * kDsPerThread];
 
-    auto load_batch = [&](uint32_t k, float(&dst)[R * kDsPerThread]) {
-        const uint64_t row0 = batch_row0(k);
-        const char *p = reinterpret_cast<const char *>(a.ds) + (k < n_local ? row0 : 0) * stride_bytes;
+    // row r of batch k -> dst[8r .. 8r+7]; rows past the end of the matrix read as zeros (range 0)
+    auto load_row = [&](uint32_t k, int r, float(&dst)[R * kDsPerThread]) {
+        const uint64_t row = batch_row0(k) + r;
+        const bool in = k < n_local && row < a.n_rows;
+        const char *p = reinterpret_cast<const char *>(a.ds) + (in ? row : 0) * stride_bytes;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, in ? row_bytes : 0u, 0x00020000);
+        const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+        const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool in = k < n_local && row0 + r < a.n_rows;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(p), 0, in ? row_bytes : 0u, 0x00020000);
-            const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-            const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                dst[r * 8 + s] = __uint_as_float(qa[s]);
-                dst[r * 8 + 4 + s] = __uint_as_float(qb[s]);
-            }
-            p += stride_bytes;
+        for (int s = 0; s < 4; ++s) {
+            dst[r * 8 + s] = __uint_as_float(qa[s]);
+            dst[r * 8 + 4 + s] = __uint_as_float(qb[s]);
         }
+    };
+    auto load_batch = [&](uint32_t k, float(&dst)[R * kDsPerThread]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) load_row(k, r, dst);
     };
 
     // partial tally of a batch: NaN count of the wave by ballot (SALU), dosage sum by a fixed tree
@@ -353,8 +391,9 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
 
     auto step = [&](uint32_t k, float(&r_cur)[R * kDsPerThread], const float(&r_tal)[R * kDsPerThread]) {
         accumulate(k, r_cur);
+        load_batch(k + 5, r_cur);  // in flight during the tally below and the next accumulation
+        __builtin_amdgcn_sched_barrier(0);
         tally(k + 4, r_tal);
-        load_batch(k + 5, r_cur);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // #(k+4)
     };
