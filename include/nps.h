@@ -175,6 +175,14 @@ int nps_finish(nps_ctx *ctx, double offset, double *scores_out, uint64_t *nloci_
 /* Same, but scores are written to a caller-allocated DEVICE buffer of n_samples doubles (e.g. a
  * torch tensor handed to an RCCL all-gather): no PCIe round trip. */
 int nps_finish_device(nps_ctx *ctx, double offset, double *d_scores_out, uint64_t *nloci_out);
+/* Row-sharded evaluation of ONE score over several GPUs (each holds a block of the score's rows
+ * and all samples, so tallies stay local and exact): the state of the reference's loop before its
+ * normalisation (nimpress.nim:639-641) -- d_sums_out[n_samples] = sum of dosage*beta over this
+ * context's rows, *nloci_out = its used rows -- is written to a DEVICE buffer for the one exchange of
+ * that layout, a sum all-reduce of both (RCCL).  nps_normalize_device then applies
+ * nimpress.nim:643-649 to the reduced sums in place: d[i] = d[i] / (2*nloci) + offset. */
+int nps_partial_device(nps_ctx *ctx, double *d_sums_out, uint64_t *nloci_out);
+int nps_normalize_device(nps_ctx *ctx, double *d_sums_inout, uint64_t nloci, double offset);
 int nps_reset(nps_ctx *ctx, const nps_params *params /* NULL = keep */);
 void nps_destroy(nps_ctx *ctx);
 

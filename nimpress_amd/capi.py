@@ -49,7 +49,7 @@ ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
 SYMBOLS = [
     "nps_abi_version", "nps_last_error", "nps_device_count", "nps_create", "nps_push_gt",
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
-    "nps_finish_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
+    "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
     "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
     "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_destroy",
@@ -87,6 +87,8 @@ def load():
     L.nps_flush.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.nps_finish.argtypes = [vp, dbl, vp, C.POINTER(u64)]
     L.nps_finish_device.argtypes = [vp, dbl, vp, C.POINTER(u64)]
+    L.nps_partial_device.argtypes = [vp, vp, C.POINTER(u64)]
+    L.nps_normalize_device.argtypes = [vp, vp, u64, dbl]
     L.nps_scoredef_create.argtypes = [C.POINTER(vp), i32, vp, u64]
     L.nps_scoredef_n_present.argtypes = [vp]
     L.nps_scoredef_n_present.restype = u64
@@ -252,6 +254,16 @@ class Scorer:
         _check(load().nps_finish_device(self._h, float(offset), C.c_void_p(d_scores_ptr),
                                         C.byref(nloci)))
         return int(nloci.value)
+
+    def partial_device(self, d_sums_ptr: int) -> int:
+        """un-normalised sums of this context's rows -> device buffer; returns its nloci."""
+        nloci = C.c_uint64(0)
+        _check(load().nps_partial_device(self._h, C.c_void_p(d_sums_ptr), C.byref(nloci)))
+        return int(nloci.value)
+
+    def normalize_device(self, d_sums_ptr: int, nloci: int, offset: float):
+        """in place: d[i] = d[i] / (2 nloci) + offset (nimpress.nim:643-649)."""
+        _check(load().nps_normalize_device(self._h, C.c_void_p(d_sums_ptr), int(nloci), float(offset)))
 
     def flush(self, max_rows: Optional[int] = None) -> np.ndarray:
         """Completes pushed rows; returns their stats (structured array, push order)."""

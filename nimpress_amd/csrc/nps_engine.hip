@@ -735,7 +735,8 @@ static int check_timeout(nps_ctx *c) {
     return NPS_OK;
 }
 
-static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nloci_out) {
+static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nloci_out,
+                         bool normalise = true) {
     int rc = run_batch(c);
     if (rc) return rc;
     unsigned long long dev_nloci = 0;
@@ -746,10 +747,11 @@ static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nlo
     const uint64_t nloci = c->host_nloci + dev_nloci;
     if (nloci_out) *nloci_out = nloci;
     if (c->n) {
-        const double denom = (double)nloci * 2.0;  // nimpress.nim:645
+        // x / 1.0 + 0.0 == x: the same kernel hands out the un-normalised sums
+        const double denom = normalise ? (double)nloci * 2.0 : 1.0;  // nimpress.nim:645
         ProfScope ps(c, P_REDUCE);
         HIP_TRY(launch_finish(c->stream, c->d_part, c->n_chunks, c->geom.part_chunk_stride, c->n,
-                              c->const_sum, denom, offset, d_dst));
+                              c->const_sum, denom, normalise ? offset : 0.0, d_dst));
     }
     return NPS_OK;
 }
@@ -774,6 +776,29 @@ extern "C" int nps_finish_device(nps_ctx *c, double offset, double *d_scores_out
     HIP_TRY(hipSetDevice(c->device));
     int rc = finish_common(c, offset, d_scores_out, nloci_out);
     if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NPS_OK;
+}
+
+extern "C" int nps_partial_device(nps_ctx *c, double *d_sums_out, uint64_t *nloci_out) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !d_sums_out) return fail(NPS_E_INVAL, "d_sums_out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = finish_common(c, 0.0, d_sums_out, nloci_out, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NPS_OK;
+}
+
+extern "C" int nps_normalize_device(nps_ctx *c, double *d_sums, uint64_t nloci, double offset) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !d_sums) return fail(NPS_E_INVAL, "d_sums_inout is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n) {
+        // one "chunk" = the reduced sums themselves, in place (every thread reads and writes its own i)
+        ProfScope ps(c, P_REDUCE);
+        HIP_TRY(launch_finish(c->stream, d_sums, 1, c->n, c->n, 0.0, (double)nloci * 2.0, offset, d_sums));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NPS_OK;
 }

@@ -390,11 +390,11 @@ hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finish_kernel(const double *__restrict__ part,
-                                                     uint32_t n_chunks, uint64_t part_chunk_stride,
-                                                     uint64_t n_samples, double const_sum,
-                                                     double denom, double offset,
-                                                     double *__restrict__ scores) {
+// (no __restrict__: nps_normalize_device runs it in place, every thread on its own element)
+__global__ __launch_bounds__(256) void finish_kernel(const double *part, uint32_t n_chunks,
+                                                     uint64_t part_chunk_stride, uint64_t n_samples,
+                                                     double const_sum, double denom, double offset,
+                                                     double *scores) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_samples) return;
     double s = 0.0;

@@ -1,4 +1,6 @@
-"""Multi-GPU evaluation: score definitions sharded over ranks, one RCCL all-gather at the end.
+"""Multi-GPU evaluation: score definitions sharded over ranks, one RCCL all-gather at the end
+(or, for ONE long score, its rows sharded over ranks and one RCCL all-reduce before the
+normalisation: shard_rows / all_reduce_partial).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 The path shards by score file (BASELINE.json north_star): every rank holds the cohort, evaluates
@@ -54,3 +56,26 @@ def evaluate_sharded(n_scores: int, n_samples: int,
     for j, i in enumerate(mine):
         score_fn(i, local[j])
     return gather_scores(local, n_scores, group)
+
+
+def shard_rows(n_rows: int, world: int, rank: int, align: int = 4) -> tuple:
+    """Contiguous block [r0, r1) of a score's rows for `rank` (second layout:
+    every GPU holds all samples of its rows, so tallies stay local and exact).  Block starts are
+    multiples of `align` (the resident 2-bit cohort stores rows in groups of 4)."""
+    per = (n_rows + world - 1) // world
+    per = (per + align - 1) // align * align
+    r0 = min(n_rows, rank * per)
+    r1 = min(n_rows, r0 + per)
+    return r0, r1
+
+
+def all_reduce_partial(sums: torch.Tensor, nloci: int, group=None):
+    """The one exchange of the row-sharded layout: sum all-reduce of the un-normalised score sums
+    (float64 [N], from nps_partial_device) and of nloci.  Returns (sums, nloci_total); the caller
+    normalises with nps_normalize_device (sums / (2 nloci) + offset, nimpress.nim:643-649)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return sums, int(nloci)
+    cnt = torch.tensor([int(nloci)], dtype=torch.int64, device=sums.device)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return sums, int(cnt.item())

@@ -251,6 +251,13 @@ void ref_row_locus(ref_state *s, int status, int ref_is_effect, double beta, dou
         ref_accumulate(s, beta);
 }
 
+/* the un-normalised sums and nloci so far (state of the loop at :641); does not free the state.  Used to
+ * check the row-sharded multi-GPU path, whose exchange happens before the normalisation. */
+void ref_partial(const ref_state *s, double *sums_out, int64_t *nloci_out) {
+    if (sums_out) memcpy(sums_out, s->scores, sizeof(double) * s->n);
+    if (nloci_out) *nloci_out = s->nloci;
+}
+
 /* :643-649; copies out scores and nloci, frees the state */
 void ref_finish(ref_state *s, double offset, double *scores_out, int64_t *nloci_out) {
     for (size_t i = 0; i < s->n; ++i) s->scores[i] /= (double)s->nloci * 2.0;

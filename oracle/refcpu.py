@@ -89,6 +89,8 @@ def lib():
     L.ref_row_locus.restype = None
     L.ref_finish.argtypes = [C.c_void_p, C.c_double, dp, C.POINTER(C.c_int64)]
     L.ref_finish.restype = None
+    L.ref_partial.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
+    L.ref_partial.restype = None
     L.ref_score_packed.argtypes = [u32p, C.c_size_t, C.c_size_t, C.c_size_t, i32p, i32p, dp, dp,
                                    C.POINTER(RefParams), C.c_double, dp, C.c_void_p,
                                    C.POINTER(C.c_int64)]
@@ -170,6 +172,13 @@ class RefScorer:
         lib().ref_row_locus(self._s, status, int(ref_is_effect), float(beta), float(eaf),
                             C.byref(st))
         self._push_stat(st)
+
+    def partial(self) -> Tuple[np.ndarray, int]:
+        """un-normalised sums and nloci so far (the state is kept)"""
+        out = np.empty(max(self.n, 1), dtype=np.float64)
+        nloci = C.c_int64(0)
+        lib().ref_partial(self._s, _p(out, C.c_double), C.byref(nloci))
+        return out[: self.n], int(nloci.value)
 
     def finish(self, offset: float) -> Tuple[np.ndarray, int]:
         out = np.empty(max(self.n, 1), dtype=np.float64)

@@ -560,3 +560,38 @@ def test_ds_fused_all_imputation_modes(pk):
     assert nloci == ref_nloci
     assert_ds_stats(stats, ref_stats)
     assert rel_err(scores, ref_scores, sub["beta"], max(nloci, 1)) <= REL_TOL
+
+
+def test_row_sharded_partial_sums_and_normalise():
+    """one score evaluated as two row blocks (what two GPUs would hold), un-normalised sums added and
+    normalised in place by the library == the unsharded evaluation"""
+    import torch
+    from nimpress_amd import multi
+    n, m = 20011, 203
+    rng = np.random.default_rng(77)
+    co = make_cohort(n, m, 31337, rng)
+    kw = PARAM_GRID[0]
+    dev = capi.Cohort(n, m)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
+    whole = capi.Scorer(n, capi.make_params(**kw))
+    whole.score_cohort(dev, descs)
+    ref_scores, ref_nloci = whole.finish(0.125)
+    whole.close()
+    total = torch.zeros(n, dtype=torch.float64, device="cuda")
+    nloci = 0
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for rank in range(2):
+        r0, r1 = multi.shard_rows(m, 2, rank)
+        sc.reset()
+        sc.score_cohort(dev, descs[r0:r1], r0)
+        part = torch.empty(n, dtype=torch.float64, device="cuda")
+        nloci += sc.partial_device(part.data_ptr())
+        total += part
+    torch.cuda.synchronize()
+    sc.normalize_device(total.data_ptr(), nloci, 0.125)
+    got = total.cpu().numpy()
+    sc.close()
+    dev.close()
+    assert nloci == ref_nloci
+    assert rel_err(got, ref_scores, co["beta"], max(nloci, 1)) <= 1e-12

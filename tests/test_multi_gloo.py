@@ -82,3 +82,52 @@ def test_shard_indices_cover_everything():
         for world in (1, 2, 4, 8):
             seen = sorted(i for r in range(world) for i in multi.shard_indices(n_scores, world, r))
             assert seen == list(range(n_scores))
+
+
+# ---- one score, rows sharded over ranks: all-reduce of the un-normalised sums ----
+def _row_worker(rank, world, port, n, m, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eaf, codes = _cohort(n, m, 11)
+        beta = np.round(np.random.default_rng(5).normal(0, 0.05, m), 4)
+        r0, r1 = multi.shard_rows(m, world, rank)
+        sc = refcpu.RefScorer(n, refcpu.make_params("ps", "homref", "int_ps", 0.05, 10))
+        for j in range(r0, r1):
+            sc.row_gt(refcpu.codes_to_gt(codes[j], n), 2, 1, False, beta[j], eaf[j])
+        sums, nloci = sc.partial()
+        sc.finish(0.0)
+        t, total = multi.all_reduce_partial(torch.from_numpy(sums.copy()), nloci)
+        ret[rank] = (t.numpy() / (2.0 * total) + 0.25, total)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m", [40, 3, 1])
+def test_row_sharded_all_reduce(m):
+    world, n = 2, 131
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_row_worker, args=(world, port, n, m, ret), nprocs=world, join=True)
+    eaf, codes = _cohort(n, m, 11)
+    beta = np.round(np.random.default_rng(5).normal(0, 0.05, m), 4)
+    ref, _, ref_nloci = refcpu.score_packed(codes, n, np.zeros(m, np.int32), np.zeros(m, np.int32), beta,
+                                            eaf, refcpu.make_params("ps", "homref", "int_ps", 0.05, 10),
+                                            0.25)
+    for r in range(world):
+        got, total = ret[r]
+        assert total == ref_nloci
+        # blocked summation order: a few ulps of the largest partial sum
+        assert np.allclose(got, ref, rtol=0, atol=1e-13 * max(1.0, np.abs(beta).sum()))
+
+
+def test_shard_rows_partition():
+    for n_rows in (0, 1, 3, 4, 5, 17, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            blocks = [multi.shard_rows(n_rows, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n_rows
+            for (a0, a1), (b0, b1) in zip(blocks, blocks[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(b[0] % 4 == 0 or b[0] == n_rows for b in blocks)
