@@ -149,6 +149,14 @@ int nps_create(nps_ctx **out, int device, uint64_t n_samples, const nps_params *
 int nps_push_gt(nps_ctx *ctx, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
                 double beta, double eaf);
 
+/* Same row, but `gt` is the typed GT vector exactly as a BCF2 record stores it (what htslib holds
+ * BEFORE bcf_get_genotypes widens it to int32): n_samples*ploidy elements of elem_bytes = 1, 2
+ * (or 4) bytes, same encoding; end-of-vector 0x81 / 0x8001 and the typed missing value 0x80 /
+ * 0x8000 are negative and therefore skipped exactly like 0x80000001 (sign extension on the
+ * device).  Moves 2 instead of 8 bytes per diploid genotype over PCIe. */
+int nps_push_gt_raw(nps_ctx *ctx, const void *gt, int elem_bytes, int ploidy, int eaidx,
+                    int ref_is_effect, double beta, double eaf);
+
 /* PRESENT row with FORMAT/DS (build-defined extension, the reference decodes GT only):
  * n_samples float32 ALT dosages, NaN = missing; ref_is_effect -> dosage = 2 - DS. */
 int nps_push_ds(nps_ctx *ctx, const float *ds, int ref_is_effect, double beta, double eaf);

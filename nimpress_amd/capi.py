@@ -49,7 +49,7 @@ ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
 SYMBOLS = [
     "nps_abi_version", "nps_last_error", "nps_device_count", "nps_create", "nps_push_gt",
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
-    "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
+    "nps_push_gt_raw", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
     "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
     "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_destroy",
@@ -81,6 +81,7 @@ def load():
     L.nps_device_count.restype = C.c_int
     L.nps_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams)]
     L.nps_push_gt.argtypes = [vp, vp, i32, i32, i32, dbl, dbl]
+    L.nps_push_gt_raw.argtypes = [vp, vp, i32, i32, i32, i32, dbl, dbl]
     L.nps_push_ds.argtypes = [vp, vp, i32, dbl, dbl]
     L.nps_push_packed.argtypes = [vp, vp, i32, dbl, dbl]
     L.nps_push_locus.argtypes = [vp, i32, i32, dbl, dbl]
@@ -220,6 +221,17 @@ class Scorer:
             raise ValueError("gts has %d values, expected %d" % (gts.size, self.n * ploidy))
         _check(load().nps_push_gt(self._h, gts.ctypes.data, ploidy, eaidx, int(bool(ref_is_effect)),
                                   float(beta), float(eaf)))
+
+    def push_gt_raw(self, gt: np.ndarray, ploidy: int, eaidx: int, ref_is_effect, beta: float,
+                    eaf: float):
+        """typed GT vector as a BCF record stores it: int8 / int16 / int32 array of n*ploidy values"""
+        gt = np.ascontiguousarray(gt)
+        if gt.dtype not in (np.int8, np.int16, np.int32):
+            raise ValueError("gt dtype must be int8, int16 or int32")
+        if gt.size != self.n * ploidy:
+            raise ValueError("gt has %d values, expected %d" % (gt.size, self.n * ploidy))
+        _check(load().nps_push_gt_raw(self._h, gt.ctypes.data, gt.dtype.itemsize, ploidy, eaidx,
+                                      int(bool(ref_is_effect)), float(beta), float(eaf)))
 
     def push_ds(self, ds: np.ndarray, ref_is_effect, beta: float, eaf: float):
         ds = np.ascontiguousarray(ds, dtype=np.float32)

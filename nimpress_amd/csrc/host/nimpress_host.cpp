@@ -385,6 +385,38 @@ struct BgzfFile {
         *csize = it->second.second;
         return true;
     }
+    // read n bytes starting at virtual offset *voff (advances it); false at EOF / on a short read
+    bool readBytes(uint64_t *voff, void *dst, size_t n) {
+        uint64_t coff = *voff >> 16;
+        uint32_t uoff = (uint32_t)(*voff & 0xffff);
+        char *out = (char *)dst;
+        while (n) {
+            const std::string *d;
+            uint32_t csize;
+            if (!block(coff, &d, &csize)) return false;
+            if (uoff >= d->size()) {
+                if (d->empty()) {  // EOF marker (or an empty block): only fine if more data follows
+                    const std::string *d2;
+                    uint32_t c2;
+                    if (!block(coff + csize, &d2, &c2)) return false;
+                }
+                coff += csize;
+                uoff = 0;
+                continue;
+            }
+            const size_t take = std::min(n, d->size() - uoff);
+            memcpy(out, d->data() + uoff, take);
+            out += take;
+            n -= take;
+            uoff += (uint32_t)take;
+            if (uoff >= d->size()) {
+                coff += csize;
+                uoff = 0;
+            }
+        }
+        *voff = (coff << 16) | uoff;
+        return true;
+    }
     // read one text line starting at virtual offset *voff (advances it); false at EOF
     bool readLine(uint64_t *voff, std::string &line) {
         line.clear();
@@ -510,6 +542,338 @@ struct TabixIndex {
     }
 };
 
+
+// ---- BCF2 (htslib's binary VCF): header dictionaries + record decoding ----------------------
+// Layout restated from the VCF/BCF specification (hts-specs VCFv4.3 section 6; the reference reads
+// BCF through htslib 1.10.2, Dockerfile:32).  Only what the path needs is decoded: CHROM, POS, ID,
+// alleles, FILTER and the FORMAT/GT vector, which is kept in the file's own width.
+struct BcfHeader {
+    std::vector<std::string> contigs;  // BCF_DT_CTG
+    std::vector<std::string> ids;      // BCF_DT_ID: FILTER/INFO/FORMAT ids, PASS = 0
+    std::vector<std::string> samples;
+
+    static bool attr(const std::string &line, const char *key, std::string &out) {
+        // value of key= inside <...>, honouring quotes
+        const size_t lt = line.find('<');
+        if (lt == std::string::npos) return false;
+        size_t i = lt + 1;
+        const std::string k = std::string(key) + "=";
+        while (i < line.size()) {
+            const size_t eq = line.find('=', i);
+            if (eq == std::string::npos) return false;
+            const std::string name = line.substr(i, eq - i);
+            size_t j = eq + 1;
+            std::string val;
+            if (j < line.size() && line[j] == '"') {
+                ++j;
+                while (j < line.size() && line[j] != '"') {
+                    if (line[j] == '\\' && j + 1 < line.size()) ++j;
+                    val += line[j++];
+                }
+                ++j;
+            } else {
+                while (j < line.size() && line[j] != ',' && line[j] != '>') val += line[j++];
+            }
+            if (name + "=" == k) {
+                out = val;
+                return true;
+            }
+            i = j + 1;  // past ',' or '>'
+        }
+        return false;
+    }
+
+    void parse(const std::string &text) {
+        std::vector<std::pair<long, std::string>> ctg, idl;  // (IDX or -1, name) in header order
+        std::unordered_map<std::string, size_t> seen;
+        idl.emplace_back(-1, "PASS");  // htslib always registers PASS first
+        seen["PASS"] = 0;
+        size_t a = 0;
+        while (a < text.size()) {
+            size_t b = text.find('\n', a);
+            if (b == std::string::npos) b = text.size();
+            std::string line = text.substr(a, b - a);
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\0')) line.pop_back();
+            a = b + 1;
+            if (line.compare(0, 6, "#CHROM") == 0) {
+                const std::vector<std::string> cols = splitChar(line, '\t');
+                for (size_t k = 9; k < cols.size(); ++k) samples.push_back(cols[k]);
+                continue;
+            }
+            const bool is_ctg = line.compare(0, 9, "##contig=") == 0;
+            const bool is_id = line.compare(0, 9, "##FILTER=") == 0 || line.compare(0, 7, "##INFO=") == 0 ||
+                               line.compare(0, 9, "##FORMAT=") == 0;
+            if (!is_ctg && !is_id) continue;
+            std::string id, idx;
+            if (!attr(line, "ID", id)) continue;
+            const long ix = attr(line, "IDX", idx) ? atol(idx.c_str()) : -1;
+            if (is_ctg) {
+                ctg.emplace_back(ix, id);
+            } else {
+                auto it = seen.find(id);
+                if (it == seen.end()) {
+                    seen[id] = idl.size();
+                    idl.emplace_back(ix, id);
+                } else if (ix >= 0) {
+                    idl[it->second].first = ix;
+                }
+            }
+        }
+        auto place = [](const std::vector<std::pair<long, std::string>> &src, std::vector<std::string> &dst) {
+            size_t next = 0;
+            for (const auto &e : src) {
+                const size_t at = e.first >= 0 ? (size_t)e.first : next;
+                if (dst.size() <= at) dst.resize(at + 1);
+                dst[at] = e.second;
+                next = at + 1;
+            }
+        };
+        place(ctg, contigs);
+        place(idl, ids);
+    }
+};
+
+struct BcfCursor {
+    const unsigned char *p, *end;
+    void need(size_t n) const {
+        if ((size_t)(end - p) < n) throw std::runtime_error("truncated BCF record");
+    }
+    uint8_t u8() {
+        need(1);
+        return *p++;
+    }
+    int32_t intOf(int type) {  // one value of an integer type, sign extended
+        switch (type) {
+        case 1: {
+            need(1);
+            const int8_t v = (int8_t)*p;
+            p += 1;
+            return v;
+        }
+        case 2: {
+            need(2);
+            int16_t v;
+            memcpy(&v, p, 2);
+            p += 2;
+            return v;
+        }
+        case 3: {
+            need(4);
+            int32_t v;
+            memcpy(&v, p, 4);
+            p += 4;
+            return v;
+        }
+        default: throw std::runtime_error("BCF: integer expected");
+        }
+    }
+    // typed-value descriptor: element type and count
+    void desc(int &type, int64_t &len) {
+        const uint8_t b = u8();
+        type = b & 0xf;
+        len = b >> 4;
+        if (len == 15) {
+            int t2;
+            int64_t l2;
+            desc(t2, l2);
+            if (l2 != 1) throw std::runtime_error("BCF: bad length descriptor");
+            len = intOf(t2);
+            if (len < 0) throw std::runtime_error("BCF: negative length");
+        }
+    }
+    static size_t sizeOf(int type) {
+        switch (type) {
+        case 0: return 0;
+        case 1: case 7: return 1;
+        case 2: return 2;
+        case 3: case 5: return 4;
+        default: throw std::runtime_error("BCF: unknown value type");
+        }
+    }
+    std::string str() {
+        int type;
+        int64_t len;
+        desc(type, len);
+        if (type == 0) return std::string();
+        if (type != 7) throw std::runtime_error("BCF: string expected");
+        need((size_t)len);
+        std::string s((const char *)p, (size_t)len);
+        p += len;
+        const size_t z = s.find('\0');
+        if (z != std::string::npos) s.resize(z);
+        return s;
+    }
+    int32_t typedInt() {
+        int type;
+        int64_t len;
+        desc(type, len);
+        if (len != 1) throw std::runtime_error("BCF: scalar integer expected");
+        return intOf(type);
+    }
+};
+
+// one record (shared + indiv blocks, without the two length words) -> Variant; returns false when
+// `wanted` is given and the record overlaps none of its regions (nothing else is decoded then)
+static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const unsigned char *indiv,
+                           size_t l_indiv, const BcfHeader &h, const RegionMap *wanted, Variant &v) {
+    BcfCursor c{shared, shared + l_shared};
+    c.need(24);
+    int32_t chrom, pos0, rlen;
+    uint32_t nai, nfs;
+    memcpy(&chrom, c.p, 4);
+    memcpy(&pos0, c.p + 4, 4);
+    memcpy(&rlen, c.p + 8, 4);
+    memcpy(&nai, c.p + 16, 4);
+    memcpy(&nfs, c.p + 20, 4);
+    c.p += 24;
+    const uint32_t n_allele = nai >> 16, n_fmt = nfs >> 24, n_sample = nfs & 0xffffff;
+    if (chrom < 0 || (size_t)chrom >= h.contigs.size()) throw std::runtime_error("BCF: CHROM out of range");
+    v = Variant();
+    v.contig = h.contigs[(size_t)chrom];
+    v.pos = (int64_t)pos0 + 1;
+    if (wanted) {  // by the record's own span (POS .. POS + rlen - 1), before anything is copied
+        bool want = false;
+        auto it = wanted->find(v.contig);
+        if (it != wanted->end()) {
+            const int64_t rend = v.pos + std::max<int64_t>(rlen, 1) - 1;
+            for (const auto &w : it->second)
+                if (v.pos <= w.second && rend >= w.first) {
+                    want = true;
+                    break;
+                }
+        }
+        if (!want) return false;
+    }
+    v.id = c.str();
+    if (v.id.empty()) v.id = ".";
+    for (uint32_t k = 0; k < n_allele; ++k) {
+        std::string al = c.str();
+        if (k == 0)
+            v.ref = al;
+        else
+            v.alt.push_back(al);
+    }
+    {  // FILTER: vector of dictionary indices; empty = "."
+        int type;
+        int64_t len;
+        c.desc(type, len);
+        if (type == 0 || len == 0) {
+            v.filter = ".";
+        } else {
+            for (int64_t k = 0; k < len; ++k) {
+                const int32_t ix = c.intOf(type);
+                if (ix < 0 || (size_t)ix >= h.ids.size()) throw std::runtime_error("BCF: FILTER id out of range");
+                if (k) v.filter += ';';
+                v.filter += h.ids[(size_t)ix];
+            }
+        }
+    }
+    // INFO is not needed; FORMAT fields
+    v.has_gt = false;
+    v.gts.clear();
+    if (n_sample != h.samples.size()) throw std::runtime_error("BCF: record sample count differs from the header");
+    BcfCursor f{indiv, indiv + l_indiv};
+    for (uint32_t k = 0; k < n_fmt; ++k) {
+        const int32_t key = f.typedInt();
+        int type;
+        int64_t len;
+        f.desc(type, len);
+        const size_t bytes = BcfCursor::sizeOf(type) * (size_t)len * n_sample;
+        f.need(bytes);
+        if (key >= 0 && (size_t)key < h.ids.size() && h.ids[(size_t)key] == "GT") {
+            if (type < 1 || type > 3) throw std::runtime_error("BCF: FORMAT/GT is not an integer vector");
+            if (len > 8) throw std::runtime_error("ploidy above 8 is not supported");
+            v.ploidy = (int)len;
+            v.gt_bytes = type == 1 ? 1 : (type == 2 ? 2 : 4);
+            v.gt_raw.assign(f.p, f.p + bytes);
+            v.has_gt = true;
+        }
+        f.p += bytes;
+    }
+    if (n_sample && !v.has_gt)
+        throw std::runtime_error("BCF record without FORMAT/GT at " + v.contig + ":" + std::to_string(v.pos));
+    return true;
+}
+
+// CSI index (htslib's generalisation of tabix; what `bcftools index` writes for BCF)
+struct CsiIndex {
+    int32_t min_shift = 14, depth = 5;
+    std::vector<std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> refs;
+
+    bool load(const std::string &path) {
+        std::string raw, t;
+        if (!readFile(path, raw) || !inflateAll(raw, t)) return false;
+        if (t.size() < 16 || memcmp(t.data(), "CSI\1", 4) != 0) return false;
+        size_t o = 4;
+        auto i32 = [&]() {
+            int32_t v;
+            if (o + 4 > t.size()) throw std::runtime_error("truncated .csi");
+            memcpy(&v, t.data() + o, 4);
+            o += 4;
+            return v;
+        };
+        auto u64 = [&]() {
+            uint64_t v;
+            if (o + 8 > t.size()) throw std::runtime_error("truncated .csi");
+            memcpy(&v, t.data() + o, 8);
+            o += 8;
+            return v;
+        };
+        min_shift = i32();
+        depth = i32();
+        const int32_t l_aux = i32();
+        if (l_aux < 0 || o + (size_t)l_aux > t.size()) throw std::runtime_error("truncated .csi");
+        o += (size_t)l_aux;
+        const int32_t n_ref = i32();
+        refs.resize((size_t)std::max(n_ref, 0));
+        for (int32_t r = 0; r < n_ref; ++r) {
+            const int32_t n_bin = i32();
+            for (int32_t b = 0; b < n_bin; ++b) {
+                const uint32_t bin = (uint32_t)i32();
+                (void)u64();  // loffset
+                const int32_t n_chunk = i32();
+                auto &v = refs[(size_t)r][bin];
+                for (int32_t k = 0; k < n_chunk; ++k) {
+                    const uint64_t beg = u64(), end = u64();
+                    v.emplace_back(beg, end);
+                }
+            }
+        }
+        return true;
+    }
+
+    std::vector<std::pair<uint64_t, uint64_t>> query(size_t ref, int64_t beg0, int64_t end0) const {
+        std::vector<std::pair<uint64_t, uint64_t>> out;
+        if (ref >= refs.size()) return out;
+        if (beg0 < 0) beg0 = 0;
+        if (end0 <= beg0) end0 = beg0 + 1;
+        const int64_t e = end0 - 1;
+        int s = min_shift + depth * 3;
+        uint64_t t = 0;
+        for (int l = 0; l <= depth; ++l) {
+            const uint64_t b0 = t + (uint64_t)(beg0 >> s), b1 = t + (uint64_t)(e >> s);
+            for (uint64_t b = b0; b <= b1; ++b) {
+                auto bi = refs[ref].find((uint32_t)b);
+                if (bi == refs[ref].end()) continue;
+                for (const auto &c : bi->second) out.push_back(c);
+            }
+            t += 1ull << (l * 3);
+            s -= 3;
+        }
+        std::sort(out.begin(), out.end());
+        return out;
+    }
+};
+
+static void bcfReadHeader(const unsigned char *p, size_t n, BcfHeader &h, size_t *body) {
+    if (n < 9 || memcmp(p, "BCF\2", 4) != 0) throw std::runtime_error("not a BCF2 file");
+    uint32_t l_text;
+    memcpy(&l_text, p + 5, 4);
+    if (9 + (size_t)l_text > n) throw std::runtime_error("truncated BCF header");
+    h.parse(std::string((const char *)p + 9, l_text));
+    *body = 9 + (size_t)l_text;
+}
+
 }  // namespace
 
 // open(): text VCF, plain or gzip/BGZF.  With `keep` and a tabix index next to a BGZF file
@@ -524,7 +888,54 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
         for (const ScoreEntry &e : *keep) wanted[e.contig].emplace_back(e.pos, e.stop());
     std::vector<int32_t> tmp;
 
-    if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // indexed access
+    if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // BCF + CSI
+        CsiIndex csi;
+        BgzfFile bg;
+        if (bg.open(path)) {
+            uint64_t voff = 0;
+            unsigned char magic[9];
+            if (bg.readBytes(&voff, magic, 9) && memcmp(magic, "BCF\2", 4) == 0 && csi.load(path + ".csi")) {
+                uint32_t l_text;
+                memcpy(&l_text, magic + 5, 4);
+                std::string text(l_text, '\0');
+                if (!bg.readBytes(&voff, &text[0], l_text)) throw std::runtime_error("truncated BCF header");
+                BcfHeader h;
+                h.parse(text);
+                samples = h.samples;
+                std::unordered_map<std::string, size_t> ctg;
+                for (size_t k = 0; k < h.contigs.size(); ++k) ctg[h.contigs[k]] = k;
+                std::map<uint64_t, Variant> found;  // by virtual offset: file order
+                std::vector<unsigned char> buf;
+                for (const ScoreEntry &e : *keep) {
+                    auto ci = ctg.find(e.contig);
+                    if (ci == ctg.end()) continue;
+                    for (const auto &chunk : csi.query(ci->second, e.pos - 1, e.stop())) {
+                        uint64_t v = chunk.first;
+                        while (v < chunk.second) {
+                            const uint64_t at = v;
+                            uint32_t ls[2];
+                            if (!bg.readBytes(&v, ls, 8)) break;
+                            buf.resize((size_t)ls[0] + ls[1]);
+                            if (!bg.readBytes(&v, buf.data(), buf.size())) throw std::runtime_error("truncated BCF record");
+                            if (found.count(at) || ls[0] < 24) continue;
+                            int32_t chrom, pos0;
+                            memcpy(&chrom, buf.data(), 4);
+                            memcpy(&pos0, buf.data() + 4, 4);
+                            if ((size_t)chrom != ci->second) continue;
+                            if ((int64_t)pos0 + 1 > e.stop()) break;  // position sorted inside a contig
+                            Variant var;
+                            if (parseBcfRecord(buf.data(), ls[0], buf.data() + ls[0], ls[1], h, &wanted, var))
+                                found.emplace(at, std::move(var));
+                        }
+                    }
+                }
+                for (auto &kv : found) records.push_back(std::move(kv.second));
+                indexed = true;
+                return true;
+            }
+        }
+    }
+    if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // vcf.gz + tabix
         TabixIndex tbi;
         BgzfFile bg;
         if (tbi.load(path + ".tbi") && bg.open(path)) {
@@ -582,8 +993,24 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
     } else {
         text.swap(raw);
     }
-    if (text.compare(0, 3, "BCF") == 0)
-        throw std::runtime_error("BCF input is not supported by this reader yet (use VCF text / vcf.gz)");
+    if (text.size() >= 5 && text.compare(0, 3, "BCF") == 0) {  // whole-file scan of a BCF
+        BcfHeader h;
+        size_t o = 0;
+        const unsigned char *base = (const unsigned char *)text.data();
+        bcfReadHeader(base, text.size(), h, &o);
+        samples = h.samples;
+        while (o + 8 <= text.size()) {
+            uint32_t ls[2];
+            memcpy(ls, base + o, 8);
+            o += 8;
+            if (o + (size_t)ls[0] + ls[1] > text.size()) throw std::runtime_error("truncated BCF record");
+            Variant v;
+            if (parseBcfRecord(base + o, ls[0], base + o + ls[0], ls[1], h, keep ? &wanted : nullptr, v))
+                records.push_back(std::move(v));
+            o += (size_t)ls[0] + ls[1];
+        }
+        return true;
+    }
     bool have_header = false;
     size_t a = 0;
     const size_t n = text.size();
@@ -611,6 +1038,28 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
         a = b + 1;
     }
     return have_header;
+}
+
+// element i as bcf_get_genotypes hands it out: int8 / int16 end-of-vector and missing become their
+// int32 counterparts, everything else is sign extended (htslib vcf.c, bcf_get_format_values)
+int32_t Variant::gtValue(size_t i) const {
+    if (gt_raw.empty()) return gts[i];
+    switch (gt_bytes) {
+    case 1: {
+        const int8_t x = (int8_t)gt_raw[i];
+        return x == (int8_t)0x81 ? (int32_t)0x80000001u : x == (int8_t)0x80 ? (int32_t)0x80000000u : x;
+    }
+    case 2: {
+        int16_t x;
+        memcpy(&x, &gt_raw[2 * i], 2);
+        return x == (int16_t)0x8001 ? (int32_t)0x80000001u : x == (int16_t)0x8000 ? (int32_t)0x80000000u : x;
+    }
+    default: {
+        int32_t x;
+        memcpy(&x, &gt_raw[4 * i], 4);
+        return x;
+    }
+    }
 }
 
 const Variant *findVariant(const std::string &contig, int64_t pos, const std::string &refseq,
@@ -814,8 +1263,13 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                                 break;
                             }
                     }
-                    npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
-                             "nps_push_gt");
+                    if (v->gt_bytes == 4 && v->gt_raw.empty())
+                        npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
+                                 "nps_push_gt");
+                    else  // the BCF record's own int8 / int16 vector: widened on the device
+                        npsCheck(nps_push_gt_raw(ctx, v->gtData(), v->gt_bytes, v->ploidy, eaidx, rie,
+                                                 e.beta, e.eaf),
+                                 "nps_push_gt_raw");
                 }
             }
             pushed.push_back(std::move(rec));
@@ -977,7 +1431,8 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
         strncpy(filter, v->filter.c_str(), (size_t)filter_cap - 1);
         filter[filter_cap - 1] = 0;
     }
-    for (size_t i = 0; i < v->gts.size() && (long)i < gts_cap; ++i) gts[i] = v->gts[i];
+    const size_t nval = v->gt_raw.empty() ? v->gts.size() : v->gt_raw.size() / (size_t)v->gt_bytes;
+    for (size_t i = 0; i < nval && (long)i < gts_cap; ++i) gts[i] = v->gtValue(i);
     return (long)(v - vcf.records.data());
 }
 

@@ -62,15 +62,24 @@ struct Variant {
     std::vector<std::string> alt;
     std::string filter;  // as written in the file ("." / "PASS" / "a;b")
     int ploidy = 2;
+    // GT as read: text VCF -> int32 in `gts` (gt_bytes = 4); BCF -> the record's typed vector as it
+    // stands in the file (int8 / int16 / int32, gt_bytes = 1 / 2 / 4) in `gt_raw`, never widened on
+    // the host (libnps decodes it on the device: nps_push_gt_raw)
+    int gt_bytes = 4;
     std::vector<int32_t> gts;
+    std::vector<uint8_t> gt_raw;
+    bool has_gt = true;
+    const void *gtData() const { return gt_raw.empty() ? (const void *)gts.data() : (const void *)gt_raw.data(); }
+    int32_t gtValue(size_t i) const;  // element i widened like bcf_get_genotypes does
 };
 
 struct VCF {
     std::vector<std::string> samples;
     std::vector<Variant> records;  // file order
-    bool indexed = false;          // records were fetched through the tabix index
-    // open(): reads the whole file (text VCF, plain or gzip/BGZF; CRLF tolerant).  If `keep` is
-    // non-null only records overlapping one of its loci are retained (memory = loci x samples).
+    bool indexed = false;          // records were fetched through the tabix / CSI index
+    // open(): text VCF (plain or gzip/BGZF; CRLF tolerant) or BCF2 (BGZF).  If `keep` is non-null
+    // only records overlapping one of its loci are retained (memory = loci x samples); with an index
+    // next to the file (.tbi for vcf.gz, .csi for BCF) only the chunks of those loci are inflated.
     bool open(const std::string &path, const std::vector<ScoreEntry> *keep = nullptr);
     int64_t n_samples() const { return (int64_t)samples.size(); }
 };

@@ -184,15 +184,16 @@ __global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restr
 
 // FORMAT/GT with ploidy > 2 (dosage can exceed 2, nimpress.nim:385-390): decoded to a float dosage
 // row on the device and scored through the DS path.  Same allele rules as decode_gt_kernel.
-__global__ __launch_bounds__(256) void decode_gt_to_ds_kernel(const int32_t *__restrict__ gts,
-                                                              uint64_t n, int ploidy, int eaidx,
+template <typename T>
+__global__ __launch_bounds__(256) void decode_gt_to_ds_kernel(const T *__restrict__ gts, uint64_t n,
+                                                              int ploidy, int eaidx,
                                                               float *__restrict__ out) {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     int cnt = 0;
     bool miss = false;
     for (int k = 0; k < ploidy; ++k) {
-        const int32_t a = gts[s * (uint64_t)ploidy + k];
+        const int32_t a = (int32_t)gts[s * (uint64_t)ploidy + k];
         if (a >= 0) {
             if (a < 2)
                 miss = true;
@@ -203,12 +204,26 @@ __global__ __launch_bounds__(256) void decode_gt_to_ds_kernel(const int32_t *__r
     out[s] = miss ? __int_as_float(0x7fc00000) : (float)cnt;
 }
 
-hipError_t launch_decode_gt_to_ds(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy,
-                                  int eaidx, float *d_out) {
+hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n,
+                                  int ploidy, int eaidx, float *d_out) {
     if (n == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(decode_gt_to_ds_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
-                       d_gts, n, ploidy, eaidx, d_out);
+    const dim3 grid((uint32_t)((n + 255) / 256)), block(256);
+    switch (elem_bytes) {
+    case 1:
+        hipLaunchKernelGGL(decode_gt_to_ds_kernel<int8_t>, grid, block, 0, st, (const int8_t *)d_gts, n,
+                           ploidy, eaidx, d_out);
+        break;
+    case 2:
+        hipLaunchKernelGGL(decode_gt_to_ds_kernel<int16_t>, grid, block, 0, st, (const int16_t *)d_gts,
+                           n, ploidy, eaidx, d_out);
+        break;
+    case 4:
+        hipLaunchKernelGGL(decode_gt_to_ds_kernel<int32_t>, grid, block, 0, st, (const int32_t *)d_gts,
+                           n, ploidy, eaidx, d_out);
+        break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -526,8 +526,8 @@ static int ensure_ds(nps_ctx *c);
 // ploidy > 2: the dosage can exceed 2, which the 2-bit codes cannot hold (nimpress is documented as
 // diploid-specific, README.md:158, but its loop counts any number of alleles, nim:385-390).  The
 // record is decoded on the device into a float dosage row and scored through the DS path.
-static int push_gt_polyploid(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
-                             double beta, double eaf) {
+static int push_gt_polyploid(nps_ctx *c, const void *gts, int elem_bytes, int ploidy, int eaidx,
+                             int ref_is_effect, double beta, double eaf) {
     int rc = ensure_ds(c);
     if (rc) return rc;
     if (c->ds_rows == c->ds_cap) {
@@ -543,7 +543,7 @@ static int push_gt_polyploid(nps_ctx *c, const int32_t *gts, int ploidy, int eai
     // the 2 - DS transform, bit 0 still selects the homref imputation value (nim:435-438)
     d.ref_is_effect = (ref_is_effect ? 1 : 0) | 2;
     if (c->n) {
-        const size_t bytes = sizeof(int32_t) * (size_t)ploidy * c->n;
+        const size_t bytes = (size_t)elem_bytes * (size_t)ploidy * c->n;
         if (bytes > c->poly_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             (void)hipFree(c->d_poly);
@@ -555,7 +555,7 @@ static int push_gt_polyploid(nps_ctx *c, const int32_t *gts, int ploidy, int eai
         HIP_TRY(hipMemcpyAsync(c->d_poly, gts, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // pageable source: the caller may reuse it on return
         ProfScope ps(c, P_DECODE);
-        HIP_TRY(launch_decode_gt_to_ds(c->stream, c->d_poly, c->n, ploidy, eaidx,
+        HIP_TRY(launch_decode_gt_to_ds(c->stream, c->d_poly, elem_bytes, c->n, ploidy, eaidx,
                                        c->d_ds + (uint64_t)slot * c->ds_stride_f));
     }
     PendingRow p;
@@ -567,15 +567,18 @@ static int push_gt_polyploid(nps_ctx *c, const int32_t *gts, int ploidy, int eai
     return NPS_OK;
 }
 
-extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
-                           double beta, double eaf) {
+static int push_gt_typed(nps_ctx *c, const void *gts, int elem_bytes, int ploidy, int eaidx,
+                         int ref_is_effect, double beta, double eaf) {
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
     if (c->n && !gts) return fail(NPS_E_INVAL, "gts is NULL");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
+        return fail(NPS_E_INVAL, "elem_bytes %d (1, 2 or 4)", elem_bytes);
     if (ploidy < 1) return fail(NPS_E_INVAL, "ploidy %d < 1", ploidy);
     if (ploidy > 8) return fail(NPS_E_UNSUPPORTED, "ploidy %d > 8", ploidy);
     if (eaidx < 0) return fail(NPS_E_INVAL, "eaidx %d < 0 (nimpress.nim:380 doAssert)", eaidx);
     HIP_TRY(hipSetDevice(c->device));
-    if (ploidy > 2) return push_gt_polyploid(c, gts, ploidy, eaidx, ref_is_effect, beta, eaf);
+    if (ploidy > 2)
+        return push_gt_polyploid(c, gts, elem_bytes, ploidy, eaidx, ref_is_effect, beta, eaf);
     uint32_t slot;
     int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
     if (rc) return rc;
@@ -584,17 +587,27 @@ extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx
         const int k = c->raw_next;
         c->raw_next = (k + 1) % nps_ctx::kRawSlots;
         HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
-        const size_t bytes = sizeof(int32_t) * (size_t)ploidy * c->n;
+        const size_t bytes = (size_t)elem_bytes * (size_t)ploidy * c->n;
         memcpy(c->h_raw[k], gts, bytes);
         HIP_TRY(hipMemcpyAsync(c->d_raw, c->h_raw[k], bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
         ProfScope ps(c, P_DECODE);
-        HIP_TRY(launch_decode_gt(c->stream, c->d_raw, c->n, ploidy, eaidx,
+        HIP_TRY(launch_decode_gt(c->stream, c->d_raw, elem_bytes, c->n, ploidy, eaidx,
                                  c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4, slot & 3,
                                  c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;
+}
+
+extern "C" int nps_push_gt(nps_ctx *c, const int32_t *gts, int ploidy, int eaidx, int ref_is_effect,
+                           double beta, double eaf) {
+    return push_gt_typed(c, gts, 4, ploidy, eaidx, ref_is_effect, beta, eaf);
+}
+
+extern "C" int nps_push_gt_raw(nps_ctx *c, const void *gt, int elem_bytes, int ploidy, int eaidx,
+                               int ref_is_effect, double beta, double eaf) {
+    return push_gt_typed(c, gt, elem_bytes, ploidy, eaidx, ref_is_effect, beta, eaf);
 }
 
 extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effect, double beta,

@@ -33,10 +33,12 @@ struct DevParams {
     double min_cs;  // compared in double, nimpress.nim:471
 };
 
-// raw bcf_get_genotypes buffer (device copy) -> row `row_in_group` of the group at d_group (group
-// interleaved layout) + tally (atomic add into *tally)
-hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
-                            uint32_t *d_group, int row_in_group, unsigned long long *d_tally);
+// raw GT buffer (device copy; elem_bytes 4 = bcf_get_genotypes int32, 1 / 2 = the int8 / int16 vector
+// of a BCF record) -> row `row_in_group` of the group at d_group (group interleaved layout) + tally
+// (atomic add into *tally)
+hipError_t launch_decode_gt(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n, int ploidy,
+                            int eaidx, uint32_t *d_group, int row_in_group,
+                            unsigned long long *d_tally);
 
 // tally of rows [0,n_rows) of a group-interleaved matrix (d_codes = first group):
 // tally[row] = (nmiss<<32)|neff   (direct store)
@@ -127,8 +129,8 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
                            DevParams prm, unsigned long long *d_tally, double *d_psum,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout);
-hipError_t launch_decode_gt_to_ds(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy,
-                                  int eaidx, float *d_out);
+hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n,
+                                  int ploidy, int eaidx, float *d_out);
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
                            uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss);

@@ -60,8 +60,11 @@ static __device__ __forceinline__ void group_sum3(uint32_t &a, uint32_t &b, uint
 // hts-nim value(): a < 0 (vector-end pad) is skipped; a in {0,1} is the missing allele (value -1);
 // otherwise allele index (a>>1)-1.  Any missing allele makes the sample missing (NaN is sticky in
 // nimpress.nim:385-390).
-template <int PLOIDY>
-__global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restrict__ gts, uint64_t n,
+// T = int32 (bcf_get_genotypes layout) or the int8 / int16 vector as a BCF record stores it: the
+// end-of-vector pad and the typed missing value are negative in every width (0x81 / 0x8001 /
+// 0x80000001, 0x80 / 0x8000 / 0x80000000), so sign extension classifies them as the int32 path does.
+template <int PLOIDY, typename T>
+__global__ __launch_bounds__(256) void decode_gt_kernel(const T *__restrict__ gts, uint64_t n,
                                                         int eaidx, uint32_t *__restrict__ out_group,
                                                         int row_in_group,
                                                         unsigned long long *__restrict__ tally) {
@@ -72,12 +75,13 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
     bool miss = false;
     if (s < n) {
         int32_t a[PLOIDY];
-        if (PLOIDY == 2) {
+        if (PLOIDY == 2 && sizeof(T) == 4) {
             const int2 v = reinterpret_cast<const int2 *>(gts)[s];
             a[0] = v.x;
             a[PLOIDY - 1] = v.y;
         } else {
-            a[0] = gts[s];
+#pragma unroll
+            for (int k = 0; k < PLOIDY; ++k) a[k] = (int32_t)gts[s * PLOIDY + k];
         }
 #pragma unroll
         for (int k = 0; k < PLOIDY; ++k) {
@@ -103,21 +107,33 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const int32_t *__restric
         atomicAdd(tally, ((unsigned long long)m << 32) | (unsigned long long)e);
 }
 
-hipError_t launch_decode_gt(hipStream_t st, const int32_t *d_gts, uint64_t n, int ploidy, int eaidx,
-                            uint32_t *d_group, int row_in_group, unsigned long long *d_tally) {
-    if (n == 0) return hipSuccess;
+template <typename T>
+static hipError_t launch_decode_gt_t(hipStream_t st, const T *d_gts, uint64_t n, int ploidy, int eaidx,
+                                     uint32_t *d_group, int row_in_group, unsigned long long *d_tally) {
     const uint64_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     if (ploidy == 2)
-        hipLaunchKernelGGL(decode_gt_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
+        hipLaunchKernelGGL((decode_gt_kernel<2, T>), dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
                            eaidx, d_group, row_in_group, d_tally);
     else if (ploidy == 1)
-        hipLaunchKernelGGL(decode_gt_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
+        hipLaunchKernelGGL((decode_gt_kernel<1, T>), dim3((uint32_t)blocks), dim3(256), 0, st, d_gts, n,
                            eaidx, d_group, row_in_group, d_tally);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+hipError_t launch_decode_gt(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n, int ploidy,
+                            int eaidx, uint32_t *d_group, int row_in_group,
+                            unsigned long long *d_tally) {
+    if (n == 0) return hipSuccess;
+    switch (elem_bytes) {
+    case 1: return launch_decode_gt_t(st, (const int8_t *)d_gts, n, ploidy, eaidx, d_group, row_in_group, d_tally);
+    case 2: return launch_decode_gt_t(st, (const int16_t *)d_gts, n, ploidy, eaidx, d_group, row_in_group, d_tally);
+    case 4: return launch_decode_gt_t(st, (const int32_t *)d_gts, n, ploidy, eaidx, d_group, row_in_group, d_tally);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

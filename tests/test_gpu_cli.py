@@ -64,3 +64,24 @@ def test_cli_defaults_and_warnings():
                                         "--imp-sample", "ps", "--afmisp", "1.0")
     assert np.allclose(vals, [0.081, 0.081, 0.081, 0.1545, 0.006, 0.006], atol=1e-4)
     assert sum("is not covered by the sequence coverage BED" in w for w in warns) == 3
+
+
+@pytest.mark.parametrize("gt_dtype", [np.int8, np.int16])
+def test_cli_on_bcf_equals_cli_on_vcf(tmp_path, gt_dtype):
+    """the fixture re-written as BCF2 (+CSI) by tests/bcfwriter.py: the typed GT vectors go to the
+    device as they stand in the file (nps_push_gt_raw); output text identical to the vcf.gz run"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bcfwriter
+    vcf = refcpu.read_vcf(os.path.join(G, "set1.vcf.gz"))
+    contigs, recs = bcfwriter.records_from_oracle_vcf(vcf)
+    path = str(tmp_path / "set1.bcf")
+    bcfwriter.write_bcf(path, contigs, vcf.samples, recs, gt_dtype=gt_dtype)
+    for flags in (["--imp-locus=ps"], ["--imp-locus=ignore", "--imp-missing=ignore", "--imp-sample=int_ps",
+                                      "--maxmis=1.0", "--mincs=0", "--ignorefilt"],
+                  ["--cov=" + os.path.join(G, "set1.bed"), "--imp-sample=ps", "--maxmis=1.0"]):
+        a = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), path], capture_output=True, text=True)
+        b = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), os.path.join(G, "set1.vcf.gz")],
+                           capture_output=True, text=True)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout

@@ -595,3 +595,40 @@ def test_row_sharded_partial_sums_and_normalise():
     dev.close()
     assert nloci == ref_nloci
     assert rel_err(got, ref_scores, co["beta"], max(nloci, 1)) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32])
+def test_push_gt_raw_typed_vectors(dtype):
+    """the typed GT vector of a BCF record (int8 / int16 with their own end-of-vector and missing
+    values) gives the same rows as the widened bcf_get_genotypes buffer"""
+    n = 1234
+    rng = np.random.default_rng(8)
+    kw = PARAM_GRID[0]
+    info = np.iinfo(dtype)
+    vend, vmiss = info.min + 1, info.min           # 0x81 / 0x8001 / 0x80000001 and 0x80 / ...
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    ref = refcpu.RefScorer(n, refcpu.make_params(**kw))
+    betas = []
+    for j, ploidy in enumerate([2, 2, 1, 3, 2]):
+        eaidx = int(rng.integers(0, 3))
+        alle = rng.integers(-1, 3, size=(n, ploidy))
+        typed = (((alle + 1) << 1) | rng.integers(0, 2, size=(n, ploidy))).astype(dtype)
+        wide = typed.astype(np.int32)
+        if ploidy >= 2:                             # haploid calls in a diploid record, typed missing
+            hap = rng.uniform(size=n) < 0.1
+            typed[hap, ploidy - 1] = vend
+            wide[hap, ploidy - 1] = -2147483647     # bcf_int32_vector_end
+            tm = rng.uniform(size=n) < 0.02
+            typed[tm, 0] = vmiss
+            wide[tm, 0] = -2147483648               # bcf_int32_missing
+        beta, eaf = float(rng.normal(0, 0.1)), float(rng.uniform(0.1, 0.5))
+        sc.push_gt_raw(typed.ravel(), ploidy, eaidx, eaidx == 0, beta, eaf)
+        ref.row_gt(wide.ravel(), ploidy, eaidx, eaidx == 0, beta, eaf)
+        betas.append(beta)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    ref_scores, ref_nloci = ref.finish(0.0)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, ref.stats)
+    assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL

@@ -363,3 +363,101 @@ def test_fast_binom_test_equals_enumeration(host):
             assert np.isnan(got), (x, n, p)
         else:
             assert got == ref or abs(got - ref) <= 1e-12 * max(abs(ref), 1e-300), (x, n, p, got, ref)
+
+
+# ---- BCF2 + CSI (fixtures written by tests/bcfwriter.py; no htslib here: parity unpinned) -------------
+@pytest.mark.parametrize("gt_dtype", [np.int8, np.int16, np.int32])
+def test_bcf_reader_matches_vcf_reader_on_set1(host, tmp_path, gt_dtype):
+    """the reference's own fixture re-written as BCF: same samples, records, FILTER strings, alleles
+    and (widened) GT values as the text reader gives; with the CSI index and by whole-file scan"""
+    import bcfwriter
+    vcf = refcpu.read_vcf(os.path.join(G, "set1.vcf.gz"))
+    contigs, recs = bcfwriter.records_from_oracle_vcf(vcf)
+    path = str(tmp_path / "set1.bcf")
+    bcfwriter.write_bcf(path, contigs, vcf.samples, recs, gt_dtype=gt_dtype)
+    score = refcpu.read_score_file(os.path.join(G, "set1.score"))
+    spath = os.path.join(G, "set1.score").encode()
+    for keep, no_index in ((None, False), (spath, False), (spath, True)):
+        if no_index:
+            os.environ["NIMPRESS_NO_INDEX"] = "1"
+        try:
+            hb = host.nh_vcf_open(path.encode(), keep)
+            ht = host.nh_vcf_open(os.path.join(G, "set1.vcf.gz").encode(), keep)
+            assert hb and ht, host.nh_last_error()
+            assert host.nh_vcf_indexed(hb) == (1 if keep and not no_index else 0)
+            n = host.nh_vcf_n_samples(hb)
+            assert [host.nh_vcf_sample(hb, i).decode() for i in range(n)] == vcf.samples
+            assert host.nh_vcf_n_records(hb) == host.nh_vcf_n_records(ht)
+            for e in score.entries:
+                out = []
+                for h in (hb, ht):
+                    rp, pl = C.c_long(), C.c_int()
+                    filt = C.create_string_buffer(64)
+                    gts = np.full(8 * n, 7, np.int32)
+                    idx = host.nh_vcf_find(h, e.contig.encode(), e.pos, e.refseq.encode(), e.easeq.encode(),
+                                           C.byref(rp), C.byref(pl), filt, 64, gts.ctypes.data, 8 * n)
+                    out.append((idx, rp.value, pl.value, filt.value, gts.tolist()) if idx >= 0 else (idx,))
+                assert out[0] == out[1], (e, out)
+            host.nh_vcf_close(hb)
+            host.nh_vcf_close(ht)
+        finally:
+            os.environ.pop("NIMPRESS_NO_INDEX", None)
+
+
+def test_bcf_random_access_multi_block(host, tmp_path):
+    """records larger than a BGZF block, three contigs, IDX= in the header, a long allele (length
+    descriptor 15), multi-filter records: CSI access == whole-file scan"""
+    import bcfwriter
+    rng = np.random.default_rng(21)
+    n = 40000                                   # 80 kB of int8 GT per record: spans BGZF blocks
+    samples = ["Q%d" % i for i in range(n)]
+    contigs = ["1", "2", "X"]
+    recs = []
+    for contig in contigs:
+        pos = 1000
+        for k in range(25):
+            pos += int(rng.integers(1, 90000))
+            ref = "A" if rng.uniform() < 0.7 else "ACGTACGTACGTACGTACGT"
+            g = ((rng.integers(-1, 3, size=(n, 2)) + 1) << 1) | rng.integers(0, 2, size=(n, 2))
+            g[rng.uniform(size=n) < 0.05, 1] = bcfwriter.INT32_END
+            recs.append(dict(contig=contig, pos=pos, id="rs%d" % k, ref=ref, alts=["G", "T"],
+                             filters=[[], ["PASS"], ["FAIL"], ["FAIL", "q10"]][k % 4], gts=g))
+    path = str(tmp_path / "big.bcf")
+    bcfwriter.write_bcf(path, contigs, samples, recs, gt_dtype=np.int8, filters=("PASS", "FAIL", "q10"),
+                        extra_header=['##INFO=<ID=DP,Number=1,Type=Integer,Description="d">'])
+    pick = rng.choice(len(recs), 20, replace=False)
+    lines = ["t", "", "", "x", "0.0"]
+    for k in pick:
+        r = recs[k]
+        lines.append("%s\t%d\t%s\tG\t0.1\t0.2" % (r["contig"], r["pos"], r["ref"]))
+    lines.append("2\t7\tA\tG\t0.1\t0.2")
+    score_path = str(tmp_path / "s.score")
+    open(score_path, "w").write("\n".join(lines))
+    results = []
+    for no_index in (False, True):
+        if no_index:
+            os.environ["NIMPRESS_NO_INDEX"] = "1"
+        try:
+            h = host.nh_vcf_open(path.encode(), score_path.encode())
+            assert h, host.nh_last_error()
+            assert host.nh_vcf_indexed(h) == (0 if no_index else 1)
+            got = []
+            gts = np.zeros(2 * n, np.int32)
+            for ln in lines[5:]:
+                c, pos, ref, ea, _, _ = ln.split("\t")
+                rp, pl = C.c_long(), C.c_int()
+                filt = C.create_string_buffer(64)
+                idx = host.nh_vcf_find(h, c.encode(), int(pos), ref.encode(), ea.encode(), C.byref(rp),
+                                       C.byref(pl), filt, 64, gts.ctypes.data, 2 * n)
+                got.append((idx >= 0, rp.value, filt.value, gts.copy()) if idx >= 0 else (False,))
+            results.append((host.nh_vcf_n_records(h), got))
+            host.nh_vcf_close(h)
+        finally:
+            os.environ.pop("NIMPRESS_NO_INDEX", None)
+    assert results[0][0] == results[1][0] == 20
+    for (a, b), k in zip(zip(results[0][1][:-1], results[1][1][:-1]), pick):
+        assert a[0] and b[0] and a[1] == b[1] == recs[k]["pos"]
+        exp_f = ";".join(recs[k]["filters"]) or "."
+        assert a[2].decode() == b[2].decode() == exp_f
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], recs[k]["gts"].ravel().astype(np.int32))
+    assert results[0][1][-1] == results[1][1][-1] == (False,)
