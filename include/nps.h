@@ -157,6 +157,14 @@ int nps_push_gt(nps_ctx *ctx, const int32_t *gts, int ploidy, int eaidx, int ref
 int nps_push_gt_raw(nps_ctx *ctx, const void *gt, int elem_bytes, int ploidy, int eaidx,
                     int ref_is_effect, double beta, double eaf);
 
+/* PRESENT row straight from a PLINK 1 .bed file (variant-major mode): ceil(n_samples/4) bytes, 4
+ * samples per byte, sample 0 in the low bits, values 0 = hom A1, 1 = missing, 2 = het, 3 = hom A2.
+ * effect_is_a1 selects the allele the score row counts (.bim column 5 or 6).  The row is already
+ * 2-bit and sample-minor: it is moved as it is and recoded on the device (build-defined extension;
+ * the reference reads VCF/BCF only). */
+int nps_push_bed(nps_ctx *ctx, const uint8_t *bed_row, int effect_is_a1, int ref_is_effect, double beta,
+                 double eaf);
+
 /* PRESENT row with FORMAT/DS (build-defined extension, the reference decodes GT only):
  * n_samples float32 ALT dosages, NaN = missing; ref_is_effect -> dosage = 2 - DS. */
 int nps_push_ds(nps_ctx *ctx, const float *ds, int ref_is_effect, double beta, double eaf);
@@ -212,6 +220,12 @@ int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *
                       size_t host_stride);
 int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t nrows, void *host_rows,
                         size_t host_stride);
+/* Rows of a PLINK 1 .bed file (variant-major; see nps_push_bed) -> rows [row0,row0+nrows) of a
+ * NPS_FMT_GT2 cohort; effect_is_a1[j] selects the counted allele of row j.  A .bed file is already
+ * 2-bit and sample-minor: bytes go over PCIe unchanged (pass the mmap'ed file + 3 header bytes,
+ * row_stride_bytes = ceil(n_samples/4)) and are recoded + interleaved on the device. */
+int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const uint8_t *bed_rows,
+                          size_t row_stride_bytes, const uint8_t *effect_is_a1);
 /* Fill rows on the device with the counter-based synthetic generator (DESIGN.md "Synthetic
  * cohorts"): per-row uint32 thresholds, code(seed,row,sample) reproducible on the CPU. */
 int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,

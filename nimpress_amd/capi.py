@@ -49,7 +49,7 @@ ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
 SYMBOLS = [
     "nps_abi_version", "nps_last_error", "nps_device_count", "nps_create", "nps_push_gt",
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
-    "nps_push_gt_raw", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
+    "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
     "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
     "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_destroy",
@@ -82,6 +82,8 @@ def load():
     L.nps_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams)]
     L.nps_push_gt.argtypes = [vp, vp, i32, i32, i32, dbl, dbl]
     L.nps_push_gt_raw.argtypes = [vp, vp, i32, i32, i32, i32, dbl, dbl]
+    L.nps_push_bed.argtypes = [vp, vp, i32, i32, dbl, dbl]
+    L.nps_cohort_upload_bed.argtypes = [vp, u64, u64, vp, C.c_size_t, vp]
     L.nps_push_ds.argtypes = [vp, vp, i32, dbl, dbl]
     L.nps_push_packed.argtypes = [vp, vp, i32, dbl, dbl]
     L.nps_push_locus.argtypes = [vp, i32, i32, dbl, dbl]
@@ -152,6 +154,14 @@ class Cohort:
         assert rows.ndim == 2
         _check(load().nps_cohort_upload(self._h, row0, rows.shape[0], rows.ctypes.data,
                                         rows.strides[0]))
+
+    def upload_bed(self, row0: int, bed_rows: np.ndarray, effect_is_a1):
+        """rows of a PLINK .bed file ([k, ceil(n/4)] uint8, e.g. a view of the mmap'ed file)"""
+        assert bed_rows.ndim == 2 and bed_rows.dtype == np.uint8 and bed_rows.strides[1] == 1
+        flags = np.ascontiguousarray(effect_is_a1, dtype=np.uint8)
+        assert flags.size == bed_rows.shape[0]
+        _check(load().nps_cohort_upload_bed(self._h, row0, bed_rows.shape[0], bed_rows.ctypes.data,
+                                            bed_rows.strides[0], flags.ctypes.data))
 
     def download(self, row0: int, nrows: int) -> np.ndarray:
         if self.fmt == FMT_DS32:
@@ -232,6 +242,14 @@ class Scorer:
             raise ValueError("gt has %d values, expected %d" % (gt.size, self.n * ploidy))
         _check(load().nps_push_gt_raw(self._h, gt.ctypes.data, gt.dtype.itemsize, ploidy, eaidx,
                                       int(bool(ref_is_effect)), float(beta), float(eaf)))
+
+    def push_bed(self, bed_row: np.ndarray, effect_is_a1, ref_is_effect, beta: float, eaf: float):
+        """one variant of a PLINK .bed file: ceil(n/4) bytes"""
+        bed_row = np.ascontiguousarray(bed_row, dtype=np.uint8)
+        if bed_row.size != (self.n + 3) // 4:
+            raise ValueError("bed row has %d bytes, expected %d" % (bed_row.size, (self.n + 3) // 4))
+        _check(load().nps_push_bed(self._h, bed_row.ctypes.data, int(bool(effect_is_a1)),
+                                   int(bool(ref_is_effect)), float(beta), float(eaf)))
 
     def push_ds(self, ds: np.ndarray, ref_is_effect, beta: float, eaf: float):
         ds = np.ascontiguousarray(ds, dtype=np.float32)

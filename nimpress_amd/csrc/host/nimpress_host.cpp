@@ -322,9 +322,27 @@ static bool parseRecordLine(const char *L, size_t len, size_t ns, const RegionMa
             s = t + 1;
         }
         v.ploidy = ploidy;
-        v.gts.resize(ns * ploidy);
-        for (size_t i = 0; i < ns; ++i)
-            for (int k = 0; k < ploidy; ++k) v.gts[i * ploidy + k] = tmp[i * cap + k];
+        // Kept the way a BCF record would hold it: int8 when every allele index fits (always, in
+        // practice), so that a row costs `ploidy` bytes per sample in host memory and over PCIe.
+        bool small = true;
+        for (size_t i = 0; i < ns && small; ++i)
+            for (int k = 0; k < ploidy; ++k) {
+                const int32_t x = tmp[i * cap + k];
+                if (x != kVectorEnd && x > 127) small = false;
+            }
+        if (small) {
+            v.gt_bytes = 1;
+            v.gt_raw.resize(ns * ploidy);
+            for (size_t i = 0; i < ns; ++i)
+                for (int k = 0; k < ploidy; ++k) {
+                    const int32_t x = tmp[i * cap + k];
+                    v.gt_raw[i * ploidy + k] = x == kVectorEnd ? (uint8_t)0x81 : (uint8_t)x;
+                }
+        } else {
+            v.gts.resize(ns * ploidy);
+            for (size_t i = 0; i < ns; ++i)
+                for (int k = 0; k < ploidy; ++k) v.gts[i * ploidy + k] = tmp[i * cap + k];
+        }
     }
     return true;
 }

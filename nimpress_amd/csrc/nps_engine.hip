@@ -635,6 +635,33 @@ extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effec
     return NPS_OK;
 }
 
+extern "C" int nps_push_bed(nps_ctx *c, const uint8_t *bed_row, int effect_is_a1, int ref_is_effect,
+                            double beta, double eaf) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->n && !bed_row) return fail(NPS_E_INVAL, "bed_row is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t slot;
+    int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
+    if (rc) return rc;
+    if (c->n) {
+        const int k = c->raw_next;
+        c->raw_next = (k + 1) % nps_ctx::kRawSlots;
+        HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
+        const size_t bytes = (size_t)((c->n + 3) / 4), padded = sizeof(uint32_t) * c->n_words;
+        memcpy(c->h_raw[k], bed_row, bytes);
+        memset((char *)c->h_raw[k] + bytes, 0, padded - bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_rowtmp, c->h_raw[k], padded, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
+        ProfScope ps(c, P_TALLY);
+        HIP_TRY(launch_bed_recode_row(c->stream, c->d_rowtmp, c->n, effect_is_a1));
+        HIP_TRY(launch_tally_scatter_row(c->stream, c->d_rowtmp, c->n,
+                                         c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
+                                         slot & 3, c->d_tally + slot));
+    }
+    commit_data_row(c, slot);
+    return NPS_OK;
+}
+
 // lazily allocate the DS streaming batch
 static int ensure_ds(nps_ctx *c) {
     if (c->d_ds) return NPS_OK;
@@ -902,6 +929,53 @@ static int gt2_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void
     return NPS_OK;
 }
 
+// rows of a host buffer -> staging on the device -> interleave (and, for .bed rows, recode) kernel.
+// width = bytes of one source row; bed_mode: nullptr (native codes) or per-row effect-is-A1 flags.
+static int gt2_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
+                      size_t host_stride, size_t width, const uint8_t *bed_mode) {
+    if (row0 & 3) return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
+    const uint64_t sw = c->stride_bytes / 4;  // word columns per group in the cohort
+    const uint64_t src_stride_words = sw;     // staging rows padded the same way (zero filled)
+    uint64_t chunk = std::max<uint64_t>(4, (256ull << 20) / (src_stride_words * 4)) / 4 * 4;
+    chunk = std::min<uint64_t>(chunk, 4ull * 65535);
+    chunk = std::min<uint64_t>(chunk, (nrows + 3) / 4 * 4);
+    uint32_t *d_stage = nullptr;
+    uint8_t *d_mode = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, chunk * src_stride_words * 4));
+    hipError_t e = hipSuccess;
+    if (bed_mode) e = hipMalloc(&d_mode, chunk);
+    for (uint64_t r = 0; e == hipSuccess && r < nrows; r += chunk) {
+        const uint64_t k = std::min(chunk, nrows - r);
+        e = hipMemsetAsync(d_stage, 0, chunk * src_stride_words * 4, nullptr);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(d_stage, src_stride_words * 4, (const char *)host_rows + r * host_stride,
+                            host_stride, width, k, hipMemcpyHostToDevice);
+        if (e == hipSuccess && bed_mode) e = hipMemcpy(d_mode, bed_mode + r, k, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = launch_interleave_rows(nullptr, d_stage, src_stride_words, k, c->n_samples,
+                                       bed_mode ? d_mode : nullptr,
+                                       (uint32_t *)((char *)c->d_data + ((row0 + r) >> 2) * sw * 16), sw);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    (void)hipFree(d_stage);
+    (void)hipFree(d_mode);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "cohort upload failed: %s", hipGetErrorString(e));
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const uint8_t *bed_rows,
+                                     size_t row_stride_bytes, const uint8_t *effect_is_a1) {
+    int rc = check_range(c, row0, nrows);
+    if (rc) return rc;
+    if (c->format != NPS_FMT_GT2) return fail(NPS_E_INVAL, ".bed rows need a 2-bit (NPS_FMT_GT2) cohort");
+    const size_t width = (size_t)((c->n_samples + 3) / 4);
+    if (nrows == 0 || width == 0) return NPS_OK;
+    if (!bed_rows || !effect_is_a1 || row_stride_bytes < width)
+        return fail(NPS_E_INVAL, "bad .bed buffer / stride / flags");
+    HIP_TRY(hipSetDevice(c->device));
+    return gt2_upload(c, row0, nrows, bed_rows, row_stride_bytes, width, effect_is_a1);
+}
+
 extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
@@ -911,7 +985,7 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
     if (c->format == NPS_FMT_GT2)
-        return gt2_transfer(c, row0, nrows, const_cast<void *>(host_rows), host_stride, true);
+        return gt2_upload(c, row0, nrows, host_rows, host_stride, width, nullptr);
     HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
                         host_stride, width, nrows, hipMemcpyHostToDevice));
     return NPS_OK;

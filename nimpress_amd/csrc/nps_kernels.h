@@ -50,6 +50,13 @@ hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint6
                                     uint32_t *d_group, int row_in_group,
                                     unsigned long long *d_tally);
 
+// plain row-major rows (native codes, or PLINK .bed rows with a per-row effect-allele flag) -> the
+// group-interleaved cohort layout, on the device; k <= 4*65535 rows per launch
+hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
+                                  uint64_t k, uint64_t n_samples, const uint8_t *d_mode, uint32_t *d_dst,
+                                  uint64_t stride_words);
+hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1);
+
 // per-row decision + LUT {0b,1b,2b,imp*b} (or the locus constant); rows [n_rows, n_rows_pad) get a
 // zero LUT.  Adds the number of used rows to *d_nloci.
 hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,

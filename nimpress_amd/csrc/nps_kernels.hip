@@ -223,6 +223,79 @@ hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint6
 }
 
 // ------------------------------------------------------------------------------------------
+// PLINK 1 .bed rows (variant-major, 4 samples per byte, sample 0 in the low bits; values 0 = hom A1,
+// 1 = missing, 2 = het, 3 = hom A2) are already 2-bit and sample-minor: the only work is a bit
+// permutation per code, chosen by which allele the score row counts:
+//   effect = A1:  0->3 (dosage 2)  2->1  3->0  1->2 (missing)   = bitwise NOT
+//   effect = A2:  0->0  2->1  3->3 (dosage 2)  1->2 (missing)   = swap the two bits of every code
+// Bits past the last sample are cleared (the .bed pads the last byte with zeros = hom A1).
+static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, bool effect_a1, uint32_t c,
+                                                       uint32_t n_words, uint32_t tail_mask) {
+    const uint32_t x = effect_a1 ? ~w : (((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1));
+    return c + 1 == n_words ? (x & tail_mask) : x;
+}
+
+// rows [0,k) of a plain row-major staging buffer (src_stride_words apart) -> the group-interleaved
+// cohort layout at dst (first group of the destination).  mode: nullptr = rows are native codes;
+// else per row 0 = .bed row, effect allele A2; 1 = .bed row, effect allele A1.
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const uint32_t *__restrict__ src,
+                                                              uint64_t src_stride_words, uint64_t k,
+                                                              uint32_t n_words, uint32_t tail_mask,
+                                                              const uint8_t *__restrict__ mode,
+                                                              uint32_t *__restrict__ dst,
+                                                              uint64_t stride_words) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t g = blockIdx.y;
+    if (c >= n_words) return;
+    uint32_t q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint64_t row = g * 4 + r;
+        uint32_t w = 0;
+        if (row < k) {
+            w = src[row * src_stride_words + c];
+            w = mode ? bed_recode(w, mode[row] != 0, c, n_words, tail_mask)
+                     : (c + 1 == n_words ? (w & tail_mask) : w);
+        }
+        q[r] = w;
+    }
+    reinterpret_cast<uint4 *>(dst)[g * stride_words + c] = make_uint4(q[0], q[1], q[2], q[3]);
+}
+
+hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
+                                  uint64_t k, uint64_t n_samples, const uint8_t *d_mode, uint32_t *d_dst,
+                                  uint64_t stride_words) {
+    if (k == 0 || n_samples == 0) return hipSuccess;
+    const uint32_t n_words = (uint32_t)words_for(n_samples);
+    const uint32_t rem = (uint32_t)(n_samples & 15);
+    const uint32_t tail_mask = rem ? ((1u << (2 * rem)) - 1u) : 0xffffffffu;
+    const uint64_t groups = (k + 3) / 4;
+    if (groups > 65535) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(interleave_rows_kernel, dim3((n_words + 255) / 256, (uint32_t)groups), dim3(256), 0,
+                       st, d_src, src_stride_words, k, n_words, tail_mask, d_mode, d_dst, stride_words);
+    return hipGetLastError();
+}
+
+// one .bed row in place -> native codes (nps_push_bed staging)
+__global__ __launch_bounds__(256) void bed_recode_row_kernel(uint32_t *__restrict__ row, uint32_t n_words,
+                                                             uint32_t tail_mask, int effect_a1) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n_words) row[c] = bed_recode(row[c], effect_a1 != 0, c, n_words, tail_mask);
+}
+
+hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1) {
+    if (n_samples == 0) return hipSuccess;
+    const uint32_t n_words = (uint32_t)words_for(n_samples);
+    const uint32_t rem = (uint32_t)(n_samples & 15);
+    const uint32_t tail_mask = rem ? ((1u << (2 * rem)) - 1u) : 0xffffffffu;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bed_recode_row_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, d_row, n_words,
+                       tail_mask, effect_a1);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // per-row decision and LUT.  Mirrors nimpress.nim:565-571 (maxmis, strict > on a double quotient),
 // :417-447 (locus imputation constant) and :450-481 (sample imputation value).
 __global__ __launch_bounds__(256) void row_params_kernel(

@@ -632,3 +632,50 @@ def test_push_gt_raw_typed_vectors(dtype):
     assert nloci == ref_nloci
     assert_stats_equal(stats, ref.stats)
     assert rel_err(scores, ref_scores, betas, max(nloci, 1)) <= REL_TOL
+
+
+# ------------------------------------------------------------------------------------------
+# PLINK 1 .bed rows (values 0 hom A1, 1 missing, 2 het, 3 hom A2; 4 samples per byte)
+def codes_to_bed(codes_row, n, effect_is_a1):
+    """native 2-bit codes (dosage of the effect allele) -> the .bed bytes that encode the same calls"""
+    c = (codes_row[np.arange(n) >> 4] >> ((np.arange(n) & 15) * 2)) & 3     # 0 d0, 1 d1, 3 d2, 2 missing
+    if effect_is_a1:
+        v = np.select([c == 0, c == 1, c == 3], [3, 2, 0], 1)              # dosage counts A1
+    else:
+        v = np.select([c == 0, c == 1, c == 3], [0, 2, 3], 1)              # dosage counts A2
+    v = np.concatenate([v, np.zeros((-n) % 4, dtype=v.dtype)]).reshape(-1, 4)
+    return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [1, 7, 16, 1001, 4097])
+def test_plink_bed_rows_streamed_and_resident(n):
+    m = 23
+    rng = np.random.default_rng(n)
+    co = make_cohort(n, m, 555, rng)
+    a1 = rng.integers(0, 2, m).astype(np.uint8)
+    bed = np.stack([codes_to_bed(co["codes"][j], n, a1[j]) for j in range(m)])
+    kw = PARAM_GRID[0]
+    ref_scores, ref_stats, ref_nloci = refcpu.score_packed(
+        co["codes"], n, np.zeros(m, np.int32), co["rie"], co["beta"], co["eaf"], refcpu.make_params(**kw), 0.5)
+    # streamed
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for j in range(m):
+        sc.push_bed(bed[j], a1[j], co["rie"][j], co["beta"][j], co["eaf"][j])
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.5)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+    # resident: .bed rows -> cohort (recode + interleave on the device) == native upload
+    dev = capi.Cohort(n, m)
+    dev.upload_bed(0, bed, a1)
+    assert np.array_equal(dev.download(0, m), co["codes"][:, : (n + 15) // 16])
+    sc.reset()
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]))
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.5)
+    sc.close()
+    dev.close()
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
