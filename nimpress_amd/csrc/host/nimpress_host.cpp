@@ -906,6 +906,81 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
         for (const ScoreEntry &e : *keep) wanted[e.contig].emplace_back(e.pos, e.stop());
     std::vector<int32_t> tmp;
 
+    {  // PLINK 1 fileset: <prefix>.bed + .bim + .fam
+        FILE *f = fopen(path.c_str(), "rb");
+        unsigned char magic[3] = {0, 0, 0};
+        const bool is_bed = f && fread(magic, 1, 3, f) == 3 && magic[0] == 0x6c && magic[1] == 0x1b;
+        if (is_bed) {
+            struct Closer {
+                FILE *f;
+                ~Closer() { fclose(f); }
+            } closer{f};
+            if (magic[2] != 1) throw std::runtime_error("sample-major .bed files are not supported");
+            std::string prefix = path;
+            if (prefix.size() > 4 && prefix.compare(prefix.size() - 4, 4, ".bed") == 0) prefix.resize(prefix.size() - 4);
+            std::string fam, bim;
+            if (!readFile(prefix + ".fam", fam) || !readFile(prefix + ".bim", bim))
+                throw std::runtime_error("cannot open " + prefix + ".fam / .bim next to the .bed file");
+            auto fields = [](const std::string &line) {
+                std::vector<std::string> out;
+                size_t i = 0;
+                while (i < line.size()) {
+                    while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) ++i;
+                    size_t j = i;
+                    while (j < line.size() && line[j] != ' ' && line[j] != '\t' && line[j] != '\r') ++j;
+                    if (j > i) out.push_back(line.substr(i, j - i));
+                    i = j;
+                }
+                return out;
+            };
+            for (const std::string &ln : splitChar(fam, '\n')) {
+                const std::vector<std::string> c = fields(ln);
+                if (c.empty()) continue;
+                if (c.size() < 2) throw std::runtime_error("bad .fam line");
+                samples.push_back(c[1]);  // IID
+            }
+            const size_t row_bytes = (samples.size() + 3) / 4;
+            size_t row = 0;
+            for (const std::string &ln : splitChar(bim, '\n')) {
+                const std::vector<std::string> c = fields(ln);
+                if (c.empty()) continue;
+                if (c.size() < 6) throw std::runtime_error("bad .bim line");
+                Variant v;
+                v.contig = c[0];
+                v.id = c[1];
+                v.pos = parseIntNim(c[3]);
+                v.ref = c[5];           // A2
+                v.alt.push_back(c[4]);  // A1
+                v.filter = ".";
+                v.is_bed = true;
+                v.gt_bytes = 0;
+                v.ploidy = 2;
+                bool want = !keep;
+                if (keep) {
+                    auto it = wanted.find(v.contig);
+                    if (it != wanted.end()) {
+                        const int64_t len = (int64_t)std::max(v.ref.size(), v.alt[0].size());
+                        for (const auto &w : it->second)
+                            if (v.pos <= w.second && v.pos + len - 1 >= w.first) {
+                                want = true;
+                                break;
+                            }
+                    }
+                }
+                if (want) {
+                    v.gt_raw.resize(row_bytes);
+                    if (row_bytes &&
+                        (fseeko(f, (off_t)(3 + row * row_bytes), SEEK_SET) != 0 ||
+                         fread(v.gt_raw.data(), 1, row_bytes, f) != row_bytes))
+                        throw std::runtime_error("truncated .bed file");
+                    records.push_back(std::move(v));
+                }
+                ++row;
+            }
+            return true;
+        }
+        if (f) fclose(f);
+    }
     if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // BCF + CSI
         CsiIndex csi;
         BgzfFile bg;
@@ -1061,6 +1136,12 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
 // element i as bcf_get_genotypes hands it out: int8 / int16 end-of-vector and missing become their
 // int32 counterparts, everything else is sign extended (htslib vcf.c, bcf_get_format_values)
 int32_t Variant::gtValue(size_t i) const {
+    if (is_bed) {  // (diploid; A2 = allele 0, A1 = allele 1)
+        const unsigned code = (gt_raw[(i / 2) >> 2] >> (((i / 2) & 3) * 2)) & 3u;
+        if (code == 1) return 0;                       // missing
+        const int n_a1 = code == 0 ? 2 : (code == 2 ? 1 : 0);
+        return ((int)(i & 1) < n_a1 ? 2 : 1) << 1;     // (allele + 1) << 1
+    }
     if (gt_raw.empty()) return gts[i];
     switch (gt_bytes) {
     case 1: {
@@ -1085,8 +1166,15 @@ const Variant *findVariant(const std::string &contig, int64_t pos, const std::st
     const int64_t stop = pos + (int64_t)refseq.size() - 1;
     for (const Variant &v : vcf.records) {  // file order = the order a region query returns
         if (v.contig != contig) continue;
-        const int64_t vend = v.pos + (int64_t)v.ref.size() - 1;
+        const size_t vlen = v.is_bed ? std::max(v.ref.size(), v.alt[0].size()) : v.ref.size();
+        const int64_t vend = v.pos + (int64_t)vlen - 1;
         if (v.pos > stop || vend < pos) continue;
+        if (v.is_bed) {  // no REF in a .bim: the row's two alleles must be the variant's two alleles
+            const std::string &a1 = v.alt[0], &a2 = v.ref;
+            if ((refseq == a2 && (easeq == a1 || easeq == a2)) || (refseq == a1 && (easeq == a1 || easeq == a2)))
+                return &v;
+            continue;
+        }
         if (v.ref != refseq) continue;  // nim:359 -- POS itself is never compared
         if (easeq == refseq) return &v;
         for (const std::string &a : v.alt)
@@ -1281,7 +1369,11 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                                 break;
                             }
                     }
-                    if (v->gt_bytes == 4 && v->gt_raw.empty())
+                    if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
+                        npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0, rie, e.beta,
+                                              e.eaf),
+                                 "nps_push_bed");
+                    else if (v->gt_bytes == 4 && v->gt_raw.empty())
                         npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
                                  "nps_push_gt");
                     else  // the BCF record's own int8 / int16 vector: widened on the device
@@ -1449,7 +1541,8 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
         strncpy(filter, v->filter.c_str(), (size_t)filter_cap - 1);
         filter[filter_cap - 1] = 0;
     }
-    const size_t nval = v->gt_raw.empty() ? v->gts.size() : v->gt_raw.size() / (size_t)v->gt_bytes;
+    const size_t nval = v->is_bed ? 2 * vcf.samples.size()
+                        : v->gt_raw.empty() ? v->gts.size() : v->gt_raw.size() / (size_t)v->gt_bytes;
     for (size_t i = 0; i < nval && (long)i < gts_cap; ++i) gts[i] = v->gtValue(i);
     return (long)(v - vcf.records.data());
 }

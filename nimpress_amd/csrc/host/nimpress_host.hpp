@@ -69,6 +69,10 @@ struct Variant {
     std::vector<int32_t> gts;
     std::vector<uint8_t> gt_raw;
     bool has_gt = true;
+    // PLINK 1 .bed source (build-defined extension): gt_raw holds the variant's ceil(N/4) .bed bytes,
+    // ref = A2 and alt = {A1} of the .bim line.  A .bim has no notion of REF, so findVariant also
+    // accepts a score row whose ref is A1.
+    bool is_bed = false;
     const void *gtData() const { return gt_raw.empty() ? (const void *)gts.data() : (const void *)gt_raw.data(); }
     int32_t gtValue(size_t i) const;  // element i widened like bcf_get_genotypes does
 };

@@ -85,3 +85,49 @@ def test_cli_on_bcf_equals_cli_on_vcf(tmp_path, gt_dtype):
                            capture_output=True, text=True)
         assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
         assert a.stdout == b.stdout
+
+
+def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
+    """the same biallelic calls as text VCF and as a PLINK 1 fileset (.bed/.bim/.fam, A1 = ALT,
+    A2 = REF, and for every third variant the other way round): identical output"""
+    rng = np.random.default_rng(4)
+    n, m = 203, 57
+    names = ["I%03d" % i for i in range(n)]
+    vcf = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
+    bim, bed = [], bytearray(b"\x6c\x1b\x01")
+    score = ["t", "", "", "x", "0.05"]
+    pos = 100
+    for j in range(m):
+        pos += int(rng.integers(1, 500))
+        contig = "1" if j < 30 else "7"
+        ref, alt = ("A", "G") if j % 5 else ("AT", "A")
+        nalt = rng.integers(0, 3, n)
+        miss = rng.uniform(size=n) < (0.3 if j % 11 == 0 else 0.03)
+        gt = ["./." if miss[i] else ("0/0", "0/1", "1/1")[nalt[i]] for i in range(n)]
+        vcf.append("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s" % (contig, pos, ref, alt, "\t".join(gt)))
+        swap = j % 3 == 0                      # .bim lists the alleles the other way round
+        a1, a2 = (ref, alt) if swap else (alt, ref)
+        n_a1 = (2 - nalt) if swap else nalt
+        code = np.where(miss, 1, np.select([n_a1 == 2, n_a1 == 1], [0, 2], 3))
+        code = np.concatenate([code, np.zeros((-n) % 4, dtype=code.dtype)]).reshape(-1, 4)
+        bed += bytes((code[:, 0] | (code[:, 1] << 2) | (code[:, 2] << 4) | (code[:, 3] << 6)).astype(np.uint8))
+        bim.append("%s\trs%d\t0\t%d\t%s\t%s" % (contig, j, pos, a1, a2))
+        if j % 4 != 3:                         # every 4th variant is not in the score
+            ea = alt if j % 2 else ref         # effect allele = ALT or REF
+            score.append("%s\t%d\t%s\t%s\t%.4f\t%.4f" % (contig, pos, ref, ea, rng.normal(0, 0.1),
+                                                          rng.uniform(0.05, 0.5)))
+    score.append("9\t5\tC\tT\t0.1\t0.2")        # absent locus
+    (tmp_path / "c.vcf").write_text("\n".join(vcf) + "\n")
+    (tmp_path / "c.bed").write_bytes(bytes(bed))
+    (tmp_path / "c.bim").write_text("\n".join(bim) + "\n")
+    (tmp_path / "c.fam").write_text("".join("F%d %s 0 0 0 -9\n" % (i, nm) for i, nm in enumerate(names)))
+    (tmp_path / "s.score").write_text("\n".join(score))
+    for flags in ([], ["--imp-locus=homref", "--imp-sample=int_fail", "--maxmis=0.1", "--mincs=10"],
+                  ["--imp-locus=ignore", "--imp-missing=ignore", "--imp-sample=ps"]):
+        a = subprocess.run([CLI, *flags, str(tmp_path / "s.score"), str(tmp_path / "c.bed")],
+                           capture_output=True, text=True)
+        b = subprocess.run([CLI, *flags, str(tmp_path / "s.score"), str(tmp_path / "c.vcf")],
+                           capture_output=True, text=True)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout
+        assert len(a.stdout.splitlines()) >= n
