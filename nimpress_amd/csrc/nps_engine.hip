@@ -918,9 +918,9 @@ static int gt2_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void
             uint32_t *hrow = (uint32_t *)((char *)host_rows + (r + j) * host_stride);
             uint32_t *g = buf.data() + (j >> 2) * sw * 4 + (j & 3);
             if (to_device)
-                for (uint64_t w = 0; w < n_words; ++w) g[w * 4] = hrow[w];
+                for (uint64_t w = 0; w < n_words; ++w) g[w * 4] = word_to_planes(hrow[w]);
             else
-                for (uint64_t w = 0; w < n_words; ++w) hrow[w] = g[w * 4];
+                for (uint64_t w = 0; w < n_words; ++w) hrow[w] = word_from_planes(g[w * 4]);
         }
         // rows of a last partial group that are not part of this upload become zero
         if (to_device)

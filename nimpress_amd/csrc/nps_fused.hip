@@ -58,22 +58,11 @@ struct FusedArgs {
                                     // hits), bit 1 skip the accumulation
 };
 
-// ---- DPP helpers --------------------------------------------------------------------------
-template <int CTRL>
-static __device__ __forceinline__ uint32_t dpp(uint32_t v) {
-    // out-of-range source lanes read 0 (bound_ctrl)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-constexpr int kQuadSwap1 = 0xB1;  // quad_perm:[1,0,3,2]  lane ^ 1
-constexpr int kQuadSwap2 = 0x4E;  // quad_perm:[2,3,0,1]  lane ^ 2
-constexpr int kRowShr4 = 0x114;
-constexpr int kRowShr8 = 0x118;
-
-// popcounts of one word, packed popc(w) << 16 | missing.  With the codes 00/01/11 = dosage 0/1/2 and
-// 10 = missing, popc(w) = effect alleles + missing samples: five VALU ops per row word.
+// popcounts of one device word, packed popc(w) << 16 | missing.  With the codes 00/01/11 = dosage
+// 0/1/2 and 10 = missing, popc(w) = effect alleles + missing samples: five VALU ops per row word.
 static __device__ __forceinline__ uint32_t tally_pack(uint32_t w) {
     const uint32_t t = __popc(w);
-    const uint32_t m = __popc((w >> 1) & ~w & 0x55555555u);
+    const uint32_t m = __popc((w >> 4) & ~w & 0x0F0F0F0Fu);
     return (t << 16) | m;
 }
 
@@ -96,26 +85,23 @@ static __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t 
     return d;
 }
 
-// 4 rows x 16 samples of 2-bit codes -> 16 table indices in 24 VALU ops (3 stages x 4 merges, each a
-// shift + v_bfi): x[q] byte k = table_index of sample 4k+q.
+// 4 rows x 16 samples of 2-bit codes -> 16 table indices in 16 VALU ops (2 stages x 4 merges, each a
+// shift + v_bfi): x[q] byte k = table_index of sample 4k+q.  The device words keep the low and the
+// high code bits of four samples in separate nibbles of a byte (nps_kernels.h), so exchanging the two
+// sample-in-byte bits with the two row bits IS the whole transposition.
 static __device__ __forceinline__ void transpose_fold_4x16(uint32_t w0, uint32_t w1, uint32_t w2,
                                                            uint32_t w3, uint32_t (&x)[4]) {
-    const uint32_t m1 = 0x55555555u, m2 = 0x33333333u, m4 = 0x0F0F0F0Fu;
-    // stage 1: per sample a 2-bit field with the same-plane bits of two rows
-    const uint32_t l01 = bfi(m1, w0, w1 << 1);
-    const uint32_t h01 = bfi(m1, w0 >> 1, w1);
-    const uint32_t l23 = bfi(m1, w2, w3 << 1);
-    const uint32_t h23 = bfi(m1, w2 >> 1, w3);
-    // stage 2: nibbles (four rows, one plane) of the even / odd samples
-    const uint32_t le = bfi(m2, l01, l23 << 2);
-    const uint32_t lo = bfi(m2, l01 >> 2, l23);
-    const uint32_t he = bfi(m2, h01, h23 << 2);
-    const uint32_t ho = bfi(m2, h01 >> 2, h23);
-    // stage 3: bytes = low-plane nibble | high-plane nibble << 4
-    x[0] = bfi(m4, le, he << 4);   // samples 0,4,8,12
-    x[2] = bfi(m4, le >> 4, he);   // samples 2,6,10,14
-    x[1] = bfi(m4, lo, ho << 4);   // samples 1,5,9,13
-    x[3] = bfi(m4, lo >> 4, ho);   // samples 3,7,11,15
+    const uint32_t m1 = 0x55555555u, m2 = 0x33333333u;
+    // stage 1: samples 4k, 4k+2 (a0, b0) and 4k+1, 4k+3 (a1, b1) of the row pairs (0,1) and (2,3)
+    const uint32_t a0 = bfi(m1, w0, w1 << 1);
+    const uint32_t a1 = bfi(m1, w0 >> 1, w1);
+    const uint32_t b0 = bfi(m1, w2, w3 << 1);
+    const uint32_t b1 = bfi(m1, w2 >> 1, w3);
+    // stage 2: nibbles = four rows, one code bit, one sample
+    x[0] = bfi(m2, a0, b0 << 2);   // samples 0,4,8,12
+    x[2] = bfi(m2, a0 >> 2, b0);   // samples 2,6,10,14
+    x[1] = bfi(m2, a1, b1 << 2);   // samples 1,5,9,13
+    x[3] = bfi(m2, a1 >> 2, b1);   // samples 3,7,11,15
 }
 
 // Row LUT from a complete tally word: the maxmis decision (nimpress.nim:565-571), the locus constant
@@ -355,22 +341,31 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         }
     };
 
-    // reduce-scatter of four packed row tallies over the wave, then one LDS add per DPP row
+    // reduce-scatter of four packed row tallies over each 16-lane DPP row, then one LDS add per quad
     auto tally_reduce4 = [&](int par, int g, const uint32_t(&tp)[4]) {
-        const bool odd = lane & 1;
-        const uint32_t x0 = odd ? tp[2] : tp[0], y0 = odd ? tp[0] : tp[2];
-        const uint32_t x1 = odd ? tp[3] : tp[1], y1 = odd ? tp[1] : tp[3];
-        const uint32_t b0 = x0 + dpp<kQuadSwap1>(y0);
-        const uint32_t b1 = x1 + dpp<kQuadSwap1>(y1);
-        const bool hi = lane & 2;
-        const uint32_t xx = hi ? b1 : b0, yy = hi ? b0 : b1;
-        uint32_t c = xx + dpp<kQuadSwap2>(yy);
-        c += dpp<kRowShr4>(c);
-        c += dpp<kRowShr8>(c);
-        if ((lane & 12) == 12) {
-            const int r = ((lane & 1) << 1) | ((lane >> 1) & 1);
-            atomicAdd(&lds.tally[par][4 * g + r], c);
-        }
+        // A DPP bank mask enables whole quads (bank b = lanes 4b..4b+3 of a 16-lane row), so the scatter
+        // goes over the quads first -- distance 8, then distance 4, every add writing only the quads
+        // that keep its row -- and the quad is summed last: quad b of every 16-lane row ends with the
+        // row-of-16 sum of tally row b in all four lanes.  8 adds and no selects.  s_nop: a DPP operand
+        // written by one of the two preceding VALU instructions needs wait states the compiler cannot
+        // see inside the asm.
+        uint32_t b0, b1, c;
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_u32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_u32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_u32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_u32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 0\n\t"
+            "v_add_u32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_u32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1\n\t"
+            "v_add_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_add_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            : "=&v"(b0), "=&v"(b1), "=&v"(c)
+            : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]));
+        if ((lane & 3) == 0) atomicAdd(&lds.tally[par][4 * g + ((lane >> 2) & 3)], c);
     };
 
     auto tally_local = [&](uint32_t k, const uint32_t(&src)[kRowsPerBatch]) {
@@ -467,7 +462,7 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedP
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T, 0>, T, 0);
     if (e != hipSuccess) return e;
     // the kernel needs 128 VGPRs: 16 waves per CU; never ask for more than that many workgroups
-    per_cu = std::min(per_cu, T == 768 ? 1 : 1024 / T);
+    per_cu = std::min(per_cu, T >= 768 ? 1 : 1024 / T);
     if (per_cu < 1) return hipSuccess;
     const uint64_t capacity = (uint64_t)cus * per_cu;
     const uint64_t cols = T - 64;  // word columns per workgroup (wave 0 is the control wave)
@@ -507,6 +502,9 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
         case 256: e = plan_for<256>(cus, n_words, n_batches, plan); break;
         case 512: e = plan_for<512>(cus, n_words, n_batches, plan); break;
         case 768: e = plan_for<768>(cus, n_words, n_batches, plan); break;
+        case 832: e = plan_for<832>(cus, n_words, n_batches, plan); break;
+        case 896: e = plan_for<896>(cus, n_words, n_batches, plan); break;
+        case 960: e = plan_for<960>(cus, n_words, n_batches, plan); break;
         case 1024: e = plan_for<1024>(cus, n_words, n_batches, plan); break;
         default: return hipErrorInvalidValue;
         }
@@ -550,6 +548,9 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
         fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256, 0>
              : plan.threads == 512 ? (const void *)fused_cw_kernel<512, 0>
              : plan.threads == 768 ? (const void *)fused_cw_kernel<768, 0>
+             : plan.threads == 832 ? (const void *)fused_cw_kernel<832, 0>
+             : plan.threads == 896 ? (const void *)fused_cw_kernel<896, 0>
+             : plan.threads == 960 ? (const void *)fused_cw_kernel<960, 0>
                                    : (const void *)fused_cw_kernel<1024, 0>;
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);

@@ -9,7 +9,11 @@
 namespace nps {
 
 // Device layout of the packed GT matrix (DESIGN.md "Data layout"): 2-bit codes, 16 samples per
-// uint32 word (word column c = samples 16c..16c+15).  Rows are stored in GROUPS OF FOUR, interleaved
+// uint32 word (word column c = samples 16c..16c+15), the two bits of a code in separate nibbles:
+// byte k of a word holds samples 16c+4k..16c+4k+3, their LOW code bits in bits 0..3 and their HIGH
+// code bits in bits 4..7 (word_to_planes / word_from_planes convert from / to the C-ABI's order,
+// sample i in bits 2i, 2i+1).  With the planes apart, four row words become sixteen table indices in
+// two merge stages instead of three.  Rows are stored in GROUPS OF FOUR, interleaved
 // at word granularity: word (row, c) lives at uint32 index ((row/4)*stride_words + c)*4 + row%4, so
 // the four rows a thread needs for one table lookup group are ONE 16-byte load and a wave reads
 // 1 KiB contiguously.  stride_words = word columns per group, padded to 64 (a group is a multiple
@@ -19,6 +23,25 @@ constexpr uint32_t kStrideAlignWords = 64;
 static inline uint64_t g4_word_index(uint64_t row, uint64_t col, uint64_t stride_words) {
     return ((row >> 2) * stride_words + col) * 4 + (row & 3);
 }
+
+// C-ABI word (sample i in bits 2i, 2i+1) -> device word (byte k: low bits of samples 4k..4k+3 in the
+// low nibble, high bits in the high nibble), and back.  Two delta swaps per direction.
+static __host__ __device__ inline uint32_t word_to_planes(uint32_t x) {
+    uint32_t t = (x ^ (x >> 1)) & 0x22222222u;  // bits 1 <-> 2 of every nibble
+    x ^= t ^ (t << 1);
+    t = (x ^ (x >> 2)) & 0x0C0C0C0Cu;  // bit pairs (3:2) <-> (5:4) of every byte
+    x ^= t ^ (t << 2);
+    return x;
+}
+static __host__ __device__ inline uint32_t word_from_planes(uint32_t x) {
+    uint32_t t = (x ^ (x >> 2)) & 0x0C0C0C0Cu;
+    x ^= t ^ (t << 2);
+    t = (x ^ (x >> 1)) & 0x22222222u;
+    x ^= t ^ (t << 1);
+    return x;
+}
+// bit of the LOW code bit of sample j (0..15) in a device word; the HIGH code bit is 4 above it
+static __host__ __device__ inline int plane_bit(int j) { return 8 * (j >> 2) + (j & 3); }
 
 static inline uint64_t words_for(uint64_t n_samples) { return (n_samples + 15) / 16; }
 static inline uint64_t stride_words_for(uint64_t n_samples) {

@@ -10,9 +10,10 @@
 // a score.  No MFMA: this is a streaming weighted reduction (0.25 B per genotype).
 //
 // The accumulate kernel never converts a genotype to a float.  Per group of 4 rows it builds a
-// 256-entry float64 table in LDS, T[c0|c1<<2|c2<<4|c3<<6] = ((l0[c0]+l1[c1])+l2[c2])+l3[c3] with
-// l_r[c] = LUT of row r (0*b, 1*b, 2*b, imputed*b), transposes four 16-sample words into sixteen
-// byte indices with 16 bit-field ops, and does one ds_read_b64 + one v_add_f64 per FOUR genotypes.
+// 256-entry float64 table in LDS, T[idx] = ((l0[c0]+l1[c1])+l2[c2])+l3[c3] (idx: low code bits of the
+// four rows in the low nibble, high code bits in the high nibble) with l_r[c] = LUT of row r (0*b,
+// 1*b, 2*b, imputed*b), transposes four 16-sample words into sixteen byte indices with two merge
+// stages, and does one ds_read_b64 + one v_add_f64 per FOUR genotypes.
 #include <algorithm>
 
 #include "nps_kernels.h"
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const T *__restrict__ gt
         }
         code = miss ? NPS_CODE_MISSING : (code == 2 ? NPS_CODE_DOSAGE2 : code);
     }
-    uint32_t sh = code << (2 * (lane & 15));
+    uint32_t sh = ((code & 1u) | ((code >> 1) << 4)) << plane_bit(lane & 15);
     sh |= __shfl_xor(sh, 1, 64);
     sh |= __shfl_xor(sh, 2, 64);
     sh |= __shfl_xor(sh, 4, 64);
@@ -137,14 +138,14 @@ hipError_t launch_decode_gt(hipStream_t st, const void *d_gts, int elem_bytes, u
 }
 
 // ------------------------------------------------------------------------------------------
-// tally of packed rows.  For a word w of sixteen 2-bit codes (00 dosage 0, 01 dosage 1, 11 dosage 2,
-// 10 missing):
+// tally of packed rows.  For a device word w of sixteen 2-bit codes (00 dosage 0, 01 dosage 1,
+// 11 dosage 2, 10 missing; high code bits four above the low ones):
 //   popc(w)                       = het + 2*hom + miss
-//   popc(w>>1 & ~w & 0x55555555)  = miss
+//   popc(w>>4 & ~w & 0x0F0F0F0F)  = miss
 //   neffect = het + 2*hom = popc(w) - miss
 static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint32_t &cm) {
     cw += __popc(w);
-    cm += __popc((w >> 1) & ~w & 0x55555555u);
+    cm += __popc((w >> 4) & ~w & 0x0F0F0F0Fu);
 }
 
 // grid = (row groups, column chunks of 1024 words); every block adds its part of the four row
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *
     __shared__ uint32_t red[4 * 3];
     uint32_t cw = 0, cm = 0, cz = 0;
     for (uint32_t c = threadIdx.x; c < n_words; c += 256) {
-        const uint32_t w = row[c];
+        const uint32_t w = word_to_planes(row[c]);  // the staging row is in the C-ABI's bit order
         tally_word(w, cw, cm);
         out_group[(uint64_t)c * 4 + row_in_group] = w;
     }
@@ -235,8 +236,8 @@ static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, bool effect_a1
     return c + 1 == n_words ? (x & tail_mask) : x;
 }
 
-// rows [0,k) of a plain row-major staging buffer (src_stride_words apart) -> the group-interleaved
-// cohort layout at dst (first group of the destination).  mode: nullptr = rows are native codes;
+// rows [0,k) of a plain row-major staging buffer (src_stride_words apart, C-ABI bit order) -> the
+// group-interleaved cohort layout at dst (first group of the destination).  mode: nullptr = rows are native codes;
 // else per row 0 = .bed row, effect allele A2; 1 = .bed row, effect allele A1.
 __global__ __launch_bounds__(256) void interleave_rows_kernel(const uint32_t *__restrict__ src,
                                                               uint64_t src_stride_words, uint64_t k,
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const uint32_t *__
             w = mode ? bed_recode(w, mode[row] != 0, c, n_words, tail_mask)
                      : (c + 1 == n_words ? (w & tail_mask) : w);
         }
-        q[r] = w;
+        q[r] = word_to_planes(w);
     }
     reinterpret_cast<uint4 *>(dst)[g * stride_words + c] = make_uint4(q[0], q[1], q[2], q[3]);
 }
@@ -377,20 +378,20 @@ hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,
 }
 
 // ------------------------------------------------------------------------------------------
-// 4 rows x 16 samples of 2-bit codes -> 16 byte indices (c0 | c1<<2 | c2<<4 | c3<<6).
-// x[q] byte k = index of sample 4k+q.
+// 4 rows x 16 samples of 2-bit codes (device words) -> 16 byte indices: bit r = low code bit of row
+// r, bit 4+r = its high code bit.  x[q] byte k = index of sample 4k+q.  Two merge stages: rows
+// (0,1),(2,3) at 1-bit, then (01,23) at 2-bit granularity.
 static __device__ __forceinline__ void transpose_4x16(uint32_t w0, uint32_t w1, uint32_t w2,
                                                       uint32_t w3, uint32_t (&x)[4]) {
-    const uint32_t m2 = 0x33333333u, m4 = 0x0F0F0F0Fu;
-    // nibbles: e = even samples, o = odd samples, rows (0,1) and (2,3)
-    const uint32_t e01 = (w0 & m2) | ((w1 << 2) & ~m2);
-    const uint32_t o01 = ((w0 >> 2) & m2) | (w1 & ~m2);
-    const uint32_t e23 = (w2 & m2) | ((w3 << 2) & ~m2);
-    const uint32_t o23 = ((w2 >> 2) & m2) | (w3 & ~m2);
-    x[0] = (e01 & m4) | ((e23 << 4) & ~m4);         // samples 0,4,8,12
-    x[1] = (o01 & m4) | ((o23 << 4) & ~m4);         // samples 1,5,9,13
-    x[2] = ((e01 >> 4) & m4) | (e23 & ~m4);         // samples 2,6,10,14
-    x[3] = ((o01 >> 4) & m4) | (o23 & ~m4);         // samples 3,7,11,15
+    const uint32_t m1 = 0x55555555u, m2 = 0x33333333u;
+    const uint32_t a0 = (w0 & m1) | ((w1 << 1) & ~m1);  // samples 4k, 4k+2 of rows 0,1
+    const uint32_t a1 = ((w0 >> 1) & m1) | (w1 & ~m1);  // samples 4k+1, 4k+3
+    const uint32_t b0 = (w2 & m1) | ((w3 << 1) & ~m1);
+    const uint32_t b1 = ((w2 >> 1) & m1) | (w3 & ~m1);
+    x[0] = (a0 & m2) | ((b0 << 2) & ~m2);         // samples 0,4,8,12
+    x[2] = ((a0 >> 2) & m2) | (b0 & ~m2);         // samples 2,6,10,14
+    x[1] = (a1 & m2) | ((b1 << 2) & ~m2);         // samples 1,5,9,13
+    x[3] = ((a1 >> 2) & m2) | (b1 & ~m2);         // samples 3,7,11,15
 }
 
 constexpr int kAccThreads = 256;
@@ -432,9 +433,11 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
 #pragma unroll
         for (int gg = 0; gg < kGps; ++gg) {
             if (gg < (int)ng) {
+                // entry tid: code of row r = bit r | bit 4+r << 1, summed in row order
                 const double *l = lut + (uint64_t)(g0 + gg) * 16;
-                T[buf][gg][tid] = ((l[tid & 3] + l[4 + ((tid >> 2) & 3)]) + l[8 + ((tid >> 4) & 3)]) +
-                                  l[12 + (tid >> 6)];
+                const int c0 = (tid & 1) | ((tid >> 3) & 2), c1 = ((tid >> 1) & 1) | ((tid >> 4) & 2);
+                const int c2 = ((tid >> 2) & 1) | ((tid >> 5) & 2), c3 = ((tid >> 3) & 1) | ((tid >> 6) & 2);
+                T[buf][gg][tid] = ((l[c0] + l[4 + c1]) + l[8 + c2]) + l[12 + c3];
             }
         }
         __syncthreads();
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ co
                     w |= c << (2 * k);
                 }
             }
-            out[rr] = w;
+            out[rr] = word_to_planes(w);
         }
     }
     reinterpret_cast<uint4 *>(codes)[((row0 >> 2) + g) * stride_words + word] =

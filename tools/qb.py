@@ -3,6 +3,9 @@
 import json, subprocess, sys
 out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + sys.argv[1:],
                      capture_output=True, text=True)
+for line in out.stderr.splitlines():
+    if line.startswith("[nps]"):
+        print(line, flush=True)
 try:
     d = json.loads(out.stdout.strip().splitlines()[-1])
     k = d["roofline"]["kernel_ms_per_step"]
