@@ -162,10 +162,13 @@ static __device__ __forceinline__ void row_lut(const FusedArgs &a, unsigned long
 // other slices, the 16 row LUTs (two float64 divisions each) and the four 256-entry tables -- while
 // the other T/64-1 waves accumulate the previous batch.  One barrier per batch, tables double
 // buffered.  Slices are (T-64)*16 samples wide.
+template <int WAVES>  // data waves
 struct __attribute__((aligned(16))) FusedCwLds {
     double table[2][4][256];
     double lut[kRowsPerBatch][4];
-    uint32_t tally[2][kRowsPerBatch];
+    // partial tallies of a batch: [parity][row group][data wave][16-lane DPP row * 4 + row in group],
+    // every slot written by exactly one quad per batch (plain stores, no LDS atomics)
+    uint32_t tslot[2][4][WAVES][16];
 };
 
 template <int T, int DBG>  // DBG: diagnostics build (bit 0 re-read rows 0..15, bit 1 skip accumulation)
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     static_assert(T % 64 == 0 && T >= 128 && T <= 1024, "workgroup size");
     constexpr int TD = T - 64;  // data threads
     constexpr int kRing = 4;    // batches in flight per data thread: k (accumulating) .. k+3 (tallying)
-    __shared__ FusedCwLds lds;
+    __shared__ FusedCwLds<TD / 64> lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t team = blockIdx.y;   // grid = (P slices, Q teams)
@@ -185,8 +188,6 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         return (uint64_t)(team + (uint64_t)k * a.Q) * kRowsPerBatch;
     };
 
-    if (tid < 2 * kRowsPerBatch) (&lds.tally[0][0])[tid] = 0;
-    __syncthreads();
 
     // Barrier #j (j = 0,1,2,...) closes the phase in which the data waves tallied batch j.
     //   data waves, phase k (between #(k+2) and #(k+3)): accumulate batch k with tables[k&1],
@@ -200,12 +201,18 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         bool timed_out = false;
         unsigned long long tel_spins = 0, tel_wait = 0, tel_chain = 0, tel_bar = 0;  // telemetry
 
-        auto publish = [&](uint32_t k) {  // LDS tally sums of batch k are complete (barrier passed)
-            if (lane < kRowsPerBatch) {
-                const int par = k & 1;
-                const uint32_t v = lds.tally[par][lane];
-                lds.tally[par][lane] = 0;  // next written two phases later
-                const uint64_t row = batch_row0(k) + lane;
+        auto publish = [&](uint32_t k) {  // the tally slots of batch k are complete (barrier passed)
+            // lane = (row of the batch, DPP row of the data waves): sum that slot over the data waves,
+            // then over the four lanes of the quad
+            const int prow = lane >> 2;
+            const uint32_t *slot = &lds.tslot[k & 1][prow >> 2][0][(lane & 3) * 4 + (prow & 3)];
+            uint32_t v = 0;
+#pragma unroll
+            for (int w = 0; w < TD / 64; ++w) v += slot[w * 16];
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // lane ^ 2
+            if ((lane & 3) == 0) {
+                const uint64_t row = batch_row0(k) + prow;
                 if (k < n_local && row < a.n_rows) {
                     const uint64_t t = v >> 16, m = v & 0xFFFFu;
                     const uint64_t neff = t - m;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
             "v_add_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
             : "=&v"(b0), "=&v"(b1), "=&v"(c)
             : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]));
-        if ((lane & 3) == 0) atomicAdd(&lds.tally[par][4 * g + ((lane >> 2) & 3)], c);
+        if ((lane & 3) == 0) lds.tslot[par][g][dt >> 6][lane >> 2] = c;
     };
 
     auto tally_local = [&](uint32_t k, const uint32_t(&src)[kRowsPerBatch]) {

@@ -8,6 +8,10 @@ import sys
 
 import pytest
 
+# torch ships its own copy of the HIP runtime: import it before libnps.so pulls in /opt/rocm's, or a
+# later torch.cuda initialisation in the same process finds no device (the order bench.py uses too)
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -23,7 +23,9 @@ constexpr int ITERS = 2000;
 #define REP32(S) REP8(S) REP8(S) REP8(S) REP8(S)
 
 template <int OP>
-__global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned int *sink, unsigned seed) {
+__global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned int *sink, unsigned seed,
+                                           const double *gtab) {
+    const double *mytab = gtab + blockIdx.x * 256;  // this workgroup's 2 KiB table in global memory
     __shared__ double tab[2048 + 64];
     unsigned r[8];
     double d[8];
@@ -163,6 +165,29 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned int 
             REP8(S)
 #undef S
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 40) {  // 8 random 8-byte gathers from the workgroup's 2 KiB global table (L1 hits)
+#define S(i) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d[i]) : "v"(idx[i]), "s"(mytab));
+            REP8(S)
+#undef S
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (OP == 41) {  // 6 LDS lookups + 2 global gathers per block of 8
+#define S(i) asm volatile("ds_read_b64 %0, %1" : "=v"(d[i]) : "v"(idx[i]));
+            S(0) S(1) S(2) S(4) S(5) S(6)
+#undef S
+#define S(i) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d[i]) : "v"(idx[i]), "s"(mytab));
+            S(3) S(7)
+#undef S
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (OP == 42) {  // 6 LDS lookups alone (reference for 41)
+#define S(i) asm volatile("ds_read_b64 %0, %1" : "=v"(d[i]) : "v"(idx[i]));
+            S(0) S(1) S(2) S(4) S(5) S(6)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 43) {  // 2 gathers alone
+#define S(i) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d[i]) : "v"(idx[i]), "s"(mytab));
+            S(3) S(7)
+#undef S
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (OP == 22) {  // the fused mix: sdwa + ds_read_b64 + v_add_f64
 #define S(i)                                                                                          \
     asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "  \
@@ -185,11 +210,12 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned int 
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + threadIdx.x / 64] = t1 - t0;
 }
 
+static const double *g_tab = nullptr;
 template <int OP>
 static int run(const char *name, int per_iter, unsigned long long *d_out, unsigned *d_sink, int cus) {
     std::vector<unsigned long long> h(cus * 16);
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(k<OP>, dim3(cus), dim3(1024), 0, 0, d_out, d_sink, 12345u + rep);
+        hipLaunchKernelGGL(k<OP>, dim3(cus), dim3(1024), 0, 0, d_out, d_sink, 12345u + rep, g_tab);
         CK(hipDeviceSynchronize());
     }
     CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
@@ -209,6 +235,10 @@ int main() {
     unsigned *d_sink;
     CK(hipMalloc(&d_out, cus * 16 * 8));
     CK(hipMalloc(&d_sink, 64));
+    double *d_tab;
+    CK(hipMalloc(&d_tab, (size_t)cus * 2048));
+    CK(hipMemset(d_tab, 0, (size_t)cus * 2048));
+    g_tab = d_tab;
     printf("%s, %d CUs\n", p.name, cus);
     run<0>("v_and_b32 (VOP2, sgpr)", 32, d_out, d_sink, cus);
     run<1>("v_bfi_b32 (VOP3, sgpr mask)", 32, d_out, d_sink, cus);
@@ -236,6 +266,10 @@ int main() {
     run<31>("8 random lookups + 32 v_bfi + wait (per block)", 1, d_out, d_sink, cus);
     run<32>("8 conflict-free lookups + 32 v_bfi + wait (per block)", 1, d_out, d_sink, cus);
     run<30>("half the waves 32 v_bfi, half 8 random lookups (per block)", 1, d_out, d_sink, cus);
+    run<40>("8 random 8-byte global gathers, 2 KiB table (per block of 8)", 1, d_out, d_sink, cus);
+    run<42>("6 random LDS lookups (per block)", 1, d_out, d_sink, cus);
+    run<43>("2 global gathers (per block)", 1, d_out, d_sink, cus);
+    run<41>("6 LDS lookups + 2 global gathers (per block)", 1, d_out, d_sink, cus);
     run<22>("mix: sdwa + ds_read_b64(random) + v_add_f64 (per triple)", 8, d_out, d_sink, cus);
     return 0;
 }
