@@ -404,6 +404,89 @@ def test_linearity_property_large():
     assert np.max(np.abs(outs[2] - (outs[0] + outs[1]))) <= 1e-12 * scale * 10
 
 
+def test_full_size_config3_properties():
+    """BASELINE.json configs[2] at its full size (500 000 samples x 1 000 000 rows, 125 GB of 2-bit
+    codes resident in HBM): far beyond what the oracle can score, so parity goes through
+    size-independent properties plus the oracle on what it CAN reach:
+      * every row's decision (1000 rows over --maxmis, nloci = M), tallies of spot rows recounted by
+        the oracle's generator over the full width;
+      * the first 16 samples scored on the CPU over ALL rows (the reference's per-row arithmetic,
+        nimpress.nim:565-583,639-649, fed with the recounted-and-spot-checked row tallies);
+      * fused single-read kernel == two-pass kernels for every sample;
+      * scores(2 beta) == 2 scores(beta) bit for bit (scaling by 2 is exact in every step);
+      * the two row halves scored separately add up to the whole."""
+    import torch
+    n, m, seed = 500_000, 1_000_000, 20250103
+    free, _total = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs 150 GB of free HBM")
+    rng = np.random.default_rng(seed)
+    beta = np.round(rng.normal(0.0, 0.02, m), 4)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.02, m)
+    miss[::1000] = 0.10
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m)
+    for r0 in range(0, m, 1 << 15):
+        r1 = min(m, r0 + (1 << 15))
+        dev.synth(r0, seed, th[r0:r1], tm[r0:r1], tmi[r0:r1])
+    descs = capi.row_descs(beta, eaf)
+
+    def run(rows, row0=0, mode=capi.MODE_FUSED, want_stats=False):
+        sc = capi.Scorer(n, capi.make_params())
+        sc.score_cohort(dev, rows, row0, mode)
+        stats = sc.flush() if want_stats else None
+        part = torch.empty(n, dtype=torch.float64, device="cuda")
+        nloci = sc.partial_device(part.data_ptr())
+        sc.close()
+        return part, nloci, stats
+
+    whole, nloci, stats = run(descs, want_stats=True)
+    assert nloci == m
+    over = stats["reason"] == capi.REASON_MAXMIS
+    assert int(over.sum()) == m // 1000 and bool(over[::1000].all())
+    assert int(stats["used"].sum()) == m
+    # spot rows: the oracle's generator over the full width
+    for j in (0, 1000, 499_999, 999_999):
+        codes = refcpu.synth_rows(n, j, 1, seed, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
+        c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
+        code = (c[:, 0] + 2 * c[:, 1])[:n]
+        assert int((code == 2).sum()) == int(stats["nmissing"][j])
+        assert int((code == 1).sum() + 2 * (code == 3).sum()) == int(stats["neffect"][j])
+        assert int(stats["ngenotyped"][j]) + int(stats["nmissing"][j]) == n
+    # the first 16 samples over all rows, on the CPU
+    codes16 = refcpu.synth_rows(16, 0, m, seed, th, tm, tmi)[:, 0]
+    nmiss = stats["nmissing"].astype(np.float64)
+    ngen = float(n) - nmiss
+    imp = np.where(ngen >= 100.0, stats["neffect"] / np.maximum(ngen, 1.0), eaf * 2.0)  # :470-477
+    locus = (nmiss / float(n)) > 0.05                                                     # :565-566
+    expect = np.empty(16)
+    for i in range(16):
+        code = (codes16 >> np.uint32(2 * i)) & np.uint32(3)
+        d = np.choose(code, [np.zeros(m), np.ones(m), imp, np.full(m, 2.0)])
+        d = np.where(locus, eaf * 2.0, d)                                                 # :417-447
+        expect[i] = np.cumsum(d * beta)[-1] / (2.0 * m)                                   # :639-645
+    got = (whole[:16] / (2.0 * nloci)).cpu().numpy()
+    scale = float(np.sum(np.abs(beta))) / (2.0 * m)
+    assert np.max(np.abs(got - expect)) <= 1e-12 * scale
+    # the two HIP paths agree for every sample
+    twopass, nloci2, _ = run(descs, mode=capi.MODE_TWOPASS)
+    assert nloci2 == m
+    assert float((whole - twopass).abs().max()) <= 1e-12 * float(np.sum(np.abs(beta)))
+    del twopass
+    # exact scaling
+    doubled, _, _ = run(capi.row_descs(2.0 * beta, eaf))
+    assert bool(torch.equal(doubled, 2.0 * whole))
+    del doubled
+    # row halves
+    h = m // 2
+    lo, nlo, _ = run(descs[:h])
+    hi, nhi, _ = run(descs[h:], row0=h)
+    assert nlo + nhi == m
+    assert float((lo + hi - whole).abs().max()) <= 1e-12 * float(np.sum(np.abs(beta)))
+    dev.close()
+
+
 # ------------------------------------------------------------------------------------------
 # FORMAT/DS (float32 dosage) path -- build-defined extension, oracle = ref_row_ds
 def make_ds_cohort(n, m, seed, rng):
@@ -560,6 +643,56 @@ def test_ds_fused_all_imputation_modes(pk):
     assert nloci == ref_nloci
     assert_ds_stats(stats, ref_stats)
     assert rel_err(scores, ref_scores, sub["beta"], max(nloci, 1)) <= REL_TOL
+
+
+def test_ds_large_fused_equals_twopass_and_scaling():
+    """BASELINE.json configs[4] shape (200 000 samples, FORMAT/DS float32, missing rate U(0,0.10) so about
+    half the rows exceed --maxmis) on 65 536 rows (52 GB): the single-read fused DS kernel and the
+    two-pass DS kernels must agree for every sample and every row decision; scaling beta by 2 scales
+    the sums exactly; one row's tally is recounted by the oracle's generator."""
+    import torch
+    n, m, seed = 200_000, 65_536, 20250105
+    free, _total = torch.cuda.mem_get_info()
+    if free < 70 * (1 << 30):
+        pytest.skip("needs 70 GB of free HBM")
+    rng = np.random.default_rng(seed)
+    beta = np.round(rng.normal(0.0, 0.02, m), 4)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.10, m)
+    rie = (rng.uniform(size=m) < 0.3).astype(np.int32)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_DS32)
+    for r0 in range(0, m, 1 << 14):
+        r1 = min(m, r0 + (1 << 14))
+        dev.synth(r0, seed, th[r0:r1], tm[r0:r1], tmi[r0:r1])
+
+    def run(b, mode):
+        sc = capi.Scorer(n, capi.make_params(imp_locus="ps"))
+        sc.score_cohort(dev, capi.row_descs(b, eaf, None, rie), 0, mode)
+        stats = sc.flush()
+        part = torch.empty(n, dtype=torch.float64, device="cuda")
+        nloci = sc.partial_device(part.data_ptr())
+        sc.close()
+        return part, nloci, stats
+
+    fused, nloci, st_f = run(beta, capi.MODE_FUSED)
+    twop, nloci2, st_t = run(beta, capi.MODE_TWOPASS)
+    assert nloci == nloci2 == m
+    for k in ("ngenotyped", "nmissing", "used", "reason"):
+        assert np.array_equal(st_f[k], st_t[k]), k
+    assert np.max(np.abs(st_f["neffect"] - st_t["neffect"]) / np.maximum(1.0, np.abs(st_t["neffect"]))) <= 1e-9
+    over = int((st_f["reason"] == capi.REASON_MAXMIS).sum())
+    assert 0.35 * m < over < 0.65 * m
+    scale = float(np.sum(np.abs(beta)))
+    assert float((fused - twop).abs().max()) <= 1e-9 * scale
+    doubled, _, _ = run(2.0 * beta, capi.MODE_FUSED)
+    assert bool(torch.equal(doubled, 2.0 * fused))
+    j = 4242
+    row = refcpu.synth_rows_ds(n, j, 1, seed, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])[0]
+    assert int(np.isnan(row).sum()) == int(st_f["nmissing"][j])
+    dose = np.where(rie[j], 2.0 - row.astype(np.float64), row.astype(np.float64))
+    assert abs(float(np.nansum(dose)) - float(st_f["neffect"][j])) <= 1e-9 * float(np.nansum(dose))
+    dev.close()
 
 
 def test_row_sharded_partial_sums_and_normalise():
