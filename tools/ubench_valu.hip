@@ -188,6 +188,26 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned int 
             S(3) S(7)
 #undef S
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (OP == 50) {  // is the front end (bytes fetched) or the VALU the limit?  v_bfi (8 B) + s_mov (4 B)
+#define S(i) asm volatile("v_bfi_b32 %0, %1, %0, %2\n\ts_mov_b32 s40, s41" : "+v"(r[i]) : "s"(sm), "v"(r[(i + 1) & 7]) : "s40");
+            REP32(S)
+#undef S
+        } else if (OP == 51) {  // v_bfi (8 B) + 2 x s_mov (8 B)
+#define S(i) asm volatile("v_bfi_b32 %0, %1, %0, %2\n\ts_mov_b32 s40, s41\n\ts_mov_b32 s42, s43" : "+v"(r[i]) : "s"(sm), "v"(r[(i + 1) & 7]) : "s40", "s42");
+            REP32(S)
+#undef S
+        } else if (OP == 52) {  // s_mov alone
+#define S(i) asm volatile("s_mov_b32 s40, s41" ::: "s40");
+            REP32(S)
+#undef S
+        } else if (OP == 53) {  // v_bfi + s_waitcnt (4 B, no-op wait)
+#define S(i) asm volatile("v_bfi_b32 %0, %1, %0, %2\n\ts_waitcnt lgkmcnt(15)" : "+v"(r[i]) : "s"(sm), "v"(r[(i + 1) & 7]));
+            REP32(S)
+#undef S
+        } else if (OP == 54) {  // v_bfi with a 32-bit literal (12 B)
+#define S(i) asm volatile("v_and_b32 %0, 0x12345678, %0" : "+v"(r[i]));
+            REP32(S)
+#undef S
         } else if (OP == 22) {  // the fused mix: sdwa + ds_read_b64 + v_add_f64
 #define S(i)                                                                                          \
     asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "  \
@@ -266,6 +286,11 @@ int main() {
     run<31>("8 random lookups + 32 v_bfi + wait (per block)", 1, d_out, d_sink, cus);
     run<32>("8 conflict-free lookups + 32 v_bfi + wait (per block)", 1, d_out, d_sink, cus);
     run<30>("half the waves 32 v_bfi, half 8 random lookups (per block)", 1, d_out, d_sink, cus);
+    run<52>("s_mov_b32 alone", 32, d_out, d_sink, cus);
+    run<50>("v_bfi_b32 + s_mov_b32 (per pair)", 32, d_out, d_sink, cus);
+    run<51>("v_bfi_b32 + 2 s_mov_b32 (per triple)", 32, d_out, d_sink, cus);
+    run<53>("v_bfi_b32 + s_waitcnt (per pair)", 32, d_out, d_sink, cus);
+    run<54>("v_and_b32_e32 with a literal (8 bytes)", 32, d_out, d_sink, cus);
     run<40>("8 random 8-byte global gathers, 2 KiB table (per block of 8)", 1, d_out, d_sink, cus);
     run<42>("6 random LDS lookups (per block)", 1, d_out, d_sink, cus);
     run<43>("2 global gathers (per block)", 1, d_out, d_sink, cus);
