@@ -169,8 +169,8 @@ int nps_push_bed(nps_ctx *ctx, const uint8_t *bed_row, int effect_is_a1, int ref
  * n_samples float32 ALT dosages, NaN = missing; ref_is_effect -> dosage = 2 - DS. */
 int nps_push_ds(nps_ctx *ctx, const float *ds, int ref_is_effect, double beta, double eaf);
 
-/* PRESENT row already in the device layout: ceil(n_samples/16) little-endian uint32, sample i
- * in bits 2*(i%16).. of word i/16; codes NPS_CODE_*: 0 = dosage 0, 1 = dosage 1, 3 = dosage 2,
+/* PRESENT row already as 2-bit codes: ceil(n_samples/16) little-endian uint32, sample i
+ * in bits 2*(i%16).. of word i/16 (the library re-orders the bits of a word for its own layout); codes NPS_CODE_*: 0 = dosage 0, 1 = dosage 1, 3 = dosage 2,
  * 2 = missing (so that popcount(word) = effect alleles + missing samples); padding bits zero.
  * `row` is a host pointer. */
 int nps_push_packed(nps_ctx *ctx, const uint32_t *row, int ref_is_effect, double beta, double eaf);
