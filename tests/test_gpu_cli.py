@@ -131,3 +131,68 @@ def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
         assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
         assert a.stdout == b.stdout
         assert len(a.stdout.splitlines()) >= n
+
+
+def test_config2_wood_height_on_100k_sample_bcf(tmp_path):
+    """BASELINE.json configs[1] at its full size: scores/wood-25282103-height.scores (697 loci, 188 of
+    them with the REF allele as effect allele) on a synthetic 100 000-sample BCF2 (+CSI) written by
+    tests/bcfwriter.py -- HWE genotypes at the row's eaf, per-row missing rate U(0, 0.02), a few loci
+    absent or FILTER-failed -- through the `nimpress` command line (CSI random access per locus, the
+    record's int8 GT vector decoded on the device), against the oracle fed with the same arrays.
+    Prints the end-to-end wall time of the command (host decode dominates; not asserted)."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bcfwriter
+    n, seed = 100_000, 20250102
+    wood = os.path.join(G, "scores", "wood-25282103-height.scores")
+    score = refcpu.read_score_file(wood)
+    rng = np.random.default_rng(seed)
+    samples = ["S%06d" % i for i in range(n)]
+    contigs, recs, truth = [], [], []
+    def ckey(e):
+        return ((0, int(e.contig)) if e.contig.isdigit() else (1, e.contig)), e.pos
+    for j, e in enumerate(sorted(score.entries, key=ckey)):
+        if e.contig not in contigs:
+            contigs.append(e.contig)
+        if j % 41 == 7:
+            truth.append((e, None, None))                 # absent from the file
+            continue
+        rie = e.easeq == e.refseq
+        alt = e.easeq if not rie else next(b for b in "ACGT" if b != e.refseq[0])
+        p_alt = (1.0 - e.eaf) if rie else e.eaf           # eaf is the frequency of the EFFECT allele
+        p_alt = min(max(p_alt, 0.0), 1.0)
+        a = (rng.uniform(size=(n, 2)) < p_alt).astype(np.int64)
+        gts = (a + 1) << 1                                # bcf GT encoding, unphased
+        gts[rng.uniform(size=n) < rng.uniform(0.0, 0.02)] = 0   # both alleles missing
+        filt = ["FAIL"] if j % 53 == 11 else (["PASS"] if j % 2 else [])
+        recs.append(dict(contig=e.contig, pos=e.pos, id=".", ref=e.refseq, alts=[alt], filters=filt, gts=gts))
+        truth.append((e, gts.astype(np.int32), filt))
+    path = str(tmp_path / "cohort.bcf")
+    bcfwriter.write_bcf(path, contigs, samples, recs, gt_dtype=np.int8)
+    t0 = time.perf_counter()
+    r = subprocess.run([CLI, "--afmisp=0", wood, path], capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split("\t") for l in r.stdout.splitlines() if not l.startswith(("WARN ", "FATAL "))]
+    assert [x[0] for x in rows] == samples
+    got = np.array([float(x[1]) for x in rows])
+    # the oracle, in score-file order, with the reference's early returns
+    by_entry = {id(e): (g, f) for e, g, f in truth}
+    sc = refcpu.RefScorer(n, refcpu.make_params())        # CLI defaults
+    for e in score.entries:
+        g, f = by_entry[id(e)]
+        rie = e.easeq == e.refseq
+        if g is None:
+            sc.row_locus(2, rie, e.beta, e.eaf)           # absent
+        elif f == ["FAIL"]:
+            sc.row_locus(3, rie, e.beta, e.eaf)           # FILTER
+        else:
+            sc.row_gt(g.reshape(-1), 2, 0 if rie else 1, rie, e.beta, e.eaf)
+    ref, nloci = sc.finish(score.offset)
+    assert nloci == len(score.entries)
+    scale = float(np.sum(np.abs([e.beta for e in score.entries]))) / (2.0 * nloci)
+    assert np.max(np.abs(got - ref)) <= 1e-6 * max(float(np.max(np.abs(ref))), 1e-12 * scale)
+    n_rec = len(recs)
+    print("\n[config 2] nimpress on a 100000-sample BCF, %d loci (%d records, %.0f MB of int8 GT): %.2f s end to end "
+          "= %.3g genotypes/s" % (len(score.entries), n_rec, n_rec * n * 2 / 1e6, wall, n_rec * n / wall))
