@@ -52,7 +52,7 @@ def build_libnps(force: bool = False, verbose: bool = False) -> str:
 HOST_DIR = os.path.join(CSRC, "host")
 LIBHOST = os.path.join(PKG_DIR, "libnimpress_host.so")
 CLI = os.path.join(PKG_DIR, "nimpress")
-GXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off"]
+GXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wextra", "-ffp-contract=off"]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> List[str]:

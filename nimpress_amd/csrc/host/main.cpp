@@ -151,7 +151,10 @@ int cliMain(int argc, char **argv) {
         {
             std::string err;
             try {
-                vcf_ok = vcf.open(positional[1], score_ok ? &scoreFile.entries : nullptr);
+                // indexed files (vcf.gz + .tbi, BCF + .csi) are streamed window by window of score
+                // rows; anything else is read whole, keeping the records of the score's loci
+                vcf_ok = vcf.openStreaming(positional[1]) ||
+                         vcf.open(positional[1], score_ok ? &scoreFile.entries : nullptr);
             } catch (const std::exception &ex) {
                 err = ex.what();
             }

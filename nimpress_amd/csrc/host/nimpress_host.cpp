@@ -15,6 +15,7 @@
 #include <limits>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 #include "../../../include/nps.h"
@@ -894,13 +895,188 @@ static void bcfReadHeader(const unsigned char *p, size_t n, BcfHeader &h, size_t
 
 }  // namespace
 
+// ---- indexed sources: vcf.gz + .tbi and BCF + .csi ------------------------------------------------
+// What hts-nim's vcf.query() (nim:358) needs: the header and the index.  Records are fetched per set
+// of score rows; every fetching thread inflates through a BGZF handle of its own.
+struct IndexedSource {
+    std::string path;
+    bool is_bcf = false;
+    BcfHeader bcf;
+    std::unordered_map<std::string, size_t> bcf_contig;
+    CsiIndex csi;
+    TabixIndex tbi;
+    size_t n_samples = 0;
+};
+
+namespace {
+
+static unsigned hostThreads(size_t work_items) {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 4;
+    t = std::min(t, 16u);
+    if (const char *e = getenv("NIMPRESS_THREADS"))
+        if (atoi(e) > 0) t = (unsigned)atoi(e);
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(t, work_items / 4 + 1));
+}
+
+// records overlapping entries [first, first+count), keyed by virtual offset (= file order)
+static void fetchRange(const IndexedSource &src, const ScoreEntry *first, size_t count,
+                       std::map<uint64_t, Variant> &found) {
+    BgzfFile bg;
+    if (!bg.open(src.path)) throw std::runtime_error("cannot open " + src.path);
+    RegionMap wanted;
+    for (size_t i = 0; i < count; ++i) wanted[first[i].contig].emplace_back(first[i].pos, first[i].stop());
+    std::vector<unsigned char> buf;
+    std::vector<int32_t> tmp;
+    std::string line;
+    for (size_t i = 0; i < count; ++i) {
+        const ScoreEntry &e = first[i];
+        if (src.is_bcf) {
+            auto ci = src.bcf_contig.find(e.contig);
+            if (ci == src.bcf_contig.end()) continue;
+            for (const auto &chunk : src.csi.query(ci->second, e.pos - 1, e.stop())) {
+                uint64_t v = chunk.first;
+                while (v < chunk.second) {
+                    const uint64_t at = v;
+                    uint32_t ls[2];
+                    if (!bg.readBytes(&v, ls, 8)) break;
+                    buf.resize((size_t)ls[0] + ls[1]);
+                    if (!bg.readBytes(&v, buf.data(), buf.size())) throw std::runtime_error("truncated BCF record");
+                    if (found.count(at) || ls[0] < 24) continue;
+                    int32_t chrom, pos0;
+                    memcpy(&chrom, buf.data(), 4);
+                    memcpy(&pos0, buf.data() + 4, 4);
+                    if ((size_t)chrom != ci->second) continue;
+                    if ((int64_t)pos0 + 1 > e.stop()) break;  // position sorted inside a contig
+                    Variant var;
+                    if (parseBcfRecord(buf.data(), ls[0], buf.data() + ls[0], ls[1], src.bcf, &wanted, var))
+                        found.emplace(at, std::move(var));
+                }
+            }
+        } else {
+            for (const auto &chunk : src.tbi.query(e.contig, e.pos - 1, e.stop())) {
+                uint64_t v = chunk.first;
+                while (v < chunk.second) {
+                    const uint64_t at = v;
+                    if (!bg.readLine(&v, line)) break;
+                    if (line.empty() || line[0] == '#') continue;
+                    if (found.count(at)) continue;
+                    // cheap pre-check of CHROM and POS before the full parse
+                    const size_t t1 = line.find('\t');
+                    const size_t t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1);
+                    if (t2 == std::string::npos) continue;
+                    if (line.compare(0, t1, e.contig) != 0) continue;
+                    const int64_t pos = parseIntNim(line.substr(t1 + 1, t2 - t1 - 1));
+                    if (pos > e.stop()) break;  // records are position sorted inside a contig
+                    Variant var;
+                    if (parseRecordLine(line.data(), line.size(), src.n_samples, &wanted, tmp, var))
+                        found.emplace(at, std::move(var));
+                }
+            }
+        }
+    }
+}
+
+static std::vector<Variant> fetchParallel(const IndexedSource &src, const ScoreEntry *first, size_t count) {
+    const unsigned nt = hostThreads(count);
+    std::vector<std::map<uint64_t, Variant>> parts(nt);
+    if (nt <= 1) {
+        fetchRange(src, first, count, parts[0]);
+    } else {
+        std::vector<std::thread> th;
+        std::vector<std::exception_ptr> err(nt);
+        const size_t per = (count + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t a = std::min(count, (size_t)t * per), b = std::min(count, a + per);
+            th.emplace_back([&, t, a, b]() {
+                try {
+                    if (b > a) fetchRange(src, first + a, b - a, parts[t]);
+                } catch (...) {
+                    err[t] = std::current_exception();
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
+    }
+    std::map<uint64_t, Variant> &all = parts[0];
+    for (unsigned t = 1; t < nt; ++t)
+        for (auto &kv : parts[t]) all.emplace(kv.first, std::move(kv.second));  // duplicates: first wins
+    std::vector<Variant> out;
+    out.reserve(all.size());
+    for (auto &kv : all) out.push_back(std::move(kv.second));
+    return out;
+}
+
+// header + index of an indexed file, or null
+static std::shared_ptr<IndexedSource> openIndexed(const std::string &path, std::vector<std::string> &samples) {
+    if (getenv("NIMPRESS_NO_INDEX")) return nullptr;
+    auto src = std::make_shared<IndexedSource>();
+    src->path = path;
+    {  // BCF + CSI
+        BgzfFile bg;
+        if (bg.open(path)) {
+            uint64_t voff = 0;
+            unsigned char magic[9];
+            if (bg.readBytes(&voff, magic, 9) && memcmp(magic, "BCF\2", 4) == 0 && src->csi.load(path + ".csi")) {
+                uint32_t l_text;
+                memcpy(&l_text, magic + 5, 4);
+                std::string text(l_text, '\0');
+                if (!bg.readBytes(&voff, &text[0], l_text)) throw std::runtime_error("truncated BCF header");
+                src->bcf.parse(text);
+                src->is_bcf = true;
+                samples = src->bcf.samples;
+                for (size_t k = 0; k < src->bcf.contigs.size(); ++k) src->bcf_contig[src->bcf.contigs[k]] = k;
+                src->n_samples = samples.size();
+                return src;
+            }
+        }
+    }
+    {  // vcf.gz + tabix
+        BgzfFile bg;
+        if (src->tbi.load(path + ".tbi") && bg.open(path)) {
+            uint64_t voff = 0;
+            std::string line;
+            while (bg.readLine(&voff, line)) {  // header lines
+                if (line.empty()) continue;
+                if (line[0] != '#') break;
+                if (line.compare(0, 6, "#CHROM") == 0) {
+                    const std::vector<std::string> cols = splitChar(line, '\t');
+                    samples.clear();
+                    for (size_t k = 9; k < cols.size(); ++k) samples.push_back(cols[k]);
+                    src->n_samples = samples.size();
+                    return src;
+                }
+            }
+        }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+bool VCF::openStreaming(const std::string &path) {
+    samples.clear();
+    records.clear();
+    source = openIndexed(path, samples);
+    indexed = streaming = source != nullptr;
+    return streaming;
+}
+
+std::vector<Variant> VCF::fetch(const ScoreEntry *first, size_t count) const {
+    if (!source) throw std::runtime_error("VCF::fetch needs an indexed file");
+    return fetchParallel(*source, first, count);
+}
+
 // open(): text VCF, plain or gzip/BGZF.  With `keep` and a tabix index next to a BGZF file
 // (path + ".tbi") only the index chunks overlapping the score loci are inflated -- the random
 // access hts-nim's vcf.query() performs (nim:358); otherwise the whole file is scanned.
 bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
     samples.clear();
     records.clear();
-    indexed = false;
+    indexed = streaming = false;
+    source.reset();
     RegionMap wanted;
     if (keep)
         for (const ScoreEntry &e : *keep) wanted[e.contig].emplace_back(e.pos, e.stop());
@@ -981,99 +1157,14 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
         }
         if (f) fclose(f);
     }
-    if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // BCF + CSI
-        CsiIndex csi;
-        BgzfFile bg;
-        if (bg.open(path)) {
-            uint64_t voff = 0;
-            unsigned char magic[9];
-            if (bg.readBytes(&voff, magic, 9) && memcmp(magic, "BCF\2", 4) == 0 && csi.load(path + ".csi")) {
-                uint32_t l_text;
-                memcpy(&l_text, magic + 5, 4);
-                std::string text(l_text, '\0');
-                if (!bg.readBytes(&voff, &text[0], l_text)) throw std::runtime_error("truncated BCF header");
-                BcfHeader h;
-                h.parse(text);
-                samples = h.samples;
-                std::unordered_map<std::string, size_t> ctg;
-                for (size_t k = 0; k < h.contigs.size(); ++k) ctg[h.contigs[k]] = k;
-                std::map<uint64_t, Variant> found;  // by virtual offset: file order
-                std::vector<unsigned char> buf;
-                for (const ScoreEntry &e : *keep) {
-                    auto ci = ctg.find(e.contig);
-                    if (ci == ctg.end()) continue;
-                    for (const auto &chunk : csi.query(ci->second, e.pos - 1, e.stop())) {
-                        uint64_t v = chunk.first;
-                        while (v < chunk.second) {
-                            const uint64_t at = v;
-                            uint32_t ls[2];
-                            if (!bg.readBytes(&v, ls, 8)) break;
-                            buf.resize((size_t)ls[0] + ls[1]);
-                            if (!bg.readBytes(&v, buf.data(), buf.size())) throw std::runtime_error("truncated BCF record");
-                            if (found.count(at) || ls[0] < 24) continue;
-                            int32_t chrom, pos0;
-                            memcpy(&chrom, buf.data(), 4);
-                            memcpy(&pos0, buf.data() + 4, 4);
-                            if ((size_t)chrom != ci->second) continue;
-                            if ((int64_t)pos0 + 1 > e.stop()) break;  // position sorted inside a contig
-                            Variant var;
-                            if (parseBcfRecord(buf.data(), ls[0], buf.data() + ls[0], ls[1], h, &wanted, var))
-                                found.emplace(at, std::move(var));
-                        }
-                    }
-                }
-                for (auto &kv : found) records.push_back(std::move(kv.second));
-                indexed = true;
-                return true;
-            }
+    if (keep) {  // vcf.gz + .tbi / BCF + .csi: only the chunks of the wanted loci are inflated
+        source = openIndexed(path, samples);
+        if (source) {
+            records = fetchParallel(*source, keep->data(), keep->size());
+            indexed = true;
+            return true;
         }
-    }
-    if (keep && !getenv("NIMPRESS_NO_INDEX")) {  // vcf.gz + tabix
-        TabixIndex tbi;
-        BgzfFile bg;
-        if (tbi.load(path + ".tbi") && bg.open(path)) {
-            uint64_t voff = 0;
-            std::string line;
-            bool have_header = false;
-            while (bg.readLine(&voff, line)) {  // header lines
-                if (line.empty()) continue;
-                if (line[0] != '#') break;
-                if (line.compare(0, 6, "#CHROM") == 0) {
-                    const std::vector<std::string> cols = splitChar(line, '\t');
-                    for (size_t k = 9; k < cols.size(); ++k) samples.push_back(cols[k]);
-                    have_header = true;
-                    break;
-                }
-            }
-            if (have_header) {
-                std::map<uint64_t, Variant> found;  // by virtual offset of the line: file order
-                for (const ScoreEntry &e : *keep) {
-                    for (const auto &chunk : tbi.query(e.contig, e.pos - 1, e.stop())) {
-                        uint64_t v = chunk.first;
-                        while (v < chunk.second) {
-                            const uint64_t at = v;
-                            if (!bg.readLine(&v, line)) break;
-                            if (line.empty() || line[0] == '#') continue;
-                            if (found.count(at)) continue;
-                            // cheap pre-check of CHROM and POS before the full parse
-                            const size_t t1 = line.find('\t');
-                            const size_t t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1);
-                            if (t2 == std::string::npos) continue;
-                            if (line.compare(0, t1, e.contig) != 0) continue;
-                            const int64_t pos = parseIntNim(line.substr(t1 + 1, t2 - t1 - 1));
-                            if (pos > e.stop()) break;  // records are position sorted inside a contig
-                            Variant var;
-                            if (parseRecordLine(line.data(), line.size(), samples.size(), &wanted, tmp, var))
-                                found.emplace(at, std::move(var));
-                        }
-                    }
-                }
-                for (auto &kv : found) records.push_back(std::move(kv.second));
-                indexed = true;
-                return true;
-            }
-            samples.clear();
-        }
+        samples.clear();
     }
 
     std::string raw;
@@ -1161,24 +1252,65 @@ int32_t Variant::gtValue(size_t i) const {
     }
 }
 
+// nim:359-363 for one record that overlaps the query
+static bool variantMatches(const Variant &v, const std::string &refseq, const std::string &easeq) {
+    if (v.is_bed) {  // no REF in a .bim: the row's two alleles must be the variant's two alleles
+        const std::string &a1 = v.alt[0], &a2 = v.ref;
+        return (refseq == a2 && (easeq == a1 || easeq == a2)) || (refseq == a1 && (easeq == a1 || easeq == a2));
+    }
+    if (v.ref != refseq) return false;  // nim:359 -- POS itself is never compared
+    if (easeq == refseq) return true;
+    for (const std::string &a : v.alt)
+        if (a == easeq) return true;
+    return false;
+}
+static int64_t variantLen(const Variant &v) {
+    return (int64_t)(v.is_bed ? std::max(v.ref.size(), v.alt[0].size()) : v.ref.size());
+}
+
 const Variant *findVariant(const std::string &contig, int64_t pos, const std::string &refseq,
                            const std::string &easeq, const VCF &vcf) {
     const int64_t stop = pos + (int64_t)refseq.size() - 1;
     for (const Variant &v : vcf.records) {  // file order = the order a region query returns
         if (v.contig != contig) continue;
-        const size_t vlen = v.is_bed ? std::max(v.ref.size(), v.alt[0].size()) : v.ref.size();
-        const int64_t vend = v.pos + (int64_t)vlen - 1;
+        const int64_t vend = v.pos + variantLen(v) - 1;
         if (v.pos > stop || vend < pos) continue;
-        if (v.is_bed) {  // no REF in a .bim: the row's two alleles must be the variant's two alleles
-            const std::string &a1 = v.alt[0], &a2 = v.ref;
-            if ((refseq == a2 && (easeq == a1 || easeq == a2)) || (refseq == a1 && (easeq == a1 || easeq == a2)))
-                return &v;
-            continue;
-        }
-        if (v.ref != refseq) continue;  // nim:359 -- POS itself is never compared
-        if (easeq == refseq) return &v;
-        for (const std::string &a : v.alt)
-            if (a == easeq) return &v;
+        if (variantMatches(v, refseq, easeq)) return &v;
+    }
+    return nullptr;
+}
+
+void RecordIndex::build(const std::vector<Variant> &recs) {
+    contigs.clear();
+    records = &recs;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        Contig &c = contigs[recs[i].contig];
+        if (!c.ids.empty() && recs[c.ids.back()].pos > recs[i].pos) c.sorted = false;
+        c.ids.push_back((uint32_t)i);
+        c.maxlen = std::max(c.maxlen, variantLen(recs[i]));
+    }
+}
+
+const Variant *RecordIndex::find(const std::string &contig, int64_t pos, const std::string &refseq,
+                                 const std::string &easeq) const {
+    auto ci = contigs.find(contig);
+    if (ci == contigs.end()) return nullptr;
+    const Contig &c = ci->second;
+    const std::vector<Variant> &recs = *records;
+    const int64_t stop = pos + (int64_t)refseq.size() - 1;
+    size_t a = 0, b = c.ids.size();
+    if (c.sorted) {  // candidates start at pos - maxlen + 1 .. stop; the first match in file order wins
+        const int64_t lo = pos - c.maxlen + 1;
+        a = (size_t)(std::lower_bound(c.ids.begin(), c.ids.end(), lo,
+                                      [&](uint32_t id, int64_t x) { return recs[id].pos < x; }) - c.ids.begin());
+        b = (size_t)(std::upper_bound(c.ids.begin(), c.ids.end(), stop,
+                                      [&](int64_t x, uint32_t id) { return x < recs[id].pos; }) - c.ids.begin());
+    }
+    for (size_t k = a; k < b; ++k) {
+        const Variant &v = recs[c.ids[k]];
+        const int64_t vend = v.pos + variantLen(v) - 1;
+        if (v.pos > stop || vend < pos) continue;
+        if (variantMatches(v, refseq, easeq)) return &v;
     }
     return nullptr;
 }
@@ -1338,51 +1470,73 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
     struct Pushed {
         const ScoreEntry *e;
         int how;  // 0 = genotyped on the device, else nps_row_kind
-        const Variant *v;
+        std::string filter;       // FILTER of the record (for the warning text)
         std::string pre_warning;  // emitted before the device result is known (coverage contig)
     };
     std::vector<Pushed> pushed;
     pushed.reserve(scoreFile.entries.size());
     try {
-        for (const ScoreEntry &e : scoreFile.entries) {
-            const int rie = e.refseq == e.easeq ? 1 : 0;
-            Pushed rec{&e, 0, nullptr, ""};
-            if (restrictToCoveredRgns && !isVariantCovered(e, coveredIvals, &rec.pre_warning)) {
-                rec.how = NPS_ROW_UNCOVERED;  // nim:526-531
-                npsCheck(nps_push_locus(ctx, NPS_ROW_UNCOVERED, rie, e.beta, e.eaf), "nps_push_locus");
-            } else {
-                const Variant *v = findVariant(e.contig, e.pos, e.refseq, e.easeq, genotypeVcf);
-                rec.v = v;
-                if (!v) {  // nim:536-551
-                    rec.how = NPS_ROW_ABSENT;
-                    npsCheck(nps_push_locus(ctx, NPS_ROW_ABSENT, rie, e.beta, e.eaf), "nps_push_locus");
-                } else if (!ignoreFilterField && v->filter != "." && v->filter != "PASS") {  // :553
-                    rec.how = NPS_ROW_FILTERED;
-                    npsCheck(nps_push_locus(ctx, NPS_ROW_FILTERED, rie, e.beta, e.eaf), "nps_push_locus");
-                } else {
-                    int eaidx = 0;  // nim:375-379
-                    if (!rie) {
-                        eaidx = -1;
-                        for (size_t k = 0; k < v->alt.size(); ++k)
-                            if (v->alt[k] == e.easeq) {
-                                eaidx = (int)k + 1;
-                                break;
-                            }
-                    }
-                    if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
-                        npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0, rie, e.beta,
-                                              e.eaf),
-                                 "nps_push_bed");
-                    else if (v->gt_bytes == 4 && v->gt_raw.empty())
-                        npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
-                                 "nps_push_gt");
-                    else  // the BCF record's own int8 / int16 vector: widened on the device
-                        npsCheck(nps_push_gt_raw(ctx, v->gtData(), v->gt_bytes, v->ploidy, eaidx, rie,
-                                                 e.beta, e.eaf),
-                                 "nps_push_gt_raw");
-                }
+        // Score rows are pushed in file order.  Streaming sources (indexed files opened with
+        // openStreaming) hand over the records of one window of rows at a time -- fetched by several
+        // threads, pushed, dropped -- so the host holds window x samples genotypes, not loci x samples.
+        const std::vector<ScoreEntry> &entries = scoreFile.entries;
+        size_t window = entries.size();
+        if (genotypeVcf.streaming) {
+            const size_t per_row = (size_t)std::max<int64_t>(nsamples, 1) * 8;  // diploid int32 at most
+            window = std::min<size_t>(std::max<size_t>((512u << 20) / per_row, 64), 8192);
+            if (const char *w = getenv("NIMPRESS_WINDOW"))
+                if (atoi(w) > 0) window = (size_t)atoi(w);
+        }
+        std::vector<Variant> fetched;
+        RecordIndex index;
+        if (!genotypeVcf.streaming) index.build(genotypeVcf.records);
+        for (size_t w0 = 0; w0 < entries.size(); w0 += window) {
+            const size_t w1 = std::min(entries.size(), w0 + window);
+            if (genotypeVcf.streaming) {
+                fetched = genotypeVcf.fetch(entries.data() + w0, w1 - w0);
+                index.build(fetched);
             }
-            pushed.push_back(std::move(rec));
+            for (size_t j = w0; j < w1; ++j) {
+                const ScoreEntry &e = entries[j];
+                const int rie = e.refseq == e.easeq ? 1 : 0;
+                Pushed rec{&e, 0, "", ""};
+                if (restrictToCoveredRgns && !isVariantCovered(e, coveredIvals, &rec.pre_warning)) {
+                    rec.how = NPS_ROW_UNCOVERED;  // nim:526-531
+                    npsCheck(nps_push_locus(ctx, NPS_ROW_UNCOVERED, rie, e.beta, e.eaf), "nps_push_locus");
+                } else {
+                    const Variant *v = index.find(e.contig, e.pos, e.refseq, e.easeq);  // nim:533
+                    if (!v) {  // nim:536-551
+                        rec.how = NPS_ROW_ABSENT;
+                        npsCheck(nps_push_locus(ctx, NPS_ROW_ABSENT, rie, e.beta, e.eaf), "nps_push_locus");
+                    } else if (!ignoreFilterField && v->filter != "." && v->filter != "PASS") {  // :553
+                        rec.how = NPS_ROW_FILTERED;
+                        rec.filter = v->filter;
+                        npsCheck(nps_push_locus(ctx, NPS_ROW_FILTERED, rie, e.beta, e.eaf), "nps_push_locus");
+                    } else {
+                        int eaidx = 0;  // nim:375-379
+                        if (!rie) {
+                            eaidx = -1;
+                            for (size_t k = 0; k < v->alt.size(); ++k)
+                                if (v->alt[k] == e.easeq) {
+                                    eaidx = (int)k + 1;
+                                    break;
+                                }
+                        }
+                        if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
+                            npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0, rie,
+                                                  e.beta, e.eaf),
+                                     "nps_push_bed");
+                        else if (v->gt_bytes == 4 && v->gt_raw.empty())
+                            npsCheck(nps_push_gt(ctx, v->gts.data(), v->ploidy, eaidx, rie, e.beta, e.eaf),
+                                     "nps_push_gt");
+                        else  // the BCF record's own int8 / int16 vector: widened on the device
+                            npsCheck(nps_push_gt_raw(ctx, v->gtData(), v->gt_bytes, v->ploidy, eaidx, rie,
+                                                     e.beta, e.eaf),
+                                     "nps_push_gt_raw");
+                    }
+                }
+                pushed.push_back(std::move(rec));
+            }
         }
         // per-row results back, in order: emit the reference's warnings
         std::vector<nps_locus_stat> stats(pushed.size());
@@ -1407,7 +1561,7 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                              formatFloat(e.eaf));
                 break;
             case NPS_ROW_FILTERED:  // nim:554-557
-                log.warn("Variant " + var + " has a FILTER flag set (value \"" + pushed[j].v->filter +
+                log.warn("Variant " + var + " has a FILTER flag set (value \"" + pushed[j].filter +
                          "\").  Imputing all dosages at this locus.");
                 break;
             default:
@@ -1524,6 +1678,34 @@ void *nh_vcf_open(const char *path, const char *score_path_or_null) {
         return nullptr;
     }
 }
+// indexed file opened for streaming, then the records of the score's rows fetched window by window
+// (what computePolygenicScores does) and kept: the result must equal nh_vcf_open(path, score)
+void *nh_vcf_open_streaming(const char *path, const char *score_path, long window) {
+    try {
+        nh_vcf *h = new nh_vcf;
+        ScoreFile sf;
+        if (!sf.open(score_path) || !h->vcf.openStreaming(path)) {
+            delete h;
+            g_nh_error = "cannot open (no index?)";
+            return nullptr;
+        }
+        std::map<std::pair<std::string, int64_t>, Variant> all;  // windows may fetch a record twice
+        std::vector<std::pair<std::string, int64_t>> order;
+        const size_t w = window > 0 ? (size_t)window : sf.entries.size();
+        for (size_t a = 0; a < sf.entries.size(); a += w) {
+            const size_t b = std::min(sf.entries.size(), a + w);
+            for (Variant &v : h->vcf.fetch(sf.entries.data() + a, b - a)) {
+                const auto key = std::make_pair(v.contig + ":" + v.ref + ":" + (v.alt.empty() ? "" : v.alt[0]), v.pos);
+                if (all.emplace(key, std::move(v)).second) order.push_back(key);
+            }
+        }
+        for (const auto &k : order) h->vcf.records.push_back(std::move(all[k]));
+        return h;
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return nullptr;
+    }
+}
 void nh_vcf_close(void *h) { delete (nh_vcf *)h; }
 long nh_vcf_n_samples(void *h) { return (long)((nh_vcf *)h)->vcf.samples.size(); }
 int nh_vcf_indexed(void *h) { return ((nh_vcf *)h)->vcf.indexed ? 1 : 0; }
@@ -1534,6 +1716,14 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
                  int *ploidy, char *filter, long filter_cap, int *gts, long gts_cap) {
     const VCF &vcf = ((nh_vcf *)h)->vcf;
     const Variant *v = findVariant(contig, pos, ref, ea, vcf);
+    {  // the indexed lookup the score driver uses must give the same record
+        RecordIndex idx;
+        idx.build(vcf.records);
+        if (idx.find(contig, pos, ref, ea) != v) {
+            g_nh_error = "RecordIndex::find disagrees with findVariant";
+            return -99;
+        }
+    }
     if (!v) return -1;
     if (rec_pos) *rec_pos = v->pos;
     if (ploidy) *ploidy = v->ploidy;
@@ -1561,7 +1751,8 @@ long nh_compute(const char *score_path, const char *vcf_path, const char *bed_pa
             return -1;
         }
         VCF vcf;
-        if (!vcf.open(vcf_path, &sf.entries)) {
+        const bool stream = getenv("NIMPRESS_STREAM") != nullptr;  // the command line always streams
+        if (!((stream && vcf.openStreaming(vcf_path)) || vcf.open(vcf_path, &sf.entries))) {
             g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
             return -1;
         }

@@ -10,6 +10,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -77,20 +78,47 @@ struct Variant {
     int32_t gtValue(size_t i) const;  // element i widened like bcf_get_genotypes does
 };
 
+struct IndexedSource;  // header + tabix / CSI index of an indexed file (nimpress_host.cpp)
+
 struct VCF {
     std::vector<std::string> samples;
     std::vector<Variant> records;  // file order
     bool indexed = false;          // records were fetched through the tabix / CSI index
-    // open(): text VCF (plain or gzip/BGZF; CRLF tolerant) or BCF2 (BGZF).  If `keep` is non-null
-    // only records overlapping one of its loci are retained (memory = loci x samples); with an index
-    // next to the file (.tbi for vcf.gz, .csi for BCF) only the chunks of those loci are inflated.
+    // non-null for vcf.gz + .tbi and BCF + .csi: what hts-nim's vcf.query() needs (nim:358)
+    std::shared_ptr<IndexedSource> source;
+    // streaming: `records` stays empty and computePolygenicScores fetches the records of a window of
+    // score rows at a time (memory = window x samples instead of loci x samples)
+    bool streaming = false;
+    // open(): text VCF (plain or gzip/BGZF; CRLF tolerant), BCF2 (BGZF) or a PLINK 1 fileset.  If
+    // `keep` is non-null only records overlapping one of its loci are retained (memory = loci x
+    // samples); with an index next to the file (.tbi for vcf.gz, .csi for BCF) only the chunks of
+    // those loci are inflated, by several threads (NIMPRESS_THREADS, default: the host's cores, at
+    // most 16).
     bool open(const std::string &path, const std::vector<ScoreEntry> *keep = nullptr);
+    // openStreaming(): indexed files only (false otherwise): header + index, no records.
+    bool openStreaming(const std::string &path);
+    // the records overlapping entries [first, first+count), in file order (indexed files only)
+    std::vector<Variant> fetch(const ScoreEntry *first, size_t count) const;
     int64_t n_samples() const { return (int64_t)samples.size(); }
 };
 
 // nim:353-364: first record overlapping contig:pos-stop with REF == ref and (ea == ref or ea in ALT).
 const Variant *findVariant(const std::string &contig, int64_t pos, const std::string &refseq,
                            const std::string &easeq, const VCF &vcf);
+// the same rule over a set of records with a per-contig position index (built once per set): the
+// score driver's lookups are O(log records) instead of a scan
+struct RecordIndex {
+    struct Contig {
+        std::vector<uint32_t> ids;  // records of the contig in file order
+        bool sorted = true;         // ... which is position order (always, for indexed files)
+        int64_t maxlen = 1;         // longest REF (or .bim allele): bounds the overlap window
+    };
+    std::map<std::string, Contig> contigs;
+    const std::vector<Variant> *records = nullptr;
+    void build(const std::vector<Variant> &recs);
+    const Variant *find(const std::string &contig, int64_t pos, const std::string &refseq,
+                        const std::string &easeq) const;
+};
 
 // nim:50-188 (only used for the AF-mismatch warnings)
 double dbinom(int64_t x, int64_t n, double p);

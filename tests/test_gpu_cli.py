@@ -16,9 +16,9 @@ G = os.path.join(ROOT, "tests", "golden")
 CLI = os.path.join(ROOT, "nimpress_amd", "nimpress")
 
 
-def run_cli(*flags):
+def run_cli(*flags, env=None):
     r = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), os.path.join(G, "set1.vcf.gz")],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     warns = [l for l in r.stdout.splitlines() if l.startswith("WARN ")]
     rows = [l.split("\t") for l in r.stdout.splitlines() if not l.startswith(("WARN ", "FATAL "))]
@@ -51,6 +51,16 @@ def test_cli_set1_golden(idx):
                                                 case["ignore_filter"])
     for t, r in zip(texts, ref):
         assert t == refcpu.format_score(r) or abs(float(t) - r) <= 1e-12
+
+
+def test_cli_streaming_windows_and_whole_file_agree():
+    """the command line streams indexed files window by window of score rows (here: 2 rows a window, 3
+    fetch threads); the output must equal the run that reads the whole file (no index)"""
+    flags = ["--imp-locus=ps", "--imp-sample=int_ps", "--maxmis=1.0", "--mincs=3"]
+    a = run_cli(*flags, env={"NIMPRESS_WINDOW": "2", "NIMPRESS_THREADS": "3"})
+    b = run_cli(*flags, env={"NIMPRESS_NO_INDEX": "1"})
+    c = run_cli(*flags)
+    assert a[2] == b[2] == c[2] and a[3] == b[3] == c[3]
 
 
 def test_cli_defaults_and_warnings():

@@ -32,6 +32,8 @@ def host():
     L.nh_bed_covered.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_long]
     L.nh_vcf_open.restype = C.c_void_p
     L.nh_vcf_open.argtypes = [C.c_char_p, C.c_char_p]
+    L.nh_vcf_open_streaming.restype = C.c_void_p
+    L.nh_vcf_open_streaming.argtypes = [C.c_char_p, C.c_char_p, C.c_long]
     L.nh_vcf_close.argtypes = [C.c_void_p]
     L.nh_vcf_n_samples.restype = C.c_long
     L.nh_vcf_n_samples.argtypes = [C.c_void_p]
@@ -318,11 +320,18 @@ def test_tabix_random_access_multi_block(host, tmp_path):
     score_path = str(tmp_path / "s.score")
     open(score_path, "w").write("\n".join(lines))
     results = []
-    for no_index in (False, True):
+    # whole-file scan, index (all loci at once, several threads), and the streaming driver's windowed
+    # fetch (windows of 7 score rows; one thread and several)
+    for no_index, window, threads in ((False, 0, None), (True, 0, None), (False, 7, "1"), (False, 7, "5")):
         if no_index:
             os.environ["NIMPRESS_NO_INDEX"] = "1"
+        if threads:
+            os.environ["NIMPRESS_THREADS"] = threads
         try:
-            h = host.nh_vcf_open(vcf_path.encode(), score_path.encode())
+            if window:
+                h = host.nh_vcf_open_streaming(vcf_path.encode(), score_path.encode(), window)
+            else:
+                h = host.nh_vcf_open(vcf_path.encode(), score_path.encode())
             assert h, host.nh_last_error()
             assert host.nh_vcf_indexed(h) == (0 if no_index else 1)
             assert host.nh_vcf_n_samples(h) == n
@@ -338,11 +347,13 @@ def test_tabix_random_access_multi_block(host, tmp_path):
             host.nh_vcf_close(h)
         finally:
             os.environ.pop("NIMPRESS_NO_INDEX", None)
-    assert results[0][0] == results[1][0] == 40
-    for a, b in zip(results[0][1], results[1][1]):
-        assert a[0] == b[0] and a[1] == b[1]
-        if a[0]:
-            assert np.array_equal(a[2], b[2])
+            os.environ.pop("NIMPRESS_THREADS", None)
+    assert all(r[0] == 40 for r in results)
+    for other in results[1:]:
+        for a, b in zip(results[0][1], other[1]):
+            assert a[0] == b[0] and a[1] == b[1]
+            if a[0]:
+                assert np.array_equal(a[2], b[2])
     assert sum(1 for a in results[0][1] if a[0]) == 40
 
 
@@ -434,11 +445,15 @@ def test_bcf_random_access_multi_block(host, tmp_path):
     score_path = str(tmp_path / "s.score")
     open(score_path, "w").write("\n".join(lines))
     results = []
-    for no_index in (False, True):
+    # CSI access (all loci, several threads), whole-file scan, windowed streaming fetch (3 rows a window)
+    for no_index, window in ((False, 0), (True, 0), (False, 3)):
         if no_index:
             os.environ["NIMPRESS_NO_INDEX"] = "1"
         try:
-            h = host.nh_vcf_open(path.encode(), score_path.encode())
+            if window:
+                h = host.nh_vcf_open_streaming(path.encode(), score_path.encode(), window)
+            else:
+                h = host.nh_vcf_open(path.encode(), score_path.encode())
             assert h, host.nh_last_error()
             assert host.nh_vcf_indexed(h) == (0 if no_index else 1)
             got = []
@@ -454,10 +469,11 @@ def test_bcf_random_access_multi_block(host, tmp_path):
             host.nh_vcf_close(h)
         finally:
             os.environ.pop("NIMPRESS_NO_INDEX", None)
-    assert results[0][0] == results[1][0] == 20
-    for (a, b), k in zip(zip(results[0][1][:-1], results[1][1][:-1]), pick):
-        assert a[0] and b[0] and a[1] == b[1] == recs[k]["pos"]
-        exp_f = ";".join(recs[k]["filters"]) or "."
-        assert a[2].decode() == b[2].decode() == exp_f
-        assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], recs[k]["gts"].ravel().astype(np.int32))
-    assert results[0][1][-1] == results[1][1][-1] == (False,)
+    assert results[0][0] == results[1][0] == results[2][0] == 20
+    for other in results[1:]:
+        for (a, b), k in zip(zip(results[0][1][:-1], other[1][:-1]), pick):
+            assert a[0] and b[0] and a[1] == b[1] == recs[k]["pos"]
+            exp_f = ";".join(recs[k]["filters"]) or "."
+            assert a[2].decode() == b[2].decode() == exp_f
+            assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], recs[k]["gts"].ravel().astype(np.int32))
+        assert results[0][1][-1] == other[1][-1] == (False,)
