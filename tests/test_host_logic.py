@@ -477,3 +477,69 @@ def test_bcf_random_access_multi_block(host, tmp_path):
             assert a[2].decode() == b[2].decode() == exp_f
             assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], recs[k]["gts"].ravel().astype(np.int32))
         assert results[0][1][-1] == other[1][-1] == (False,)
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_ingest_under_sanitizers(tmp_path, san):
+    """the host ingest (BGZF inflate, tabix / CSI random access, BCF decode, the per-contig record index,
+    the multi-threaded window fetch) built with -fsanitize=address,undefined and -fsanitize=thread (CPU
+    build only) on a multi-block vcf.gz + .tbi and a multi-block BCF + .csi: no report, and the
+    streaming windows pick the same records as the all-at-once load"""
+    import shutil
+    import subprocess
+    import bcfwriter
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "ingest")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe,
+           os.path.join(ROOT, "tests", "native", "ingest_driver.cpp"),
+           os.path.join(ROOT, "nimpress_amd", "csrc", "host", "nimpress_host.cpp"),
+           "-L" + os.path.join(ROOT, "nimpress_amd"), "-lnps", "-lz",
+           "-Wl,-rpath," + os.path.join(ROOT, "nimpress_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(5)
+    n = 9000
+    samples = ["Q%d" % i for i in range(n)]
+    contigs = ["1", "2", "X"]
+    recs, vlines = [], []
+    for contig in contigs:
+        pos = 500
+        for k in range(30):
+            pos += int(rng.integers(1, 70000))
+            ref = "A" if rng.uniform() < 0.7 else "ACGTAC"
+            a = rng.integers(0, 3, size=(n, 2))
+            g = (a + 1) << 1
+            g[rng.uniform(size=n) < 0.03] = 0
+            recs.append(dict(contig=contig, pos=pos, id=".", ref=ref, alts=["G", "T"],
+                             filters=[[], ["PASS"], ["FAIL"]][k % 3], gts=g))
+            txt = np.where(g[:, 0] == 0, "./.", np.char.add(np.char.add((a[:, 0]).astype(str), "/"), a[:, 1].astype(str)))
+            vlines.append((contig, pos, ref, "%s\t%d\t.\t%s\tG,T\t.\t%s\t.\tGT\t%s" % (
+                contig, pos, ref, ";".join(recs[-1]["filters"]) or ".", "\t".join(txt.tolist()))))
+    bcf = str(tmp_path / "c.bcf")
+    bcfwriter.write_bcf(bcf, contigs, samples, recs, gt_dtype=np.int16)
+    vcf = str(tmp_path / "c.vcf.gz")
+    write_bgzf_vcf_with_tbi(vcf, ["##fileformat=VCFv4.2",
+                                  "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)], vlines)
+    lines = ["t", "", "", "x", "0.0"]
+    for k in rng.permutation(len(recs))[:50]:
+        lines.append("%s\t%d\t%s\t%s\t0.1\t0.2" % (recs[k]["contig"], recs[k]["pos"], recs[k]["ref"], "GT"[k % 2]))
+    lines.append("2\t3\tA\tG\t0.1\t0.2")
+    score = str(tmp_path / "s.score")
+    open(score, "w").write("\n".join(lines))
+    env = dict(os.environ, NIMPRESS_THREADS="4", ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1")
+    outs = []
+    for path in (bcf, vcf):
+        r = subprocess.run([exe, score, path, "7"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+        for bad in ("Sanitizer", "runtime error"):
+            assert bad not in r.stderr, r.stderr[-3000:]
+        out = r.stdout.splitlines()
+        assert len(out) == 2 * 51 and out[:51] == out[51:]        # whole load == streaming windows
+        assert sum("absent" in l for l in out[:51]) == 1
+        outs.append(out)
+    # BCF (int16 vectors) and text VCF give the same widened GT values
+    assert outs[0] == outs[1]
