@@ -176,7 +176,7 @@ def main():
         dominant = max(("tally", "accumulate", "fused"), key=lambda k: kern_ms[k])
         achieved = alg_bytes / (hot_ms_per_step * 1e-3) / 1e9 if hot_ms_per_step > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_ds.json" if is_ds else "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))

@@ -46,8 +46,9 @@ def pmc(name, counter):
 
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 cfg = bench["config"]
+is_ds = "FORMAT/DS" in cfg["workload"]
 traffic = {"round": tag, "samples": cfg["samples"], "variants": cfg["variants"],
-           "kernel": "nps::fused_cw_kernel<1024, 0>",
+           "kernel": "nps::ds_fused_kernel" if is_ds else "nps::fused_cw_kernel<1024, 0>",
            "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_step"]}
 if fetch and write:
     traffic.update({
@@ -56,6 +57,6 @@ if fetch and write:
         "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide "
                       "(16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE taken as is; separate --pmc passes",
         "hbm_bytes_per_step": 2.0 * fetch[0] * 1024.0 + write[0] * 1024.0})
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, "traffic_ds.json" if is_ds else "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(out_dir, "bench.json")).read().strip()[:600])
