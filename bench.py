@@ -89,6 +89,46 @@ def cpu_baseline(n, eaf, miss, seed, rows):
                       "639-641, binomTest warnings off, %.1f s" % (rows, n, n_distinct, secs)}
 
 
+def score_delta(sc_factory, cohort, beta, eaf, miss, seed, n, m, th, tm, tmi):
+    """The second half of BASELINE.json's metric ("+ max-abs score delta vs reference"), outside the
+    timed region and on rank 0 only: one more pass with per-row statistics, then the oracle's
+    arithmetic (nimpress.nim:565-583, 639-649) on the CPU for the first 16 samples over ALL rows, fed
+    with the row tallies the GPU reports, four of which are recounted over the full width by the
+    oracle's generator.  The oracle is the checker here, nothing of it is timed or shipped."""
+    from oracle import refcpu
+    from nimpress_amd import capi
+    sc = sc_factory()
+    sc.score_cohort(cohort, capi.row_descs(beta, eaf))
+    stats = sc.flush()
+    got, nloci = sc.finish(0.0)
+    sc.close()
+    recount_ok = True
+    for j in sorted({0, min(1000, m - 1), m // 2, m - 1}):
+        codes = refcpu.synth_rows(n, j, 1, seed, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
+        c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
+        code = (c[:, 0] + 2 * c[:, 1])[:n]
+        recount_ok &= int((code == 2).sum()) == int(stats["nmissing"][j])
+        recount_ok &= int((code == 1).sum() + 2 * (code == 3).sum()) == int(stats["neffect"][j])
+    k = min(16, n)
+    codes16 = refcpu.synth_rows(k, 0, m, seed, th, tm, tmi)[:, 0]
+    nmiss = stats["nmissing"].astype(np.float64)
+    ngen = float(n) - nmiss
+    imp = np.where(ngen >= 100.0, stats["neffect"] / np.maximum(ngen, 1.0), eaf * 2.0)
+    locus = (nmiss / float(n)) > 0.05
+    ref = np.empty(k)
+    for i in range(k):
+        code = (codes16 >> np.uint32(2 * i)) & np.uint32(3)
+        d = np.choose(code, [np.zeros(m), np.ones(m), imp, np.full(m, 2.0)])
+        d = np.where(locus, eaf * 2.0, d)
+        ref[i] = np.cumsum(d * beta)[-1] / (2.0 * m)
+    delta = np.abs(got[:k] - ref)
+    floor = 1e-12 * float(np.sum(np.abs(beta))) / (2.0 * max(int(nloci), 1))
+    return {"max_abs": float(delta.max()), "max_rel": float((delta / np.maximum(np.abs(ref), floor)).max()),
+            "nloci_equal": bool(int(nloci) == int(stats["used"].sum()) == m), "tally_recount_equal": bool(recount_ok),
+            "checked": "first %d samples x all %d rows vs the oracle's arithmetic on the CPU; row tallies of 4 "
+                       "rows recounted over all %d samples" % (k, m, n)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -213,6 +253,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not is_ds:
             out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)
+            out["score_delta_vs_reference"] = score_delta(
+                lambda: capi.Scorer(n, capi.make_params(), device=local_rank), cohort, beta, eaf, miss,
+                args.seed, n, m, t_het, t_hom, t_miss)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
