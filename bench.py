@@ -43,6 +43,9 @@ def parse_args():
                     help="gt: 2-bit packed GT matrix (the headline, config 3); ds: float32 FORMAT/DS "
                          "matrix (config 5 shape: pass --samples 200000 and as many --variants as fit HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimize", action="store_true",
+                    help="skip nps_cohort_optimize (the row of each group of 4 with the most dosage-2 / "
+                         "missing codes in the bank-selecting slot)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20250103)
     return ap.parse_args()
@@ -161,6 +164,8 @@ def main():
     for r0 in range(0, m, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
         r1 = min(m, r0 + (1 << 15))
         cohort.synth(r0, args.seed, t_het[r0:r1], t_hom[r0:r1], t_miss[r0:r1])
+    if not args.no_optimize:
+        cohort.optimize()  # one-time layout step of a resident cohort (nps_cohort_optimize), untimed
     # this rank's score definition: its own betas (score files sharded across GPUs)
     beta = np.round(np.random.default_rng(args.seed + 1000 + rank).normal(0.0, 0.02, m), 4)
     sdef = capi.ScoreDef(capi.row_descs(beta, eaf), device=local_rank)

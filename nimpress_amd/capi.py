@@ -52,7 +52,8 @@ SYMBOLS = [
     "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
     "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
-    "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_destroy",
+    "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_optimize",
+    "nps_cohort_destroy",
     "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream",
 ]
 
@@ -109,6 +110,7 @@ def load():
     L.nps_cohort_upload.argtypes = [vp, u64, u64, vp, C.c_size_t]
     L.nps_cohort_download.argtypes = [vp, u64, u64, vp, C.c_size_t]
     L.nps_cohort_synth.argtypes = [vp, u64, u64, u64, vp, vp, vp]
+    L.nps_cohort_optimize.argtypes = [vp]
     L.nps_cohort_destroy.argtypes = [vp]
     L.nps_cohort_destroy.restype = None
     L.nps_score_cohort.argtypes = [vp, vp, u64, vp, u64, i32]
@@ -177,6 +179,11 @@ class Cohort:
         assert th.size == tm.size == tmi.size
         _check(load().nps_cohort_synth(self._h, row0, th.size, seed, th.ctypes.data, tm.ctypes.data,
                                        tmi.ctypes.data))
+
+    def optimize(self):
+        """one-time layout optimisation (nps_cohort_optimize): the row of every group of 4 with the most
+        dosage-2 / missing codes moves to the slot that selects the LDS bank; results unchanged"""
+        _check(load().nps_cohort_optimize(self._h))
 
     def close(self):
         if self._h:

@@ -56,7 +56,18 @@ struct nps_cohort {
     uint64_t n_samples = 0, n_rows = 0;
     uint64_t stride_bytes = 0;  // per row (GT2: rows are interleaved in groups of 4, a group is 4*stride_bytes)
     void *d_data = nullptr;
+    // nps_cohort_optimize (GT2): per group the logical row (0..3) that sits in slot 0 (and logical row 0
+    // in that slot); host copy for downloads and for putting per-row results back in row order
+    bool optimized = false;
+    uint8_t *d_swap = nullptr;
+    std::vector<uint8_t> h_swap;
 };
+
+// slot <-> logical row inside a group (the exchange of slot 0 and slot j is its own inverse)
+static inline uint64_t swapped_row(uint64_t row, uint8_t j) {
+    const uint64_t s = row & 3;
+    return (row & ~3ull) + (s == 0 ? j : (s == j ? 0 : s));
+}
 
 struct PendingRow {
     int32_t batch_idx;  // >= 0: index into the open GT / DS batch's device stats; -1: host stat
@@ -65,6 +76,9 @@ struct PendingRow {
 };
 
 struct nps_ctx {
+    nps_row_desc *d_desc_perm = nullptr;  // row descriptors in slot order (optimized cohorts)
+    uint64_t desc_perm_cap = 0;
+    std::vector<uint8_t> res_swap;        // swap bytes of the range scored last (empty: not optimized)
     int device = 0;
     hipStream_t stream = nullptr;
     uint64_t n = 0;         // samples
@@ -271,6 +285,7 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_rds_rowp);
     (void)hipFree(c->d_rds_psum);
     (void)hipFree(c->d_part_fused);
+    (void)hipFree(c->d_desc_perm);
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
@@ -888,7 +903,38 @@ extern "C" void nps_cohort_destroy(nps_cohort *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_data);
+    (void)hipFree(c->d_swap);
     delete c;
+}
+
+// back to plain row order (before rows are written into an optimized cohort)
+static int cohort_unoptimize(nps_cohort *c) {
+    if (!c->optimized) return NPS_OK;
+    hipError_t e = launch_cohort_swap(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
+                                      c->n_rows, c->d_swap);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(NPS_E_HIP, "cohort re-ordering failed: %s", hipGetErrorString(e));
+    c->optimized = false;
+    c->h_swap.clear();
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_optimize(nps_cohort *c) {
+    if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
+    if (c->format != NPS_FMT_GT2 || c->optimized || c->n_rows == 0 || c->n_samples == 0) return NPS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t n_groups = (c->n_rows + 3) / 4;
+    uint32_t *d_counts = nullptr;
+    if (!c->d_swap) HIP_TRY(hipMalloc(&c->d_swap, n_groups));
+    HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * 4 * n_groups));
+    hipError_t e = launch_cohort_optimize(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
+                                          c->n_rows, d_counts, c->d_swap);
+    c->h_swap.assign(n_groups, 0);
+    if (e == hipSuccess) e = hipMemcpy(c->h_swap.data(), c->d_swap, n_groups, hipMemcpyDeviceToHost);
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "cohort optimisation failed: %s", hipGetErrorString(e));
+    c->optimized = true;
+    return NPS_OK;
 }
 
 static int check_range(const nps_cohort *c, uint64_t row0, uint64_t nrows) {
@@ -916,7 +962,9 @@ static int gt2_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void
             HIP_TRY(hipMemcpy(buf.data(), dev, groups * sw * 16, hipMemcpyDeviceToHost));
         for (uint64_t j = 0; j < k; ++j) {
             uint32_t *hrow = (uint32_t *)((char *)host_rows + (r + j) * host_stride);
-            uint32_t *g = buf.data() + (j >> 2) * sw * 4 + (j & 3);
+            // slot of logical row row0 + r + j inside its group
+            const uint64_t slot = c->optimized ? swapped_row(j, c->h_swap[(row0 + r + j) >> 2]) : j;
+            uint32_t *g = buf.data() + (slot >> 2) * sw * 4 + (slot & 3);
             if (to_device)
                 for (uint64_t w = 0; w < n_words; ++w) g[w * 4] = word_to_planes(hrow[w]);
             else
@@ -973,6 +1021,8 @@ extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (!bed_rows || !effect_is_a1 || row_stride_bytes < width)
         return fail(NPS_E_INVAL, "bad .bed buffer / stride / flags");
     HIP_TRY(hipSetDevice(c->device));
+    rc = cohort_unoptimize(c);
+    if (rc) return rc;
     return gt2_upload(c, row0, nrows, bed_rows, row_stride_bytes, width, effect_is_a1);
 }
 
@@ -984,8 +1034,11 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->format == NPS_FMT_GT2)
+    if (c->format == NPS_FMT_GT2) {
+        rc = cohort_unoptimize(c);
+        if (rc) return rc;
         return gt2_upload(c, row0, nrows, host_rows, host_stride, width, nullptr);
+    }
     HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
                         host_stride, width, nrows, hipMemcpyHostToDevice));
     return NPS_OK;
@@ -1015,6 +1068,8 @@ extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, ui
     if (c->format == NPS_FMT_GT2 && (row0 & 3))
         return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
     HIP_TRY(hipSetDevice(c->device));
+    rc = cohort_unoptimize(c);
+    if (rc) return rc;
     uint32_t *d_t = nullptr;
     HIP_TRY(hipMalloc(&d_t, sizeof(uint32_t) * 3 * nrows));
     hipError_t e = hipMemcpy(d_t, t_het, sizeof(uint32_t) * nrows, hipMemcpyHostToDevice);
@@ -1124,8 +1179,16 @@ static int materialize_resident_stats(nps_ctx *c) {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     size_t h = 0;
-    for (size_t j = 0; j < c->res_index.size(); ++j)
-        c->ready.push_back(c->res_index[j] >= 0 ? dev[(size_t)c->res_index[j]] : c->res_host_stats[h++]);
+    for (size_t j = 0; j < c->res_index.size(); ++j) {
+        if (c->res_index[j] < 0) {
+            c->ready.push_back(c->res_host_stats[h++]);
+            continue;
+        }
+        uint64_t at = (uint64_t)c->res_index[j];  // logical row; the kernels wrote slot order
+        if (!c->res_swap.empty()) at = swapped_row(at, c->res_swap[at >> 2]);
+        c->ready.push_back(dev[(size_t)at]);
+    }
+    c->res_swap.clear();
     c->res_pending = false;
     c->res_index.clear();
     c->res_host_stats.clear();
@@ -1284,6 +1347,31 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     const uint64_t stride_words = co->stride_bytes / 4;
     const uint32_t *codes = (const uint32_t *)co->d_data + (cohort_row0 >> 2) * stride_words * 4;
+    const nps_row_desc *d_desc = def->d_desc;
+    c->res_swap.clear();
+    if (co->optimized) {
+        // rows of a group have changed places: the scored range must consist of whole groups, the row
+        // descriptors go into slot order and the per-row results come back through the same exchange
+        if (((cohort_row0 + m) & 3) && cohort_row0 + m != co->n_rows)
+            return fail(NPS_E_UNSUPPORTED, "an optimised cohort is scored in whole groups of 4 rows: "
+                        "cohort_row0 + rows must be a multiple of 4 or the end of the cohort");
+        if (m_pad > c->desc_perm_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_desc_perm);
+            c->d_desc_perm = nullptr;
+            c->desc_perm_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_desc_perm, sizeof(nps_row_desc) * m_pad));
+            c->desc_perm_cap = m_pad;
+        }
+        {
+            ProfScope ps(c, P_PARAMS);
+            HIP_TRY(launch_permute_desc(c->stream, def->d_desc, c->d_desc_perm,
+                                        co->d_swap + (cohort_row0 >> 2), m));
+        }
+        d_desc = c->d_desc_perm;
+        c->res_swap.assign(co->h_swap.begin() + (long)(cohort_row0 >> 2),
+                           co->h_swap.begin() + (long)((cohort_row0 + m + 3) >> 2));
+    }
     if (plan.ok && c->n) {
         // fused single-read path
         const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
@@ -1300,7 +1388,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         hipError_t fe;
         {
             ProfScope ps(c, P_FUSED);
-            fe = launch_fused(c->stream, plan, codes, stride_words, c->n, m, def->d_desc,
+            fe = launch_fused(c->stream, plan, codes, stride_words, c->n, m, d_desc,
                               dev_params(c->params), c->d_rtally, c->d_rstats, c->d_nloci,
                               c->d_part_fused, c->d_timeout);
         }
@@ -1344,7 +1432,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         {
             ProfScope ps(c, P_PARAMS);
-            HIP_TRY(launch_row_params(c->stream, c->d_rtally + r0, def->d_desc + r0, k, k_pad, c->n,
+            HIP_TRY(launch_row_params(c->stream, c->d_rtally + r0, d_desc + r0, k, k_pad, c->n,
                                       dev_params(c->params), c->d_rlut + r0 * 4, c->d_rstats + r0,
                                       c->d_nloci));
         }

@@ -80,6 +80,17 @@ hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_
                                   uint64_t stride_words);
 hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1);
 
+// nps_cohort_optimize (nps_kernels.hip): per group, the row with the most dosage-2 / missing codes goes
+// to slot 0.  d_counts: [4 * groups] scratch; d_swap: [groups], logical row now in slot 0.
+// launch_cohort_swap applies (or, applied again, undoes) a given d_swap; launch_permute_desc puts the
+// row descriptors of a scored range into slot order.
+hipError_t launch_cohort_optimize(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
+                                  uint64_t n_samples, uint64_t n_rows, uint32_t *d_counts, uint8_t *d_swap);
+hipError_t launch_cohort_swap(hipStream_t st, uint32_t *d_codes, uint64_t stride_words, uint64_t n_samples,
+                              uint64_t n_rows, const uint8_t *d_swap);
+hipError_t launch_permute_desc(hipStream_t st, const nps_row_desc *d_src, nps_row_desc *d_dst,
+                               const uint8_t *d_swap, uint64_t m);
+
 // per-row decision + LUT {0b,1b,2b,imp*b} (or the locus constant); rows [n_rows, n_rows_pad) get a
 // zero LUT.  Adds the number of used rows to *d_nloci.
 hipError_t launch_row_params(hipStream_t st, const unsigned long long *d_tally,
