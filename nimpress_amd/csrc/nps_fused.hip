@@ -166,9 +166,10 @@ template <int WAVES>  // data waves
 struct __attribute__((aligned(16))) FusedCwLds {
     double table[2][4][256];
     double lut[kRowsPerBatch][4];
-    // partial tallies of a batch: [parity][row group][data wave][16-lane DPP row * 4 + row in group],
-    // every slot written by exactly one quad per batch (plain stores, no LDS atomics)
-    uint32_t tslot[2][4][WAVES][16];
+    // partial tallies of a batch: [parity][row group][data wave][lane]; lane = 16-lane DPP row * 16 +
+    // row in group * 4 + lane in quad: every data lane stores its partial of ONE row (plain stores, no
+    // LDS atomics); the control wave sums the 4 lanes x 4 DPP rows x WAVES slots of a row
+    uint32_t tslot[2][4][WAVES][64];
 };
 
 template <int T, int DBG>  // DBG: diagnostics build (bit 0 re-read rows 0..15, bit 1 skip accumulation)
@@ -202,13 +203,17 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         unsigned long long tel_spins = 0, tel_wait = 0, tel_chain = 0, tel_bar = 0;  // telemetry
 
         auto publish = [&](uint32_t k) {  // the tally slots of batch k are complete (barrier passed)
-            // lane = (row of the batch, DPP row of the data waves): sum that slot over the data waves,
-            // then over the four lanes of the quad
+            // lane = (row of the batch, DPP row of the data waves): sum the four quad lanes of that slot
+            // over the data waves, then over the four lanes of the quad
             const int prow = lane >> 2;
-            const uint32_t *slot = &lds.tslot[k & 1][prow >> 2][0][(lane & 3) * 4 + (prow & 3)];
+            const uint4 *slot = reinterpret_cast<const uint4 *>(
+                &lds.tslot[k & 1][prow >> 2][0][(lane & 3) * 16 + (prow & 3) * 4]);
             uint32_t v = 0;
 #pragma unroll
-            for (int w = 0; w < TD / 64; ++w) v += slot[w * 16];
+            for (int w = 0; w < TD / 64; ++w) {
+                const uint4 q = slot[w * 16];
+                v += (q.x + q.y) + (q.z + q.w);
+            }
             v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // lane ^ 1
             v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // lane ^ 2
             if ((lane & 3) == 0) {
@@ -348,14 +353,14 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         }
     };
 
-    // reduce-scatter of four packed row tallies over each 16-lane DPP row, then one LDS add per quad
+    // reduce-scatter of four packed row tallies over the quads of each 16-lane DPP row
     auto tally_reduce4 = [&](int par, int g, const uint32_t(&tp)[4]) {
         // A DPP bank mask enables whole quads (bank b = lanes 4b..4b+3 of a 16-lane row), so the scatter
-        // goes over the quads first -- distance 8, then distance 4, every add writing only the quads
-        // that keep its row -- and the quad is summed last: quad b of every 16-lane row ends with the
-        // row-of-16 sum of tally row b in all four lanes.  8 adds and no selects.  s_nop: a DPP operand
-        // written by one of the two preceding VALU instructions needs wait states the compiler cannot
-        // see inside the asm.
+        // goes over the quads -- distance 8, then distance 4, every add writing only the quads that keep
+        // its row: lane j of quad b of every 16-lane row ends with the sum of tally row b over lanes
+        // j, j+4, j+8, j+12 of that row.  6 adds, no selects; the control wave adds the four lanes of
+        // the quad.  s_nop: a DPP operand written by one of the two preceding VALU instructions needs
+        // wait states the compiler cannot see inside the asm.
         uint32_t b0, b1, c;
         asm volatile(
             "s_nop 1\n\t"
@@ -366,13 +371,9 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
             "s_nop 0\n\t"
             "v_add_u32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_u32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-            "s_nop 1\n\t"
-            "v_add_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_add_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
             : "=&v"(b0), "=&v"(b1), "=&v"(c)
             : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]));
-        if ((lane & 3) == 0) lds.tslot[par][g][dt >> 6][lane >> 2] = c;
+        lds.tslot[par][g][dt >> 6][lane] = c;
     };
 
     auto tally_local = [&](uint32_t k, const uint32_t(&src)[kRowsPerBatch]) {
