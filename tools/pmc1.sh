@@ -6,7 +6,7 @@ O=$R/gpurun_out/pmc1
 mkdir -p $O
 run() { # name, counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d $O/$n -o $n --output-format csv -- python3 $R/bench.py --samples 500000 --variants 400000 --steps 2 --warmup 1 --mode fused --no-cpu-baseline > $O/$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $O/$n -o $n --output-format csv -- python3 $R/bench.py --samples 500000 --variants 400000 --steps 2 --warmup 1 --mode fused --no-cpu-baseline $NPS_BENCH_EXTRA > $O/$n.log 2>&1
   f=$(ls $O/$n/*/*counter_collection.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(ls $O/$n/*counter_collection.csv | head -1)
   python3 - "$f" <<'PY'
 import csv,sys,collections
