@@ -244,6 +244,9 @@ def main():
                                     "HBM (BASELINE.json configs[2]), CLI-default imputation flags")
                                    % (m, n),
                        "samples": n, "variants": m, "nloci": int(nloci),
+                       "cohort_layout": "plain" if (args.no_optimize or is_ds) else
+                                        "nps_cohort_optimize (one-time, untimed: per group of 4 rows the row "
+                                        "with the most dosage-2/missing codes in the bank-selecting slot)",
                        "mode": args.mode, "parallelism": "score-sharded x%d + RCCL all-gather" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
