@@ -501,22 +501,30 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
     const uint64_t n_words = words_for(n_samples);
     const uint64_t n_batches = (n_rows + kRowsPerBatch - 1) / kRowsPerBatch;
     if (n_batches > 0xfffffff0ull) return hipSuccess;
-    // default: the smallest workgroup whose team still fits the 8-bit arrival count and the grid
-    const int order_default[3] = {kFusedDefaultThreads, 512, 1024};
-    const int order_want[3] = {want_threads, want_threads, want_threads};
-    const int *order = want_threads ? order_want : order_default;
-    for (int i = 0; i < 3 && !plan->ok; ++i) {
-        switch (order[i]) {
-        case 256: e = plan_for<256>(cus, n_words, n_batches, plan); break;
-        case 512: e = plan_for<512>(cus, n_words, n_batches, plan); break;
-        case 768: e = plan_for<768>(cus, n_words, n_batches, plan); break;
-        case 832: e = plan_for<832>(cus, n_words, n_batches, plan); break;
-        case 896: e = plan_for<896>(cus, n_words, n_batches, plan); break;
-        case 960: e = plan_for<960>(cus, n_words, n_batches, plan); break;
-        case 1024: e = plan_for<1024>(cus, n_words, n_batches, plan); break;
+    auto try_plan = [&](int threads, FusedPlan *out) -> hipError_t {
+        *out = FusedPlan{};
+        switch (threads) {
+        case 256: return plan_for<256>(cus, n_words, n_batches, out);
+        case 512: return plan_for<512>(cus, n_words, n_batches, out);
+        case 768: return plan_for<768>(cus, n_words, n_batches, out);
+        case 832: return plan_for<832>(cus, n_words, n_batches, out);
+        case 896: return plan_for<896>(cus, n_words, n_batches, out);
+        case 960: return plan_for<960>(cus, n_words, n_batches, out);
+        case 1024: return plan_for<1024>(cus, n_words, n_batches, out);
         default: return hipErrorInvalidValue;
         }
+    };
+    if (want_threads) return try_plan(want_threads, plan);
+    // A pass takes (row batches / teams) batch phases, and a phase is a little shorter with fewer data
+    // waves per workgroup (measured: 14 waves 0.8 % faster than 15 at the same number of teams): the
+    // most teams first, then the smallest workgroup that still gives that many.
+    const int candidates[5] = {1024, 960, 896, 832, 512};
+    for (int t : candidates) {
+        FusedPlan p;
+        e = try_plan(t, &p);
         if (e != hipSuccess) return e;
+        if (p.ok && (!plan->ok || p.Q > plan->Q || (p.Q == plan->Q && t >= 832 && p.threads < plan->threads)))
+            *plan = p;
     }
     return hipSuccess;
 }
