@@ -25,6 +25,9 @@ if st:
     open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w").write(open(st).read())
 
 
+kernel_names = set()
+
+
 def pmc(name, counter):
     f = find("%s/**/*counter_collection.csv" % name)
     vals, rows = [], []
@@ -35,6 +38,7 @@ def pmc(name, counter):
         if "fused" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
             rows.append(r)
+            kernel_names.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
     with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, counter)), "w", newline="") as fo:
         if rows:
             w = csv.DictWriter(fo, fieldnames=list(rows[0].keys()))
@@ -57,6 +61,8 @@ if fetch and write:
         "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide "
                       "(16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE taken as is; separate --pmc passes",
         "hbm_bytes_per_step": 2.0 * fetch[0] * 1024.0 + write[0] * 1024.0})
+if kernel_names:
+    traffic["kernel"] = sorted(kernel_names)[0]
 json.dump(traffic, open(os.path.join(dst, "traffic_ds.json" if is_ds else "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(out_dir, "bench.json")).read().strip()[:600])
