@@ -33,9 +33,8 @@ namespace nps {
 constexpr int kDsRows = 2;     // rows per batch
 constexpr int kDsPerThread = 8;
 constexpr int kDsRing = 5;     // batches in flight per data thread
-constexpr int kDsThreads = 1024;
-constexpr int kDsDataThreads = kDsThreads - 64;
-constexpr uint32_t kDsSliceSamples = kDsDataThreads * kDsPerThread;  // 7 680
+// workgroup size T: wave 0 is the control wave, T/64 - 1 data waves of 512 samples each
+static constexpr uint32_t ds_slice_samples(int threads) { return (uint32_t)(threads - 64) * kDsPerThread; }
 constexpr uint32_t kDsSpinLimit = 1u << 20;
 
 struct DsFusedArgs {
@@ -98,7 +97,9 @@ static __device__ __forceinline__ double uniform_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedArgs a) {
+template <int T>
+__global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
+    constexpr uint32_t kDsSliceSamples = ds_slice_samples(T);
     constexpr int R = kDsRows, D = kDsRing;
     __shared__ DsFusedLds lds;
     const int tid = threadIdx.x;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
             if (lane < R) {
                 const int par = k & 1;
 #pragma unroll
-                for (int w = 1; w < 16; ++w) {  // fixed order
+                for (int w = 1; w < T / 64; ++w) {  // fixed order
                     s += lds.wsum[par][lane][w];
                     cnt += lds.wcnt[par][lane][w];
                 }
@@ -430,6 +431,29 @@ __global__ __launch_bounds__(kDsThreads, 4) void ds_fused_kernel(const DsFusedAr
 }
 
 // ---- host side ------------------------------------------------------------------------------
+template <int T>
+static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, FusedPlan *plan) {
+    *plan = FusedPlan{};
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel<T>, T, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) return hipSuccess;
+    const uint64_t slice = ds_slice_samples(T);
+    const uint64_t P = (n_samples + slice - 1) / slice;
+    if (P > (uint64_t)cus || P > 255) return hipSuccess;
+    uint64_t Q = std::min<uint64_t>((uint64_t)cus / P, n_batches);
+    if (const char *env = getenv("NPS_FUSED_MAXQ"))
+        if (atoi(env) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(env));
+    if (Q < 1 || Q > 65535) return hipSuccess;
+    plan->threads = T;
+    plan->P = (uint32_t)P;
+    plan->Q = (uint32_t)Q;
+    plan->n_batches = (uint32_t)n_batches;
+    plan->part_team_stride = P * slice;
+    plan->ok = true;
+    return hipSuccess;
+}
+
 hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan) {
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 30)) return hipSuccess;
@@ -437,23 +461,21 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedP
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return e;
     const int cus = prop.multiProcessorCount;
-    int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel, kDsThreads, 0);
-    if (e != hipSuccess) return e;
-    if (cus < 1 || per_cu < 1) return hipSuccess;
-    const uint64_t P = (n_samples + kDsSliceSamples - 1) / kDsSliceSamples;
+    if (cus < 1) return hipSuccess;
     const uint64_t n_batches = (n_rows + kDsRows - 1) / kDsRows;
-    if (P > (uint64_t)cus || P > 255 || n_batches > 0xfffffff0ull) return hipSuccess;
-    uint64_t Q = std::min<uint64_t>((uint64_t)cus / P, n_batches);
-    if (const char *env = getenv("NPS_FUSED_MAXQ"))
-        if (atoi(env) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(env));
-    if (Q < 1 || Q > 65535) return hipSuccess;
-    plan->threads = kDsThreads;
-    plan->P = (uint32_t)P;
-    plan->Q = (uint32_t)Q;
-    plan->n_batches = (uint32_t)n_batches;
-    plan->part_team_stride = P * kDsSliceSamples;
-    plan->ok = true;
+    if (n_batches > 0xfffffff0ull) return hipSuccess;
+    // as for the GT kernel: the most teams first, then the smallest workgroup that still gives that many
+    const int want = getenv("NPS_FUSED_THREADS") ? atoi(getenv("NPS_FUSED_THREADS")) : 0;
+    const int candidates[3] = {1024, 960, 896};
+    for (int t : candidates) {
+        if (want && want != t) continue;
+        FusedPlan p;
+        e = t == 1024 ? ds_plan_for<1024>(cus, n_samples, n_batches, &p)
+            : t == 960 ? ds_plan_for<960>(cus, n_samples, n_batches, &p)
+                       : ds_plan_for<896>(cus, n_samples, n_batches, &p);
+        if (e != hipSuccess) return e;
+        if (p.ok && (!plan->ok || p.Q > plan->Q || (p.Q == plan->Q && p.threads < plan->threads))) *plan = p;
+    }
     return hipSuccess;
 }
 
@@ -481,8 +503,10 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
     a.timeout = d_timeout;
     void *args[] = {&a};
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
-    return hipLaunchCooperativeKernel((const void *)ds_fused_kernel, dim3(plan.P, plan.Q),
-                                      dim3(plan.threads), args, 0, st);
+    const void *fn = plan.threads == 1024  ? (const void *)ds_fused_kernel<1024>
+                     : plan.threads == 960 ? (const void *)ds_fused_kernel<960>
+                                           : (const void *)ds_fused_kernel<896>;
+    return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
 }
 
 }  // namespace nps
