@@ -255,7 +255,7 @@ def test_fused_all_imputation_modes(pk):
 
 
 def test_fused_equals_twopass_large():
-    """500 000 samples x 4096 rows (31 slices x 8 teams, the bench geometry): the two HIP paths
+    """500 000 samples x 4096 rows (35 slices x 7 teams, the bench geometry): the two HIP paths
     must agree -- tallies bit for bit, scores to rounding -- at a size the oracle cannot reach."""
     n, m = 500_000, 4096
     rng = np.random.default_rng(123)
