@@ -34,7 +34,6 @@
 namespace nps {
 
 constexpr int kRowsPerBatch = 16;
-constexpr int kFusedDefaultThreads = 1024;
 constexpr uint32_t kSpinLimit = 1u << 20;  // ~1 s of polling before a wait gives up
 
 struct FusedArgs {
