@@ -202,7 +202,12 @@ int nps_normalize_device(nps_ctx *ctx, double *d_sums_inout, uint64_t nloci, dou
 int nps_reset(nps_ctx *ctx, const nps_params *params /* NULL = keep */);
 void nps_destroy(nps_ctx *ctx);
 
-/* ---- resident cohort: a packed genotype matrix kept in HBM ------------------------------ */
+/* ---- resident cohort: a packed genotype matrix kept in HBM ------------------------------
+ * Ordering: nps_score_cohort[_def] returns while its kernels still run on the context's stream.  The
+ * calls that write cohort rows (nps_cohort_upload, _upload_bed, _synth, _optimize) first wait for
+ * ALL work queued on the device (hipDeviceSynchronize), so a cohort can be modified safely at any
+ * time; destroying a cohort waits the same way.  A 2-bit upload / synth that ends inside a group of
+ * four rows zeroes the remaining rows of that last group (rows are stored in groups of four). */
 #define NPS_FMT_GT2 0  /* 2-bit codes, 16 per uint32, variant-major / sample-minor */
 #define NPS_CODE_DOSAGE0 0u
 #define NPS_CODE_DOSAGE1 1u
@@ -253,6 +258,10 @@ int nps_score_cohort(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
 int nps_scoredef_create(nps_scoredef **out, int device, const nps_row_desc *rows, uint64_t n_desc);
 uint64_t nps_scoredef_n_present(const nps_scoredef *d); /* rows that consume a cohort row */
 void nps_scoredef_destroy(nps_scoredef *d);
+/* Error behaviour: everything that can be refused (arguments, ranges, NPS_E_UNSUPPORTED shapes, a
+ * failed allocation) is checked before the context changes, so such a call can simply be repeated
+ * (e.g. with another mode).  A HIP failure between the first and the last launch of a run leaves the
+ * context's sums undefined: every later call returns NPS_E_STATE until nps_reset. */
 int nps_score_cohort_def(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
                          const nps_scoredef *def, int mode);
 

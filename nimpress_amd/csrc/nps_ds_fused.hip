@@ -432,7 +432,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
 
 // ---- host side ------------------------------------------------------------------------------
 template <int T>
-static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, FusedPlan *plan) {
+static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, int max_q, FusedPlan *plan) {
     *plan = FusedPlan{};
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel<T>, T, 0);
@@ -442,8 +442,7 @@ static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, F
     const uint64_t P = (n_samples + slice - 1) / slice;
     if (P > (uint64_t)cus || P > 255) return hipSuccess;
     uint64_t Q = std::min<uint64_t>((uint64_t)cus / P, n_batches);
-    if (const char *env = getenv("NPS_FUSED_MAXQ"))
-        if (atoi(env) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(env));
+    if (max_q > 0) Q = std::min<uint64_t>(Q, (uint64_t)max_q);  // diagnostics: fewer CUs in use
     if (Q < 1 || Q > 65535) return hipSuccess;
     plan->threads = T;
     plan->P = (uint32_t)P;
@@ -454,7 +453,8 @@ static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, F
     return hipSuccess;
 }
 
-hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan) {
+hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want, int max_q,
+                         FusedPlan *plan) {
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 30)) return hipSuccess;
     hipDeviceProp_t prop;
@@ -465,14 +465,13 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedP
     const uint64_t n_batches = (n_rows + kDsRows - 1) / kDsRows;
     if (n_batches > 0xfffffff0ull) return hipSuccess;
     // as for the GT kernel: the most teams first, then the smallest workgroup that still gives that many
-    const int want = getenv("NPS_FUSED_THREADS") ? atoi(getenv("NPS_FUSED_THREADS")) : 0;
     const int candidates[3] = {1024, 960, 896};
     for (int t : candidates) {
         if (want && want != t) continue;
         FusedPlan p;
-        e = t == 1024 ? ds_plan_for<1024>(cus, n_samples, n_batches, &p)
-            : t == 960 ? ds_plan_for<960>(cus, n_samples, n_batches, &p)
-                       : ds_plan_for<896>(cus, n_samples, n_batches, &p);
+        e = t == 1024 ? ds_plan_for<1024>(cus, n_samples, n_batches, max_q, &p)
+            : t == 960 ? ds_plan_for<960>(cus, n_samples, n_batches, max_q, &p)
+                       : ds_plan_for<896>(cus, n_samples, n_batches, max_q, &p);
         if (e != hipSuccess) return e;
         if (p.ok && (!plan->ok || p.Q > plan->Q || (p.Q == plan->Q && p.threads < plan->threads))) *plan = p;
     }

@@ -131,8 +131,13 @@ struct nps_ctx {
     AccumGeom geom{};         // streaming geometry (groups_per_chunk for a full batch)
     uint32_t n_chunks = 1;
     double *d_part = nullptr;  // [n_chunks][part_chunk_stride]
+    // which chunks of d_part hold data: 0 = none yet (nothing has been zeroed either: the first
+    // writer overwrites), 1 = chunk 0 only (fused epilogues), n_chunks = all (two-pass kernels)
+    uint32_t chunks_used = 0;
     double *d_scores = nullptr;
-    unsigned long long *d_nloci = nullptr;
+    unsigned long long *d_nloci = nullptr;   // [0] used rows counted on the device, [1] sticky status bits
+    unsigned long long *h_result = nullptr;  // pinned copy of that block
+    bool broken = false;                     // a launch sequence failed half-way: nps_reset first
     double const_sum = 0.0;   // contributions of rows without genotype data (host decided)
     uint64_t host_nloci = 0;
 
@@ -143,9 +148,13 @@ struct nps_ctx {
     nps_locus_stat *d_rstats = nullptr;
     double *d_part_fused = nullptr;         // [Q][team stride] partial scores of the fused kernel
     uint64_t part_fused_cap = 0;            // doubles
-    unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernel
-    unsigned int h_timeout = 0;             // host copy, checked at the next synchronisation
-    bool timeout_check = false;
+    unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernels (cleared by fold_kernel)
+    bool rtally_clean = false;              // d_rtally is all zero (allocation, or the last fused epilogue)
+    // shape -> persistent-grid plan of the last resident run (occupancy queries are slow)
+    bool plan_valid = false;
+    int plan_fmt = -1;
+    uint64_t plan_m = 0;
+    FusedPlan plan_cache{};
     bool res_pending = false;               // stats of the last resident run still on the device
     uint64_t res_m = 0;
     std::vector<int64_t> res_index;
@@ -298,10 +307,12 @@ static void free_ctx(nps_ctx *c) {
 }
 
 static int zero_state(nps_ctx *c) {
-    HIP_TRY(hipMemsetAsync(c->d_part, 0, sizeof(double) * c->n_chunks * c->geom.part_chunk_stride,
-                           c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_nloci, 0, sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * c->batch_cap, c->stream));
+    // d_part is not touched: chunks_used = 0 makes the first writer overwrite it
+    HIP_TRY(hipMemsetAsync(c->d_nloci, 0, 2 * sizeof(unsigned long long), c->stream));
+    if (c->batch_rows)  // tallies of rows decoded into the open batch (the array is zero otherwise)
+        HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * c->batch_rows, c->stream));
+    c->chunks_used = 0;
+    c->broken = false;
     c->const_sum = 0.0;
     c->host_nloci = 0;
     c->batch_rows = 0;
@@ -309,11 +320,20 @@ static int zero_state(nps_ctx *c) {
     c->pending.clear();
     c->ready.clear();
     c->ready_cursor = 0;
-    c->timeout_check = false;
-    c->h_timeout = 0;
     c->res_pending = false;  // unflushed stats of a resident run are dropped, never copied
     c->res_index.clear();
     c->res_host_stats.clear();
+    return NPS_OK;
+}
+
+// the two-pass kernels add into every chunk of d_part: zero the chunks nothing has written yet
+static int ensure_all_chunks(nps_ctx *c) {
+    if (c->chunks_used < c->n_chunks) {
+        HIP_TRY(hipMemsetAsync(c->d_part + (uint64_t)c->chunks_used * c->geom.part_chunk_stride, 0,
+                               sizeof(double) * (c->n_chunks - c->chunks_used) * c->geom.part_chunk_stride,
+                               c->stream));
+        c->chunks_used = c->n_chunks;
+    }
     return NPS_OK;
 }
 
@@ -366,10 +386,13 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
         const size_t sz_desc = up(sizeof(nps_row_desc) * c->batch_cap);
         const size_t sz_stats = up(sizeof(nps_locus_stat) * c->batch_cap);
         const size_t sz_raw = up(sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1));
-        size_t total = sz_desc + sz_stats + nps_ctx::kRawSlots * sz_raw;
+        size_t total = 4096 + sz_desc + sz_stats + nps_ctx::kRawSlots * sz_raw;
         total = (total + 65535) / 65536 * 65536;
         CTX_TRY(hipHostMalloc(&c->h_arena, total));
         char *p = (char *)c->h_arena;
+        c->h_result = (unsigned long long *)p;
+        c->h_result[0] = c->h_result[1] = 0;
+        p += 4096;
         c->h_desc = (nps_row_desc *)p;
         p += sz_desc;
         c->h_stats = (nps_locus_stat *)p;
@@ -389,6 +412,8 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipMalloc(&c->d_scores, sizeof(double) * std::max<uint64_t>(c->n, 1)));
     CTX_TRY(hipMalloc(&c->d_nloci, 256));
     CTX_TRY(hipMalloc(&c->d_timeout, 256));
+    CTX_TRY(hipMemsetAsync(c->d_timeout, 0, 256, c->stream));
+    CTX_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * c->batch_cap, c->stream));
 #undef CTX_TRY
     rc = zero_state(c);
     if (rc) {
@@ -409,7 +434,8 @@ extern "C" int nps_reset(nps_ctx *c, const nps_params *params) {
         c->params = *params;
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // no stream synchronisation: everything below is ordered on the context's stream, and no call
+    // returns with a device-to-host copy still in flight
     return zero_state(c);
 }
 
@@ -447,8 +473,15 @@ static void host_locus_row(nps_ctx *c, int kind, int rie, double beta, double ea
     }
 }
 
+static int check_usable(nps_ctx *c) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (c->broken)
+        return fail(NPS_E_STATE, "a previous call on this context failed half-way through its launches; "
+                                 "call nps_reset before using it again");
+    return NPS_OK;
+}
+
 static int materialize_resident_stats(nps_ctx *c);
-static int check_timeout(nps_ctx *c);
 
 // run the open batch: params -> accumulate; then collect its stats
 static int run_batch(nps_ctx *c) {
@@ -473,6 +506,8 @@ static int run_batch(nps_ctx *c) {
                                       dev_params(c->params), c->d_lut, c->d_stats, c->d_nloci));
         }
         if (c->n) {
+            int rc = ensure_all_chunks(c);
+            if (rc) return rc;
             ProfScope ps(c, P_ACCUM);
             HIP_TRY(launch_accumulate(c->stream, c->d_codes, c->stride_words, rows, c->d_lut, c->geom,
                                       c->d_part));
@@ -496,6 +531,8 @@ static int run_batch(nps_ctx *c) {
                                      dev_params(c->params), c->d_ds_rowp, c->d_ds_stats, c->d_nloci));
         }
         {
+            int rc = ensure_all_chunks(c);
+            if (rc) return rc;
             ProfScope ps(c, P_ACCUM);
             HIP_TRY(launch_ds_accumulate(c->stream, c->d_ds, c->ds_stride_f, c->n, c->d_ds_rowp, drows,
                                          c->d_part, c->n_chunks, c->geom.part_chunk_stride));
@@ -584,7 +621,7 @@ static int push_gt_polyploid(nps_ctx *c, const void *gts, int elem_bytes, int pl
 
 static int push_gt_typed(nps_ctx *c, const void *gts, int elem_bytes, int ploidy, int eaidx,
                          int ref_is_effect, double beta, double eaf) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (int urc = check_usable(c)) return urc;
     if (c->n && !gts) return fail(NPS_E_INVAL, "gts is NULL");
     if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
         return fail(NPS_E_INVAL, "elem_bytes %d (1, 2 or 4)", elem_bytes);
@@ -627,7 +664,7 @@ extern "C" int nps_push_gt_raw(nps_ctx *c, const void *gt, int elem_bytes, int p
 
 extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effect, double beta,
                                double eaf) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (int urc = check_usable(c)) return urc;
     if (c->n && !row) return fail(NPS_E_INVAL, "row is NULL");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t slot;
@@ -652,7 +689,7 @@ extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effec
 
 extern "C" int nps_push_bed(nps_ctx *c, const uint8_t *bed_row, int effect_is_a1, int ref_is_effect,
                             double beta, double eaf) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (int urc = check_usable(c)) return urc;
     if (c->n && !bed_row) return fail(NPS_E_INVAL, "bed_row is NULL");
     HIP_TRY(hipSetDevice(c->device));
     uint32_t slot;
@@ -710,7 +747,7 @@ static int ensure_ds(nps_ctx *c) {
 }
 
 extern "C" int nps_push_ds(nps_ctx *c, const float *ds, int ref_is_effect, double beta, double eaf) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (int urc = check_usable(c)) return urc;
     if (c->n && !ds) return fail(NPS_E_INVAL, "ds is NULL");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_ds(c);
@@ -744,7 +781,7 @@ extern "C" int nps_push_ds(nps_ctx *c, const float *ds, int ref_is_effect, doubl
 }
 
 extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double beta, double eaf) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (int urc = check_usable(c)) return urc;
     if (kind != NPS_ROW_UNCOVERED && kind != NPS_ROW_ABSENT && kind != NPS_ROW_FILTERED)
         return fail(NPS_E_INVAL, "kind %d is not a no-data row kind", kind);
     PendingRow p;
@@ -755,16 +792,34 @@ extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double be
     return NPS_OK;
 }
 
+// the device's result block (used rows, status bits) -> pinned host copy; the caller synchronises
+static int fetch_result(nps_ctx *c) {
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_nloci, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           c->stream));
+    return NPS_OK;
+}
+
+// after a stream synchronisation that followed fetch_result: did a bounded wait inside a fused kernel
+// expire?  The bit is sticky until nps_reset (the scores of this context are invalid).
+static int check_status(nps_ctx *c) {
+    if (c->h_result[1] & 1ull)
+        return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
+                                   "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
+    return NPS_OK;
+}
+
 extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size_t *n_out) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    int rc = check_usable(c);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = NPS_OK;
     if (stats_out) rc = materialize_resident_stats(c);
     if (rc) return rc;
     rc = run_batch(c);
     if (rc) return rc;
+    rc = fetch_result(c);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    rc = check_timeout(c);
+    rc = check_status(c);
     if (rc) return rc;
     size_t n = 0;
     if (stats_out) {
@@ -778,71 +833,52 @@ extern "C" int nps_flush(nps_ctx *c, nps_locus_stat *stats_out, size_t cap, size
     return NPS_OK;
 }
 
-// after a stream synchronisation: did a bounded wait inside the fused kernel expire?
-static int check_timeout(nps_ctx *c) {
-    if (!c->timeout_check) return NPS_OK;
-    c->timeout_check = false;
-    if (c->h_timeout) {
-        c->h_timeout = 0;
-        return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
-                                   "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
-    }
-    return NPS_OK;
-}
-
-static int finish_common(nps_ctx *c, double offset, double *d_dst, uint64_t *nloci_out,
-                         bool normalise = true) {
+// nimpress.nim:643-649 on the device, one enqueue and ONE synchronisation: the finish kernel reads
+// the device's count of used rows itself, the count and the status bits come back in the same copy
+// as (optionally) the scores.
+static int finish_common(nps_ctx *c, double offset, double *d_dst, double *h_scores_out,
+                         uint64_t *nloci_out, bool normalise = true) {
     int rc = run_batch(c);
     if (rc) return rc;
-    unsigned long long dev_nloci = 0;
-    HIP_TRY(hipMemcpyAsync(&dev_nloci, c->d_nloci, sizeof dev_nloci, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    rc = check_timeout(c);
-    if (rc) return rc;
-    const uint64_t nloci = c->host_nloci + dev_nloci;
-    if (nloci_out) *nloci_out = nloci;
     if (c->n) {
-        // x / 1.0 + 0.0 == x: the same kernel hands out the un-normalised sums
-        const double denom = normalise ? (double)nloci * 2.0 : 1.0;  // nimpress.nim:645
         ProfScope ps(c, P_REDUCE);
-        HIP_TRY(launch_finish(c->stream, c->d_part, c->n_chunks, c->geom.part_chunk_stride, c->n,
-                              c->const_sum, denom, normalise ? offset : 0.0, d_dst));
+        HIP_TRY(launch_finish(c->stream, c->d_part, c->chunks_used, c->geom.part_chunk_stride, c->n,
+                              c->const_sum, c->d_nloci, c->host_nloci, normalise ? 1 : 0, offset, d_dst));
     }
+    rc = fetch_result(c);
+    if (rc) return rc;
+    if (h_scores_out && c->n)
+        HIP_TRY(hipMemcpyAsync(h_scores_out, d_dst, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    if (rc) return rc;
+    if (nloci_out) *nloci_out = c->host_nloci + c->h_result[0];
     return NPS_OK;
 }
 
 extern "C" int nps_finish(nps_ctx *c, double offset, double *scores_out, uint64_t *nloci_out) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    int rc = check_usable(c);
+    if (rc) return rc;
     if (c->n && !scores_out) return fail(NPS_E_INVAL, "scores_out is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = finish_common(c, offset, c->d_scores, nloci_out);
-    if (rc) return rc;
-    if (c->n)
-        HIP_TRY(hipMemcpyAsync(scores_out, c->d_scores, sizeof(double) * c->n, hipMemcpyDeviceToHost,
-                               c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return NPS_OK;
+    return finish_common(c, offset, c->d_scores, scores_out, nloci_out);
 }
 
 extern "C" int nps_finish_device(nps_ctx *c, double offset, double *d_scores_out,
                                  uint64_t *nloci_out) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    int rc = check_usable(c);
+    if (rc) return rc;
     if (c->n && !d_scores_out) return fail(NPS_E_INVAL, "d_scores_out is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = finish_common(c, offset, d_scores_out, nloci_out);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return NPS_OK;
+    return finish_common(c, offset, d_scores_out, nullptr, nloci_out);
 }
 
 extern "C" int nps_partial_device(nps_ctx *c, double *d_sums_out, uint64_t *nloci_out) {
-    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    int rc = check_usable(c);
+    if (rc) return rc;
     if (c->n && !d_sums_out) return fail(NPS_E_INVAL, "d_sums_out is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = finish_common(c, 0.0, d_sums_out, nloci_out, false);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return NPS_OK;
+    return finish_common(c, 0.0, d_sums_out, nullptr, nloci_out, false);
 }
 
 extern "C" int nps_normalize_device(nps_ctx *c, double *d_sums, uint64_t nloci, double offset) {
@@ -852,7 +888,7 @@ extern "C" int nps_normalize_device(nps_ctx *c, double *d_sums, uint64_t nloci, 
     if (c->n) {
         // one "chunk" = the reduced sums themselves, in place (every thread reads and writes its own i)
         ProfScope ps(c, P_REDUCE);
-        HIP_TRY(launch_finish(c->stream, d_sums, 1, c->n, c->n, 0.0, (double)nloci * 2.0, offset, d_sums));
+        HIP_TRY(launch_finish(c->stream, d_sums, 1, c->n, c->n, 0.0, nullptr, nloci, 1, offset, d_sums));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return NPS_OK;
@@ -923,6 +959,7 @@ extern "C" int nps_cohort_optimize(nps_cohort *c) {
     if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
     if (c->format != NPS_FMT_GT2 || c->optimized || c->n_rows == 0 || c->n_samples == 0) return NPS_OK;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows moved here
     const uint64_t n_groups = (c->n_rows + 3) / 4;
     uint32_t *d_counts = nullptr;
     if (!c->d_swap) HIP_TRY(hipMalloc(&c->d_swap, n_groups));
@@ -1021,6 +1058,7 @@ extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (!bed_rows || !effect_is_a1 || row_stride_bytes < width)
         return fail(NPS_E_INVAL, "bad .bed buffer / stride / flags");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     rc = cohort_unoptimize(c);
     if (rc) return rc;
     return gt2_upload(c, row0, nrows, bed_rows, row_stride_bytes, width, effect_is_a1);
@@ -1034,6 +1072,7 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     if (c->format == NPS_FMT_GT2) {
         rc = cohort_unoptimize(c);
         if (rc) return rc;
@@ -1068,6 +1107,7 @@ extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, ui
     if (c->format == NPS_FMT_GT2 && (row0 & 3))
         return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     rc = cohort_unoptimize(c);
     if (rc) return rc;
     uint32_t *d_t = nullptr;
@@ -1161,6 +1201,9 @@ extern "C" void nps_scoredef_destroy(nps_scoredef *d) {
 
 // ------------------------------------------------------------------------------------------
 // resident scoring.  Two-pass mode: per block of rows, tally -> params -> accumulate.
+#ifdef NPS_DIAGNOSTICS
+// run-time switches exist in diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): the release
+// library reads no environment variable on its launch path
 static uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
@@ -1168,6 +1211,9 @@ static uint64_t env_u64(const char *name, uint64_t dflt) {
     unsigned long long v = strtoull(s, &end, 10);
     return end && *end == 0 ? (uint64_t)v : dflt;
 }
+#else
+static inline uint64_t env_u64(const char *, uint64_t dflt) { return dflt; }
+#endif
 
 // stats of the last resident run stay on the device until somebody asks for them
 static int materialize_resident_stats(nps_ctx *c) {
@@ -1195,6 +1241,18 @@ static int materialize_resident_stats(nps_ctx *c) {
     return NPS_OK;
 }
 
+// (re)allocation helper: *p holds at least `need` elements of `elem` bytes afterwards
+static int grow(nps_ctx *c, void **p, uint64_t *cap, uint64_t need, size_t elem) {
+    if (need <= *cap) return NPS_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(p, elem * need));
+    *cap = need;
+    return NPS_OK;
+}
+
 static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     if (m_pad <= c->res_cap) return NPS_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1205,6 +1263,7 @@ static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     c->d_rlut = nullptr;
     c->d_rstats = nullptr;
     c->res_cap = 0;
+    c->rtally_clean = false;
     HIP_TRY(hipMalloc(&c->d_rtally, sizeof(unsigned long long) * m_pad));
     HIP_TRY(hipMalloc(&c->d_rlut, sizeof(double) * 4 * m_pad));
     HIP_TRY(hipMalloc(&c->d_rstats, sizeof(nps_locus_stat) * m_pad));
@@ -1212,9 +1271,16 @@ static int ensure_resident_buffers(nps_ctx *c, uint64_t m_pad) {
     return NPS_OK;
 }
 
+// Everything that can be refused is checked BEFORE the context changes: a call that returns an error
+// from its validation leaves the context exactly as it was, so it can be repeated (e.g. in another
+// mode).  The rows without genotype data are applied, and the run is registered for nps_flush, only
+// once all launches have been queued; a failure between the first and the last launch marks the
+// context broken (NPS_E_STATE until nps_reset).
 extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t cohort_row0,
                                     const nps_scoredef *def, int mode) {
-    if (!c || !co || !def) return fail(NPS_E_INVAL, "ctx, cohort or scoredef is NULL");
+    int rc = check_usable(c);
+    if (rc) return rc;
+    if (!co || !def) return fail(NPS_E_INVAL, "cohort or scoredef is NULL");
     if (co->device != c->device || def->device != c->device)
         return fail(NPS_E_INVAL, "cohort / scoredef / context on different devices");
     if (co->n_samples != c->n)
@@ -1222,79 +1288,130 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                     (unsigned long long)co->n_samples, (unsigned long long)c->n);
     if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
-    HIP_TRY(hipSetDevice(c->device));
-    FusedPlan plan;
-    if (mode != NPS_MODE_TWOPASS) {
-        if (co->format == NPS_FMT_DS32)
-            HIP_TRY(ds_fused_plan(c->device, c->n, def->m, &plan));
-        else
-            HIP_TRY(fused_plan(c->device, c->n, def->m, (int)env_u64("NPS_FUSED_THREADS", 0), &plan));
-        if (const char *e = getenv("NPS_DISABLE_FUSED"))
-            if (*e == '1' && mode == NPS_MODE_AUTO) plan.ok = false;
-        if (!plan.ok && mode == NPS_MODE_FUSED && c->n && def->m)
-            return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the fused "
-                        "persistent grid", (unsigned long long)c->n, (unsigned long long)def->m);
-    }
-    int rc = run_batch(c);  // keep push order: finish whatever was streamed before
-    if (rc) return rc;
-    rc = materialize_resident_stats(c);
-    if (rc) return rc;
     const uint64_t m = def->m;
     rc = check_range(co, cohort_row0, m);
     if (rc) return rc;
-
-    // rows without genotype data, in order (host decided; nimpress.nim:526-558)
-    c->res_host_stats.clear();
-    c->res_host_stats.reserve(def->host_rows.size());
-    for (const nps_row_desc &r : def->host_rows) {
-        nps_locus_stat st;
-        host_locus_row(c, r.kind, r.ref_is_effect, r.beta, r.eaf, &st);
-        c->res_host_stats.push_back(st);
+    const bool is_ds = co->format == NPS_FMT_DS32;
+    if (!is_ds && (cohort_row0 & 3))
+        return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
+    if (!is_ds && co->optimized && ((cohort_row0 + m) & 3) && cohort_row0 + m != co->n_rows)
+        return fail(NPS_E_UNSUPPORTED, "an optimised cohort is scored in whole groups of 4 rows: "
+                    "cohort_row0 + rows must be a multiple of 4 or the end of the cohort");
+    HIP_TRY(hipSetDevice(c->device));
+    FusedPlan plan;
+    if (mode != NPS_MODE_TWOPASS && m && c->n) {
+        if (c->plan_valid && c->plan_fmt == co->format && c->plan_m == m) {
+            plan = c->plan_cache;
+        } else {
+            const int want = (int)env_u64("NPS_FUSED_THREADS", 0), max_q = (int)env_u64("NPS_FUSED_MAXQ", 0);
+            if (is_ds)
+                HIP_TRY(ds_fused_plan(c->device, c->n, m, want, max_q, &plan));
+            else
+                HIP_TRY(fused_plan(c->device, c->n, m, want, max_q, &plan));
+            c->plan_cache = plan;
+            c->plan_fmt = co->format;
+            c->plan_m = m;
+            c->plan_valid = true;
+        }
+        if (env_u64("NPS_DISABLE_FUSED", 0) == 1 && mode == NPS_MODE_AUTO) plan.ok = false;
+        if (!plan.ok && mode == NPS_MODE_FUSED)
+            return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the fused "
+                        "persistent grid", (unsigned long long)c->n, (unsigned long long)m);
     }
-    c->res_index = def->data_index;
-    c->res_m = m;
-    c->res_pending = true;
-    if (m == 0) return NPS_OK;
 
+    rc = run_batch(c);  // keep push order: finish whatever was streamed before
+    if (rc) return rc;
+    rc = materialize_resident_stats(c);
+    if (rc) return rc;
+
+    // the run is registered only after its launches are queued (commit below)
+    auto commit = [&]() {
+        c->res_host_stats.clear();
+        c->res_host_stats.reserve(def->host_rows.size());
+        for (const nps_row_desc &r : def->host_rows) {  // host decided; nimpress.nim:526-558
+            nps_locus_stat st;
+            host_locus_row(c, r.kind, r.ref_is_effect, r.beta, r.eaf, &st);
+            c->res_host_stats.push_back(st);
+        }
+        c->res_index = def->data_index;
+        c->res_m = m;
+        c->res_pending = true;
+        c->res_swap.clear();
+        if (m && !is_ds && co->optimized)
+            c->res_swap.assign(co->h_swap.begin() + (long)(cohort_row0 >> 2),
+                               co->h_swap.begin() + (long)((cohort_row0 + m + 3) >> 2));
+    };
+    if (m == 0) {
+        commit();
+        return NPS_OK;
+    }
+
+    // buffers (a failed allocation leaves the context usable: nothing has been queued yet)
     const uint64_t m_pad = (m + 15) / 16 * 16;
     rc = ensure_resident_buffers(c, m_pad);
     if (rc) return rc;
-    if (co->format == NPS_FMT_DS32) {
+    const bool fused = plan.ok && c->n;
+    if (fused) {
+        rc = grow(c, (void **)&c->d_part_fused, &c->part_fused_cap,
+                  (uint64_t)plan.Q * plan.part_team_stride, sizeof(double));
+        if (rc) return rc;
+    }
+    if (is_ds) {
         if (m_pad > c->res_ds_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_rds_tally);
-            (void)hipFree(c->d_rds_rowp);
-            c->d_rds_tally = nullptr;
-            c->d_rds_rowp = nullptr;
-            c->res_ds_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_rds_tally, sizeof(DsTally) * m_pad));
-            HIP_TRY(hipMalloc(&c->d_rds_rowp, sizeof(DsRowP) * m_pad));
-            c->res_ds_cap = m_pad;
+            uint64_t cap_a = c->res_ds_cap, cap_b = c->res_ds_cap;
+            rc = grow(c, (void **)&c->d_rds_tally, &cap_a, m_pad, sizeof(DsTally));
+            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_rds_rowp, &cap_b, m_pad, sizeof(DsRowP));
+            c->res_ds_cap = std::min(cap_a, cap_b);
+            if (rc) return rc;
         }
+        if (fused) {
+            rc = grow(c, (void **)&c->d_rds_psum, &c->psum_cap, m * plan.P, sizeof(double));
+            if (rc) return rc;
+        }
+    } else if (co->optimized) {
+        rc = grow(c, (void **)&c->d_desc_perm, &c->desc_perm_cap, m_pad, sizeof(nps_row_desc));
+        if (rc) return rc;
+    }
+
+    // ---- launches.  From here on an error leaves queued work behind: the context is marked broken.
+    struct Guard {
+        nps_ctx *c;
+        bool armed = false, ok = false;  // armed: a launch that changes the context's sums is queued
+        ~Guard() { if (armed && !ok) c->broken = true; }
+    } guard{c};
+    auto done = [&]() {
+        commit();
+        guard.ok = true;
+        return NPS_OK;
+    };
+    // the fused kernels' tally words must be zero on entry; their epilogue (fold_kernel) leaves them so
+    auto tally_ready = [&]() -> int {
+        if (!c->rtally_clean)
+            HIP_TRY(hipMemsetAsync(c->d_rtally, 0, sizeof(unsigned long long) * c->res_cap, c->stream));
+        c->rtally_clean = false;
+        return NPS_OK;
+    };
+    auto epilogue = [&]() -> int {
+        ProfScope ps(c, P_REDUCE);
+        HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n, c->d_part,
+                            c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_timeout,
+                            c->d_nloci + 1));
+        c->chunks_used = std::max(c->chunks_used, 1u);
+        c->rtally_clean = true;  // all words were zero before the run, [0, m_pad) are zero again
+        return NPS_OK;
+    };
+
+    if (is_ds) {
         const uint64_t stride_f = co->stride_bytes / 4;
         const float *ds = (const float *)co->d_data + cohort_row0 * stride_f;
-        if (plan.ok && c->n) {
-            // fused single-read path
-            const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
-            if (need > c->part_fused_cap) {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                (void)hipFree(c->d_part_fused);
-                c->d_part_fused = nullptr;
-                c->part_fused_cap = 0;
-                HIP_TRY(hipMalloc(&c->d_part_fused, sizeof(double) * need));
-                c->part_fused_cap = need;
-            }
-            const uint64_t need_psum = m * plan.P;
-            if (need_psum > c->psum_cap) {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                (void)hipFree(c->d_rds_psum);
-                c->d_rds_psum = nullptr;
-                c->psum_cap = 0;
-                HIP_TRY(hipMalloc(&c->d_rds_psum, sizeof(double) * need_psum));
-                c->psum_cap = need_psum;
-            }
-            HIP_TRY(hipMemsetAsync(c->d_rtally, 0, sizeof(unsigned long long) * m_pad, c->stream));
-            HIP_TRY(hipMemsetAsync(c->d_timeout, 0, 256, c->stream));
+        if (fused) {
+            rc = tally_ready();
+            if (rc) return rc;
+#ifdef NPS_DIAGNOSTICS
+            // soak / test builds: a consumer that read a partial sum before it was stored would see
+            // NaNs instead of the previous pass's (identical) bits
+            HIP_TRY(hipMemsetAsync(c->d_rds_psum, 0xFF, sizeof(double) * m * plan.P, c->stream));
+#endif
             hipError_t fe;
             {
                 ProfScope ps(c, P_FUSED);
@@ -1303,17 +1420,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                      c->d_nloci, c->d_part_fused, c->d_timeout);
             }
             if (fe == hipSuccess) {
-                {
-                    ProfScope ps(c, P_REDUCE);
-                    HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n,
-                                        c->d_part));
-                }
-                HIP_TRY(hipMemcpyAsync(&c->h_timeout, c->d_timeout, sizeof(unsigned int),
-                                       hipMemcpyDeviceToHost, c->stream));
-                c->timeout_check = true;
-                return NPS_OK;
+                guard.armed = true;
+                rc = epilogue();
+                if (rc) return rc;
+                return done();
             }
             (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
+            c->rtally_clean = true;   // (zeroed above, untouched)
             if (mode == NPS_MODE_FUSED || fe != hipErrorCooperativeLaunchTooLarge)
                 return fail(NPS_E_HIP, "fused DS kernel launch failed: %s", hipGetErrorString(fe));
         }
@@ -1321,6 +1434,9 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         // tally; samples x row chunks in the accumulation)
         uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
         if (block_rows == 0) block_rows = std::max<uint64_t>(2048, (256ull << 20) / co->stride_bytes);
+        rc = ensure_all_chunks(c);
+        if (rc) return rc;
+        guard.armed = true;
         for (uint64_t r0 = 0; r0 < m; r0 += block_rows) {
             const uint64_t k = std::min(block_rows, m - r0);
             {
@@ -1341,50 +1457,23 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                              c->geom.part_chunk_stride));
             }
         }
-        return NPS_OK;
+        return done();
     }
-    if (cohort_row0 & 3)
-        return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
+
     const uint64_t stride_words = co->stride_bytes / 4;
     const uint32_t *codes = (const uint32_t *)co->d_data + (cohort_row0 >> 2) * stride_words * 4;
     const nps_row_desc *d_desc = def->d_desc;
-    c->res_swap.clear();
     if (co->optimized) {
-        // rows of a group have changed places: the scored range must consist of whole groups, the row
-        // descriptors go into slot order and the per-row results come back through the same exchange
-        if (((cohort_row0 + m) & 3) && cohort_row0 + m != co->n_rows)
-            return fail(NPS_E_UNSUPPORTED, "an optimised cohort is scored in whole groups of 4 rows: "
-                        "cohort_row0 + rows must be a multiple of 4 or the end of the cohort");
-        if (m_pad > c->desc_perm_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_desc_perm);
-            c->d_desc_perm = nullptr;
-            c->desc_perm_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_desc_perm, sizeof(nps_row_desc) * m_pad));
-            c->desc_perm_cap = m_pad;
-        }
-        {
-            ProfScope ps(c, P_PARAMS);
-            HIP_TRY(launch_permute_desc(c->stream, def->d_desc, c->d_desc_perm,
-                                        co->d_swap + (cohort_row0 >> 2), m));
-        }
+        // rows of a group have changed places: the row descriptors go into slot order and the per-row
+        // results come back through the same exchange
+        ProfScope ps(c, P_PARAMS);
+        HIP_TRY(launch_permute_desc(c->stream, def->d_desc, c->d_desc_perm,
+                                    co->d_swap + (cohort_row0 >> 2), m));
         d_desc = c->d_desc_perm;
-        c->res_swap.assign(co->h_swap.begin() + (long)(cohort_row0 >> 2),
-                           co->h_swap.begin() + (long)((cohort_row0 + m + 3) >> 2));
     }
-    if (plan.ok && c->n) {
-        // fused single-read path
-        const uint64_t need = (uint64_t)plan.Q * plan.part_team_stride;
-        if (need > c->part_fused_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_part_fused);
-            c->d_part_fused = nullptr;
-            c->part_fused_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_part_fused, sizeof(double) * need));
-            c->part_fused_cap = need;
-        }
-        HIP_TRY(hipMemsetAsync(c->d_rtally, 0, sizeof(unsigned long long) * m_pad, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_timeout, 0, 256, c->stream));
+    if (fused) {
+        rc = tally_ready();
+        if (rc) return rc;
         hipError_t fe;
         {
             ProfScope ps(c, P_FUSED);
@@ -1393,27 +1482,26 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                               c->d_part_fused, c->d_timeout);
         }
         if (fe == hipSuccess) {
-            {
-                ProfScope ps(c, P_REDUCE);
-                HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n,
-                                    c->d_part));
-            }
-            HIP_TRY(hipMemcpyAsync(&c->h_timeout, c->d_timeout, sizeof(unsigned int),
-                                   hipMemcpyDeviceToHost, c->stream));
-            c->timeout_check = true;
+            guard.armed = true;
+            rc = epilogue();
+            if (rc) return rc;
+#ifdef NPS_DIAGNOSTICS
             if (getenv("NPS_TELEMETRY")) {  // diagnostics of the control wave (cycles, summed)
                 unsigned long long t[8] = {0};
                 (void)hipStreamSynchronize(c->stream);
                 (void)hipMemcpy(t, (char *)c->d_timeout + 16, sizeof t, hipMemcpyDeviceToHost);
+                (void)hipMemset((char *)c->d_timeout + 16, 0, sizeof t);
                 const double wg = (double)plan.P * plan.Q, st = t[4] ? (double)t[4] : 1.0;
                 fprintf(stderr, "[nps] fused P=%u Q=%u T=%u: per step per WG: spins %.2f, poll wait "
                         "%.0f cyc, control chain %.0f cyc, barrier wait %.0f cyc (steps/WG %.0f)\n",
                         plan.P, plan.Q, plan.threads, t[0] / st, t[1] / st, t[2] / st, t[3] / st, st / wg);
             }
-            return NPS_OK;
+#endif
+            return done();
         }
         // the runtime refused the cooperative grid (it would not be fully resident): nothing ran
         (void)hipGetLastError();
+        c->rtally_clean = true;
         if (mode == NPS_MODE_FUSED || fe != hipErrorCooperativeLaunchTooLarge)
             return fail(NPS_E_HIP, "fused kernel launch failed: %s", hipGetErrorString(fe));
     }
@@ -1422,6 +1510,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
     if (block_rows == 0) block_rows = std::max<uint64_t>(64, (96ull << 20) / co->stride_bytes);
     block_rows = (block_rows + 15) / 16 * 16;
+    rc = ensure_all_chunks(c);
+    if (rc) return rc;
+    guard.armed = true;
+    c->rtally_clean = false;  // the two-pass tally kernel leaves its counts in d_rtally
     for (uint64_t r0 = 0; r0 < m; r0 += block_rows) {
         const uint64_t k = std::min(block_rows, m - r0);
         const uint64_t k_pad = (k + 3) / 4 * 4;  // only the last block can be ragged
@@ -1445,7 +1537,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                       c->d_rlut + r0 * 4, g, c->d_part));
         }
     }
-    return NPS_OK;
+    return done();
 }
 
 extern "C" int nps_score_cohort(nps_ctx *c, const nps_cohort *co, uint64_t cohort_row0,

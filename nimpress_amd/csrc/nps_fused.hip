@@ -52,10 +52,16 @@ struct FusedArgs {
     double *part;               // [Q][part_team_stride]
     uint64_t part_team_stride;
     unsigned int *timeout;      // zeroed before the launch
-    unsigned long long *telemetry;  // 8 counters (control-wave variant), zeroed before the launch
-    int dbg_same_rows;              // diagnostics only: bit 0 every batch re-reads rows 0..15 (L2
-                                    // hits), bit 1 skip the accumulation
+    unsigned long long *telemetry;  // diagnostics builds only: 8 counters of the control wave
 };
+
+// control-wave telemetry (cycles spent polling / in the chain / at the barrier) exists in diagnostics
+// builds only (-DNPS_DIAGNOSTICS, tools/mkexp.sh); the release kernel carries none of it
+#ifdef NPS_DIAGNOSTICS
+#define NPS_TEL(x) x
+#else
+#define NPS_TEL(x)
+#endif
 
 // popcounts of one device word, packed popc(w) << 16 | missing.  With the codes 00/01/11 = dosage
 // 0/1/2 and 10 = missing, popc(w) = effect alleles + missing samples: five VALU ops per row word.
@@ -199,7 +205,8 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         // ------------------------------------------------------------------ control wave
         uint32_t nloci_local = 0;
         bool timed_out = false;
-        unsigned long long tel_spins = 0, tel_wait = 0, tel_chain = 0, tel_bar = 0;  // telemetry
+        NPS_TEL(unsigned long long tel_spins = 0; unsigned long long tel_wait = 0;
+                unsigned long long tel_chain = 0; unsigned long long tel_bar = 0;)
 
         auto publish = [&](uint32_t k) {  // the tally slots of batch k are complete (barrier passed)
             // lane = (row of the batch, DPP row of the data waves): sum the four quad lanes of that slot
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
             unsigned long long x = 0;
             double beta = 0.0, eaf = 0.0;
             bool rie = false;
-            const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
+            NPS_TEL(const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();)
             if (valid) {
                 x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 beta = a.desc[row].beta;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
             bool ok = !valid || (uint32_t)(x >> 56) == a.P;
             uint32_t spins = 0;
             while (!__all(ok) && !timed_out) {
-                ++tel_spins;
+                NPS_TEL(++tel_spins;)
                 __builtin_amdgcn_s_sleep(1);
                 if (!ok) {
                     x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
                     }
                 }
             }
-            tel_wait += __builtin_amdgcn_s_memtime() - t_w0;
+            NPS_TEL(tel_wait += __builtin_amdgcn_s_memtime() - t_w0;)
             int used = 0;
             if (lane < kRowsPerBatch) {
                 double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -296,22 +303,21 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         phase(1, 0);
         __syncthreads();  // #2
         for (uint32_t k = 0; k < n_steps; ++k) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            NPS_TEL(const unsigned long long t0 = __builtin_amdgcn_s_memtime();)
             phase(k + 2, k + 1);
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            NPS_TEL(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
             __syncthreads();  // #(k+3)
-            tel_chain += t1 - t0;
-            tel_bar += __builtin_amdgcn_s_memtime() - t1;
+            NPS_TEL(tel_chain += t1 - t0; tel_bar += __builtin_amdgcn_s_memtime() - t1;)
         }
         if (slice == 0 && lane == 0 && nloci_local)
             atomicAdd(a.nloci, (unsigned long long)nloci_local);
-        if (lane == 0 && a.telemetry) {  // summed over workgroups; read by the host for diagnostics
+        NPS_TEL(if (lane == 0 && a.telemetry) {  // summed over workgroups; read by the host
             atomicAdd(&a.telemetry[0], tel_spins);
             atomicAdd(&a.telemetry[1], tel_wait);
             atomicAdd(&a.telemetry[2], tel_chain);
             atomicAdd(&a.telemetry[3], tel_bar);
             atomicAdd(&a.telemetry[4], (unsigned long long)n_steps);
-        }
+        })
         return;
     }
 
@@ -451,20 +457,31 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     }
 }
 
-// part0[i] += sum_q part[q][i]  (fold the teams' partial scores into chunk 0 of the context)
+// Epilogue of a fused pass: part0[i] (+)= sum_q part[q][i] (the teams' partial scores, fixed order, into
+// chunk 0 of the context); the tally words go back to zero for the next pass (every slice has read
+// them); a raised bounded-wait word is recorded in the context's sticky status word and cleared.
 __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ part, uint32_t Q,
                                                    uint64_t team_stride, uint64_t n,
-                                                   double *__restrict__ part0) {
+                                                   double *__restrict__ part0, int overwrite,
+                                                   unsigned long long *__restrict__ tally, uint64_t n_tally,
+                                                   unsigned int *__restrict__ timeout,
+                                                   unsigned long long *__restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    for (uint64_t j = i; j < n_tally; j += nthreads) tally[j] = 0ull;
+    if (i == 0 && timeout) {
+        if (*timeout) atomicOr(status, 1ull);
+        *timeout = 0u;
+    }
     if (i >= n) return;
     double s = 0.0;
     for (uint32_t q = 0; q < Q; ++q) s += part[(uint64_t)q * team_stride + i];
-    part0[i] += s;
+    part0[i] = overwrite ? s : part0[i] + s;
 }
 
 // ---- host side ------------------------------------------------------------------------------
 template <int T>
-static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedPlan *plan) {
+static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, int max_q, FusedPlan *plan) {
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T, 0>, T, 0);
     if (e != hipSuccess) return e;
@@ -476,8 +493,7 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedP
     const uint64_t P = (n_words + cols - 1) / cols;
     if (P > capacity || P > 255) return hipSuccess;  // 8-bit arrival count in the tally word
     uint64_t Q = std::min<uint64_t>(capacity / P, n_batches);
-    if (const char *e = getenv("NPS_FUSED_MAXQ"))  // diagnostics: fewer teams = fewer CUs in use
-        if (atoi(e) > 0) Q = std::min<uint64_t>(Q, (uint64_t)atoi(e));
+    if (max_q > 0) Q = std::min<uint64_t>(Q, (uint64_t)max_q);  // diagnostics: fewer CUs in use
     if (Q < 1 || Q > 65535) return hipSuccess;
     plan->threads = T;
     plan->P = (uint32_t)P;
@@ -488,7 +504,7 @@ static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, FusedP
     return hipSuccess;
 }
 
-hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads,
+hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads, int max_q,
                       FusedPlan *plan) {
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;
@@ -503,13 +519,13 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
     auto try_plan = [&](int threads, FusedPlan *out) -> hipError_t {
         *out = FusedPlan{};
         switch (threads) {
-        case 256: return plan_for<256>(cus, n_words, n_batches, out);
-        case 512: return plan_for<512>(cus, n_words, n_batches, out);
-        case 768: return plan_for<768>(cus, n_words, n_batches, out);
-        case 832: return plan_for<832>(cus, n_words, n_batches, out);
-        case 896: return plan_for<896>(cus, n_words, n_batches, out);
-        case 960: return plan_for<960>(cus, n_words, n_batches, out);
-        case 1024: return plan_for<1024>(cus, n_words, n_batches, out);
+        case 256: return plan_for<256>(cus, n_words, n_batches, max_q, out);
+        case 512: return plan_for<512>(cus, n_words, n_batches, max_q, out);
+        case 768: return plan_for<768>(cus, n_words, n_batches, max_q, out);
+        case 832: return plan_for<832>(cus, n_words, n_batches, max_q, out);
+        case 896: return plan_for<896>(cus, n_words, n_batches, max_q, out);
+        case 960: return plan_for<960>(cus, n_words, n_batches, max_q, out);
+        case 1024: return plan_for<1024>(cus, n_words, n_batches, max_q, out);
         default: return hipErrorInvalidValue;
         }
     };
@@ -551,32 +567,35 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
     a.part_team_stride = plan.part_team_stride;
     a.timeout = d_timeout;
     a.telemetry = reinterpret_cast<unsigned long long *>(d_timeout) + 2;  // same 256-byte block
-    a.dbg_same_rows = getenv("NPS_DEBUG_FLAGS") ? atoi(getenv("NPS_DEBUG_FLAGS")) : 0;
     void *args[] = {&a};
-    const void *fn;
-    const int dbg = a.dbg_same_rows & 3;
-    if (dbg && plan.threads == 1024)  // diagnostics builds exist for T = 1024 only
+    const void *fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256, 0>
+                     : plan.threads == 512 ? (const void *)fused_cw_kernel<512, 0>
+                     : plan.threads == 768 ? (const void *)fused_cw_kernel<768, 0>
+                     : plan.threads == 832 ? (const void *)fused_cw_kernel<832, 0>
+                     : plan.threads == 896 ? (const void *)fused_cw_kernel<896, 0>
+                     : plan.threads == 960 ? (const void *)fused_cw_kernel<960, 0>
+                                           : (const void *)fused_cw_kernel<1024, 0>;
+#ifdef NPS_DIAGNOSTICS
+    // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_DEBUG_FLAGS bit 0 = every batch
+    // re-reads rows 0..15 (L2 hits), bit 1 = skip the accumulation; instantiated for T = 1024 only
+    const int dbg = getenv("NPS_DEBUG_FLAGS") ? atoi(getenv("NPS_DEBUG_FLAGS")) & 3 : 0;
+    if (dbg && plan.threads == 1024)
         fn = dbg == 1   ? (const void *)fused_cw_kernel<1024, 1>
              : dbg == 2 ? (const void *)fused_cw_kernel<1024, 2>
                         : (const void *)fused_cw_kernel<1024, 3>;
-    else
-        fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256, 0>
-             : plan.threads == 512 ? (const void *)fused_cw_kernel<512, 0>
-             : plan.threads == 768 ? (const void *)fused_cw_kernel<768, 0>
-             : plan.threads == 832 ? (const void *)fused_cw_kernel<832, 0>
-             : plan.threads == 896 ? (const void *)fused_cw_kernel<896, 0>
-             : plan.threads == 960 ? (const void *)fused_cw_kernel<960, 0>
-                                   : (const void *)fused_cw_kernel<1024, 0>;
+#endif
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
 }
 
 hipError_t launch_fold(hipStream_t st, const double *d_part, uint32_t Q, uint64_t team_stride,
-                       uint64_t n_samples, double *d_part0) {
-    if (n_samples == 0 || Q == 0) return hipSuccess;
+                       uint64_t n_samples, double *d_part0, int overwrite, unsigned long long *d_tally,
+                       uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status) {
+    if (Q == 0) return hipSuccess;
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
-    hipLaunchKernelGGL(fold_kernel, dim3((uint32_t)((n_samples + 255) / 256)), dim3(256), 0, st,
-                       d_part, Q, team_stride, n_samples, d_part0);
+    const uint64_t blocks = std::max<uint64_t>(1, (n_samples + 255) / 256);
+    hipLaunchKernelGGL(fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_part, Q, team_stride,
+                       n_samples, d_part0, overwrite, d_tally, n_tally, d_timeout, d_status);
     return hipGetLastError();
 }
 

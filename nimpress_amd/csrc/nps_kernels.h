@@ -109,10 +109,13 @@ hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t s
                              uint64_t n_rows, const double *d_lut, const AccumGeom &g,
                              double *d_part);
 
-// scores[i] = (sum_chunks part[c][i] + const_sum) / denom + offset      nimpress.nim:643-649
+// scores[i] = (sum_chunks part[c][i] + const_sum) / (2 * nloci) + offset      nimpress.nim:643-649
+// nloci = host_nloci + *d_nloci (d_nloci may be null), read on the device so that no host round
+// trip sits between the accumulation and this kernel; normalise = 0 hands out the plain sums.
 hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks,
                          uint64_t part_chunk_stride, uint64_t n_samples, double const_sum,
-                         double denom, double offset, double *d_scores);
+                         const unsigned long long *d_nloci, uint64_t host_nloci, int normalise,
+                         double offset, double *d_scores);
 
 // synthetic cohort rows (counter-based generator shared with oracle/refcpu.c)
 hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
@@ -128,8 +131,9 @@ struct FusedPlan {
     uint32_t n_batches = 0;
     uint64_t part_team_stride = 0;  // doubles per team in the partial-score buffer
 };
-// want_threads: 0 = default, else 256 / 512 / 1024
-hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads,
+// want_threads: 0 = default, else a workgroup size the kernel is instantiated for; max_q: 0 = no limit
+// (both non-zero only in diagnostics builds)
+hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads, int max_q,
                       FusedPlan *plan);
 // d_tally: [plan.n_batches*16] zeroed; d_part: [Q*part_team_stride]; d_timeout: zeroed word
 hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d_codes,
@@ -137,8 +141,12 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
                         const nps_row_desc *d_desc, DevParams prm, unsigned long long *d_tally,
                         nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                         unsigned int *d_timeout);
+// Epilogue of a fused pass, one launch: part0[i] (+)= sum_q part[q][i] (overwrite != 0: part0 holds
+// nothing yet and is written, not read); the n_tally tally words are zeroed again for the next pass;
+// a raised bounded-wait word is ORed into *d_status and cleared.
 hipError_t launch_fold(hipStream_t st, const double *d_part, uint32_t Q, uint64_t team_stride,
-                       uint64_t n_samples, double *d_part0);
+                       uint64_t n_samples, double *d_part0, int overwrite, unsigned long long *d_tally,
+                       uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status);
 
 // ---- FORMAT/DS float32 path (nps_ds.hip) ---------------------------------------------------------
 struct DsTally {
@@ -164,7 +172,8 @@ hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stri
                                 uint32_t n_chunks, uint64_t part_chunk_stride);
 // single-read kernel for a resident DS cohort (nps_ds_fused.hip); plan.threads/P/Q as for the GT kernel.
 // d_tally: [n_rows] zeroed; d_psum: [n_rows * plan.P]; d_part: [Q*part_team_stride]
-hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, FusedPlan *plan);
+hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads, int max_q,
+                         FusedPlan *plan);
 hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
                            DevParams prm, unsigned long long *d_tally, double *d_psum,

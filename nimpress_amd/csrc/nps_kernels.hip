@@ -616,26 +616,32 @@ hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t s
 // (no __restrict__: nps_normalize_device runs it in place, every thread on its own element)
 __global__ __launch_bounds__(256) void finish_kernel(const double *part, uint32_t n_chunks,
                                                      uint64_t part_chunk_stride, uint64_t n_samples,
-                                                     double const_sum, double denom, double offset,
+                                                     double const_sum, const unsigned long long *d_nloci,
+                                                     uint64_t host_nloci, int normalise, double offset,
                                                      double *scores) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_samples) return;
     double s = 0.0;
     for (uint32_t c = 0; c < n_chunks; ++c) s += part[(uint64_t)c * part_chunk_stride + i];
     s += const_sum;
-    s /= denom;   // nimpress.nim:645
-    s += offset;  // nimpress.nim:649
+    if (normalise) {
+        const uint64_t nloci = host_nloci + (d_nloci ? (uint64_t)*d_nloci : 0ull);
+        s /= (double)nloci * 2.0;  // nimpress.nim:645 (nloci = 0: 0/0 = NaN, as in the reference)
+        s += offset;               // nimpress.nim:649
+    }
     scores[i] = s;
 }
 
 hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks,
                          uint64_t part_chunk_stride, uint64_t n_samples, double const_sum,
-                         double denom, double offset, double *d_scores) {
+                         const unsigned long long *d_nloci, uint64_t host_nloci, int normalise,
+                         double offset, double *d_scores) {
     if (n_samples == 0) return hipSuccess;
     const uint64_t blocks = (n_samples + 255) / 256;
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(finish_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_part, n_chunks,
-                       part_chunk_stride, n_samples, const_sum, denom, offset, d_scores);
+                       part_chunk_stride, n_samples, const_sum, d_nloci, host_nloci, normalise, offset,
+                       d_scores);
     return hipGetLastError();
 }
 
