@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: genotype-dosage accumulations/s on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 Workload (BASELINE.json configs[2], the configuration the north-star metric is quoted on):
 synthetic 1 000 000-variant PRS on a 500 000-sample bit-packed GT matrix (125 GB of 2-bit codes)
@@ -10,16 +10,25 @@ maxmis 0.05, mincs 100); every 1000th row has 10 % missingness so the locus-impu
 runs.  One STEP = one full pass of the hot path over the cohort: tally -> per-row decision/LUT ->
 accumulate -> /(2 nloci) + offset, inputs already in HBM, result left in a device buffer.
 
-N > 1 (weak scaling): one process per GPU (torch.distributed, backend nccl = RCCL).  Each rank
-scores ITS OWN score definition (its own betas) against its own resident copy of the cohort --
-multi-score evaluation sharded by score file, BASELINE.json north_star -- and each step ends
-with the one real exchange of the path: an RCCL all-gather of the samples x scores matrix.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started under
+torch.distributed.run the ranks come from the environment; started as plain `python bench.py --gpus N`
+this process spawns the N rank processes itself (before anything here touches a GPU) and relays
+rank 0's line.
+  --scaling weak (default): each rank scores ITS OWN score definition (its own betas) against its own
+      resident copy of the cohort -- multi-score evaluation sharded by score file, BASELINE.json
+      north_star -- and each step ends with the one real exchange of that layout, an RCCL all-gather of
+      the samples x scores matrix.
+  --scaling strong: ONE 1M-row score, its rows sharded in contiguous blocks (every GPU holds all
+      samples of its rows, so tallies stay local and exact); each step ends with the exchange of that
+      layout, a sum all-reduce of the un-normalised scores and of nloci, then /(2 nloci) + offset.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,13 +45,20 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--samples", type=int, default=500_000, help="cohort size N (default: config 3)")
     ap.add_argument("--variants", type=int, default=1_000_000, help="score rows M (default: config 3)")
     ap.add_argument("--mode", choices=["auto", "twopass", "fused"], default="auto")
     ap.add_argument("--format", choices=["gt", "ds"], default="gt",
                     help="gt: 2-bit packed GT matrix (the headline, config 3); ds: float32 FORMAT/DS "
-                         "matrix (config 5 shape: pass --samples 200000 and as many --variants as fit HBM)")
+                         "matrix (config 5: --samples 200000 --variants 2000000 --chunk-rows 300000)")
+    ap.add_argument("--chunk-rows", type=int, default=0,
+                    help="score the rows in resident chunks of this many rows, each regenerated on the "
+                         "device outside the timed segments (for matrices larger than HBM: config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (config 5 DS pass, streaming entry points, "
+                         "config 2 end to end)")
     ap.add_argument("--no-optimize", action="store_true",
                     help="skip nps_cohort_optimize (the row of each group of 4 with the most dosage-2 / "
                          "missing codes in the bank-selecting slot)")
@@ -51,14 +67,54 @@ def parse_args():
     return ap.parse_args()
 
 
-def synth_score(m, seed):
-    """SURVEY.md section 8(d) config 3: beta ~ N(0,0.02^2) and eaf ~ U(0.01,0.5), 4 decimals;
-    missing rate U(0,0.02), every 1000th row 0.10."""
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run
+def spawn_ranks(n):
+    """Start the N rank processes (this process never touches a GPU), wait for them, pass on the
+    highest exit code.  Rank 0 inherits stdout, so its JSON line is this command's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------------------
+def synth_score(m, seed, fmt="gt"):
+    """beta ~ N(0,0.02^2) and eaf ~ U(0.01,0.5), 4 decimals.  Config 3 (gt):
+    missing rate U(0,0.02), every 1000th row 0.10.  Config 5 (ds): missing rate U(0,0.10), mean 5 %."""
     rng = np.random.default_rng(seed)
     beta = np.round(rng.normal(0.0, 0.02, m), 4)
     eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
-    miss = rng.uniform(0.0, 0.02, m)
-    miss[::1000] = 0.10
+    if fmt == "ds":
+        miss = rng.uniform(0.0, 0.10, m)
+    else:
+        miss = rng.uniform(0.0, 0.02, m)
+        miss[::1000] = 0.10
     return beta, eaf, miss
 
 
@@ -73,114 +129,325 @@ def hwe_thresholds(eaf, miss):
     return t_het, t_hom, t_miss
 
 
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
 def cpu_baseline(n, eaf, miss, seed, rows):
-    """The oracle (CPU restatement of the reference's per-row path) timed on one host core on a
-    bounded sample of the same workload: `rows` score rows at the full cohort size."""
+    """The oracle (CPU restatement of the reference's per-row path) timed on the host on bounded samples
+    of the same workload, at the full cohort size:
+      value          -- 1 core, dosage math only (decode, tally, impute, accumulate), `rows` rows
+      with_binomtest -- 1 core, plus the O(N) binomTest enumeration the reference ALWAYS executes per
+                        genotyped row (nimpress.nim:573 -> :155-188); fewer rows (it is ~10x slower)
+      all_cores      -- the dosage math split over the samples with OpenMP (not a restatement: the
+                        reference is single-threaded)"""
+    model, nproc, usable = host_info()
     from oracle import refcpu
+    threads = refcpu.host_threads(16)  # the GPU box's CPU share for one GPU
     n_distinct = 16
     th, tm, tmi = refcpu.hwe_thresholds(eaf[:n_distinct], miss[:n_distinct])
     codes = refcpu.synth_rows(n, 0, n_distinct, seed, th, tm, tmi)
     gts = np.stack([refcpu.codes_to_gt(codes[j], n) for j in range(n_distinct)])
     rng = np.random.default_rng(1)
     beta = np.round(rng.normal(0, 0.02, rows), 4)
-    secs, _, _ = refcpu.bench_gt(gts, n, rows, beta, np.resize(eaf[:n_distinct], rows),
-                                 refcpu.make_params())
-    return {"value": n * rows / secs, "unit": "genotype-dosage accumulations/s", "cores": 1,
-            "kind": "port",
+    e = np.resize(eaf[:n_distinct], rows)
+    prm = refcpu.make_params()
+    secs, _, _ = refcpu.bench_gt(gts, n, rows, beta, e, prm)
+    rows_b = max(8, min(rows, int(300 * 500_000 / max(n, 1))))
+    secs_b, _, _, warned = refcpu.bench_gt_full(gts, n, rows_b, beta[:rows_b], e[:rows_b], prm, True, 0.001)
+    refcpu.bench_gt_allcores(gts, n, min(rows, 64), beta[:64], e[:64], prm, threads)  # start the thread team
+    secs_a, _, _, used = refcpu.bench_gt_allcores(gts, n, rows, beta, e, prm, threads)
+    unit = "genotype-dosage accumulations/s"
+    return {"value": n * rows / secs, "unit": unit, "cores": 1, "kind": "port",
             "sample": "%d score rows x %d samples (bcf_get_genotypes int32 buffers, %d distinct rows "
                       "cycled), literal decode+tally+impute+accumulate of nimpress.nim:561-583,"
-                      "639-641, binomTest warnings off, %.1f s" % (rows, n, n_distinct, secs)}
+                      "639-641, binomTest warnings off, %.1f s" % (rows, n, n_distinct, secs),
+            "with_binomtest": {"value": n * rows_b / secs_b, "unit": unit, "cores": 1,
+                               "sample": "%d rows x %d samples incl. binomTest(neffect, 2*ngenotyped, eaf) "
+                                         "per row as the reference always runs it (nimpress.nim:573, "
+                                         "155-188), %.1f s, %d rows below --afmisp 0.001"
+                                         % (rows_b, n, secs_b, warned)},
+            "all_cores": {"value": n * rows / secs_a, "unit": unit, "cores": used,
+                          "sample": "%d rows x %d samples, the same passes split over the samples with "
+                                    "OpenMP, %.2f s" % (rows, n, secs_a)},
+            "nproc": nproc, "nproc_usable": usable, "cpu_model": model}
 
 
-def score_delta(sc_factory, cohort, beta, eaf, miss, seed, n, m, th, tm, tmi):
-    """The second half of BASELINE.json's metric ("+ max-abs score delta vs reference"), outside the
-    timed region and on rank 0 only: one more pass with per-row statistics, then the oracle's
-    arithmetic (nimpress.nim:565-583, 639-649) on the CPU for the first 16 samples over ALL rows, fed
-    with the row tallies the GPU reports, four of which are recounted over the full width by the
-    oracle's generator.  The oracle is the checker here, nothing of it is timed or shipped."""
+def cover_columns(n_per_thread_samples, n, samples_per_slice):
+    """Samples that look at EVERY slice of the persistent grid: per slice the first, a middle and the
+    last thread's samples (first / middle / last lane of a wave among them), plus the last, ragged
+    group of the cohort (sample n-1)."""
+    k = n_per_thread_samples
+    units = (n + k - 1) // k            # thread-sized groups of samples (word columns for GT)
+    per_slice = max(samples_per_slice // k, 1)
+    cols = set()
+    n_slices = (units + per_slice - 1) // per_slice
+    for p in range(n_slices):
+        first = p * per_slice
+        last = min(units, first + per_slice) - 1
+        for c in (first, first + 31, first + 63, (first + last) // 2, last):
+            if first <= c <= last:
+                cols.add(c)
+    cols.add(units - 1)
+    samples = np.concatenate([np.arange(c * k, min(n, (c + 1) * k)) for c in sorted(cols)])
+    return samples.astype(np.uint64), n_slices, len(cols)
+
+
+def score_delta(stats, got, nloci, fmt, beta, eaf, seed, n, m, th, tm, tmi, geometry, row0=0,
+                recount=1000, params=None):
+    """The second half of BASELINE.json's metric ("+ max-abs score delta vs reference"), outside the timed
+    region, rank 0 only.  `stats` / `got` / `nloci` come from one more pass with per-row statistics.
+    The oracle (oracle/refcpu.c, the checker -- nothing of it is timed or shipped) then
+      * recounts the whole-row tallies of `recount` random rows over all n samples (decode + tallyAlleles)
+        and compares them with the device's, bit for bit (GT) / 1e-9 (DS dosage sums);
+      * scores samples from EVERY slice of the persistent grid over ALL rows with the restated procs
+        (ref_score_subset: decode, the maxmis decision, imputeLocus/SampleDosages, accumulate in row
+        order), fed with each row's whole-row tally."""
     from oracle import refcpu
-    from nimpress_amd import capi
-    sc = sc_factory()
-    sc.score_cohort(cohort, capi.row_descs(beta, eaf))
-    stats = sc.flush()
-    got, nloci = sc.finish(0.0)
-    sc.close()
-    recount_ok = True
-    for j in sorted({0, min(1000, m - 1), m // 2, m - 1}):
-        codes = refcpu.synth_rows(n, j, 1, seed, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
-        c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
-        code = (c[:, 0] + 2 * c[:, 1])[:n]
-        recount_ok &= int((code == 2).sum()) == int(stats["nmissing"][j])
-        recount_ok &= int((code == 1).sum() + 2 * (code == 3).sum()) == int(stats["neffect"][j])
-    k = min(16, n)
-    codes16 = refcpu.synth_rows(k, 0, m, seed, th, tm, tmi)[:, 0]
-    nmiss = stats["nmissing"].astype(np.float64)
-    ngen = float(n) - nmiss
-    imp = np.where(ngen >= 100.0, stats["neffect"] / np.maximum(ngen, 1.0), eaf * 2.0)
-    locus = (nmiss / float(n)) > 0.05
-    ref = np.empty(k)
-    for i in range(k):
-        code = (codes16 >> np.uint32(2 * i)) & np.uint32(3)
-        d = np.choose(code, [np.zeros(m), np.ones(m), imp, np.full(m, 2.0)])
-        d = np.where(locus, eaf * 2.0, d)
-        ref[i] = np.cumsum(d * beta)[-1] / (2.0 * m)
-    delta = np.abs(got[:k] - ref)
+    is_ds = fmt == "ds"
+    slices, teams, sps = geometry
+    samples, n_slices, n_cols = cover_columns(8 if is_ds else 16, n, sps if sps else (960 * 16))
+    rng = np.random.default_rng(seed + 7)
+    rows = np.unique(np.concatenate([rng.choice(m, size=min(recount, m), replace=False),
+                                     [0, m - 1, min(1000, m - 1)]])).astype(np.uint64)
+    ri = rows.astype(np.int64)
+    g, ms, ne = refcpu.tally_synth_rows(rows + np.uint64(row0), n, seed, th[ri], tm[ri], tmi[ri], is_ds=is_ds)
+    tally_ok = bool(np.array_equal(ms, stats["nmissing"][ri].astype(np.float64)) and
+                    np.array_equal(g, stats["ngenotyped"][ri].astype(np.float64)))
+    if is_ds:
+        tally_ok &= bool(np.allclose(ne, stats["neffect"][ri], rtol=1e-9, atol=0.0))
+    else:
+        tally_ok &= bool(np.array_equal(ne, stats["neffect"][ri]))
+    sums, ref_nloci = refcpu.score_subset(samples, n, row0, seed, th, tm, tmi, beta, eaf, 0,
+                                          stats["ngenotyped"].astype(np.float64),
+                                          stats["nmissing"].astype(np.float64), stats["neffect"],
+                                          params or refcpu.make_params(), is_ds=is_ds)
+    ref = sums / (2.0 * ref_nloci)
+    idx = samples.astype(np.int64)
+    delta = np.abs(got[idx] - ref)
     floor = 1e-12 * float(np.sum(np.abs(beta))) / (2.0 * max(int(nloci), 1))
     return {"max_abs": float(delta.max()), "max_rel": float((delta / np.maximum(np.abs(ref), floor)).max()),
-            "nloci_equal": bool(int(nloci) == int(stats["used"].sum()) == m), "tally_recount_equal": bool(recount_ok),
-            "checked": "first %d samples x all %d rows vs the oracle's arithmetic on the CPU; row tallies of 4 "
-                       "rows recounted over all %d samples" % (k, m, n)}
+            "nloci_equal": bool(int(nloci) == int(ref_nloci) == int(stats["used"].sum())),
+            "tally_recount_equal": tally_ok, "samples_checked": int(samples.size),
+            "slices_covered": "%d of %d" % (n_slices, max(slices, n_slices)), "rows_recounted": int(rows.size),
+            "checked": "%d samples (%d thread columns: first / lane 31 / lane 63 / middle / last of each of "
+                       "the %d slices of the %dx%d persistent grid, and the last ragged column) x all %d "
+                       "rows scored by oracle/refcpu.c (ref_score_subset); whole-row tallies of %d random "
+                       "rows recounted over all %d samples" % (samples.size, n_cols, n_slices, slices, teams,
+                                                               m, rows.size, n)}
 
 
+# ------------------------------------------------------------------------------------------------
+# secondary measurements (rank 0, N = 1, after the headline; none of them is `value`)
+def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=20250105):
+    """BASELINE.json configs[4] at its stated size on ONE GPU: 2 000 000 x 200 000 float32 dosages are
+    1.6 TB, so the rows are scored in resident chunks; each chunk is regenerated on the device (outside the
+    timed segments), the partial scores and nloci carry across chunks inside the context, the timed
+    segments (HIP events around the hot kernels + wall around each scoring call) are summed."""
+    beta, eaf, miss = synth_score(m, seed, "ds")
+    th, tm, tmi = hwe_thresholds(eaf, miss)
+    chunk = min(chunk, m)
+    co = capi.Cohort(n, chunk, fmt=capi.FMT_DS32, device=device)
+    sc = capi.Scorer(n, capi.make_params(imp_locus="ps"), device=device)
+    geo = sc.fused_geometry(chunk, capi.FMT_DS32)
+    sc.profile_enable(True)
+    sc.profile_get(reset=True)
+    wall = 0.0
+    stats = []
+    sc.reset()
+    for r0 in range(0, m, chunk):
+        r1 = min(m, r0 + chunk)
+        for a in range(r0, r1, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
+            b = min(r1, a + (1 << 15))
+            co.synth_at(a - r0, a, seed, th[a:b], tm[a:b], tmi[a:b])
+        rows = capi.row_descs(beta[r0:r1], eaf[r0:r1])
+        sdef = capi.ScoreDef(rows, device=device)
+        sc.sync()
+        t0 = time.perf_counter()
+        sc.score_cohort_def(co, sdef, 0, capi.MODE_AUTO)
+        sc.sync()
+        wall += time.perf_counter() - t0
+        stats.append(sc.flush())
+        sdef.close()
+    got, nloci = sc.finish(0.0)
+    prof = sc.profile_get(reset=True)
+    sc.close()
+    co.close()
+    hot_ms = prof.ms_tally + prof.ms_params + prof.ms_accumulate + prof.ms_fused
+    alg = 4 * m * n + 40 * m + 8 * n
+    out = {"workload": "synthetic %d-variant PRS on %d-sample float32 FORMAT/DS matrix (BASELINE.json "
+                       "configs[4], 1.6 TB) in %d resident chunks of %d rows, 5 %% mean missingness, "
+                       "--imp-locus=ps" % (m, n, (m + chunk - 1) // chunk, chunk),
+           "value": n * m / wall, "unit": "genotype-dosage accumulations/s", "wall_s_scoring": wall,
+           "kernel_ms": hot_ms, "nloci": int(nloci),
+           "roofline": {"bound": "hbm", "achieved": alg / (hot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes": alg, "kernel": "ds_fused" if prof.n_fused else "ds two-pass"}}
+    if not args.no_cpu_baseline:
+        st = np.concatenate(stats)
+        # the last chunk's rows stand for the matrix in the full-width recount (its generator rows are
+        # the global row numbers, so any row can be recounted); all rows are scored for the subset
+        from oracle import refcpu
+        out["score_delta_vs_reference"] = score_delta(st, got, nloci, "ds", beta, eaf, seed, n, m, th, tm, tmi,
+                                                      geo, recount=300, params=refcpu.make_params("ps"))
+    return out
+
+
+def streaming_rates(capi, device, n, seed):
+    """The drop-in entry points (what the command line uses): one call per score row with a HOST buffer, so
+    these rates include the pinned copy + PCIe transfer + decode launch per row.  Never `value`."""
+    from oracle import refcpu  # only to build input rows (bcf_get_genotypes buffers); nothing is checked here
+    rng = np.random.default_rng(seed)
+    nd = 8
+    eaf = np.round(rng.uniform(0.05, 0.5, nd), 4)
+    th, tm, tmi = hwe_thresholds(eaf, np.full(nd, 0.01))
+    codes = refcpu.synth_rows(n, 0, nd, seed, th, tm, tmi)
+    gt32 = [refcpu.codes_to_gt(codes[j], n) for j in range(nd)]
+    gt8 = [g.astype(np.int8) for g in gt32]
+    out = {}
+    for name, rows, nbytes, push in (
+            ("nps_push_gt int32", 200, 8 * n, lambda sc, j: sc.push_gt(gt32[j % nd], 2, 1, False, 0.01, eaf[j % nd])),
+            ("nps_push_gt_raw int8", 400, 2 * n, lambda sc, j: sc.push_gt_raw(gt8[j % nd], 2, 1, False, 0.01, eaf[j % nd])),
+            ("nps_push_packed", 2000, 4 * ((n + 15) // 16), lambda sc, j: sc.push_packed(codes[j % nd], False, 0.01, eaf[j % nd]))):
+        sc = capi.Scorer(n, capi.make_params(), device=device)
+        for j in range(8):
+            push(sc, j)
+        sc.sync()
+        sc.reset()
+        t0 = time.perf_counter()
+        for j in range(rows):
+            push(sc, j)
+        sc.sync()
+        dt = time.perf_counter() - t0
+        sc.close()
+        out[name] = {"genotypes_per_s": n * rows / dt, "host_to_device_GBps": nbytes * rows / dt / 1e9,
+                     "rows": rows, "samples": n, "seconds": dt}
+    return out
+
+
+def config2_e2e(tmpdir):
+    """BASELINE.json configs[1] end to end through the `nimpress` command line: wood-height (697 loci) on a
+    synthetic 100 000-sample BCF2 + CSI (written by tests/config2.py), process start to last output line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config2
+    cli = os.path.join(ROOT, "nimpress_amd", "nimpress")
+    wood = os.path.join(ROOT, "tests", "golden", "scores", "wood-25282103-height.scores")
+    path, n_rec, n = config2.write_cohort(tmpdir, wood, level=1)[:3]
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "--afmisp=0", wood, path], capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        best = dt if best is None else min(best, dt)
+    return {"config2_e2e_s": best, "genotypes_per_s": n_rec * n / best, "records": n_rec, "samples": n,
+            "workload": "nimpress --afmisp=0 wood-25282103-height.scores cohort.bcf (100 000 samples, "
+                        "int8 GT, CSI random access), process start to exit, best of 2"}
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
+    from nimpress_amd import capi, multi   # (capi.load() makes libnps.so and torch share one HIP runtime)
+    capi.load()
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
     torch.cuda.set_device(local_rank)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one)               # sanity: every rank takes part in an RCCL collective
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == dist.get_world_size() == world
 
-    from nimpress_amd import capi, multi
     n, m = args.samples, args.variants
     mode = {"auto": capi.MODE_AUTO, "twopass": capi.MODE_TWOPASS, "fused": capi.MODE_FUSED}[args.mode]
+    is_ds = args.format == "ds"
+    strong = args.scaling == "strong" and world > 1
+    fmt = capi.FMT_DS32 if is_ds else capi.FMT_GT2
 
     # synthetic cohort, generated on the device; identical on every rank (same seed)
-    _, eaf, miss = synth_score(m, args.seed)
+    _, eaf, miss = synth_score(m, args.seed, args.format)
     t_het, t_hom, t_miss = hwe_thresholds(eaf, miss)
-    is_ds = args.format == "ds"
-    cohort = capi.Cohort(n, m, fmt=capi.FMT_DS32 if is_ds else capi.FMT_GT2, device=local_rank)
-    for r0 in range(0, m, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
-        r1 = min(m, r0 + (1 << 15))
-        cohort.synth(r0, args.seed, t_het[r0:r1], t_hom[r0:r1], t_miss[r0:r1])
-    if not args.no_optimize:
-        cohort.optimize()  # one-time layout step of a resident cohort (nps_cohort_optimize), untimed
-    # this rank's score definition: its own betas (score files sharded across GPUs)
-    beta = np.round(np.random.default_rng(args.seed + 1000 + rank).normal(0.0, 0.02, m), 4)
-    sdef = capi.ScoreDef(capi.row_descs(beta, eaf), device=local_rank)
-    sc = capi.Scorer(n, capi.make_params(), device=local_rank)
+    if strong:   # this rank's block of the ONE score's rows (blocks start on a group of 4)
+        r0, r1 = multi.shard_rows(m, world, rank)
+    else:
+        r0, r1 = 0, m
+    chunk = args.chunk_rows if args.chunk_rows > 0 else (r1 - r0)
+    chunks = [(a, min(r1, a + chunk)) for a in range(r0, r1, max(chunk, 1))]
+    resident = len(chunks) == 1
+    cohort = capi.Cohort(n, chunks[0][1] - chunks[0][0] if chunks else 0, fmt=fmt, device=local_rank)
+
+    def fill(a, b):     # rows [a, b) of the matrix -> cohort rows [0, b - a)
+        for x in range(a, b, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
+            y = min(b, x + (1 << 15))
+            cohort.synth_at(x - a, x, args.seed, t_het[x:y], t_hom[x:y], t_miss[x:y])
+        if not args.no_optimize:
+            cohort.optimize()  # one-time layout step of a resident cohort (nps_cohort_optimize), untimed
+
+    # this rank's score definition.  weak: its own betas (score files sharded across GPUs); strong: all
+    # ranks share ONE score, each holds its rows
+    beta_seed = args.seed + 1000 + (0 if strong else rank)
+    beta = np.round(np.random.default_rng(beta_seed).normal(0.0, 0.02, m), 4)
+    sdefs = [capi.ScoreDef(capi.row_descs(beta[a:b], eaf[a:b]), device=local_rank) for a, b in chunks]
+    params = capi.make_params(imp_locus="ps") if is_ds else capi.make_params()
+    sc = capi.Scorer(n, params, device=local_rank)
+    geometry = sc.fused_geometry(chunks[0][1] - chunks[0][0], fmt) if chunks else (0, 0, 0)
     d_scores = torch.empty(n, dtype=torch.float64, device="cuda")
     offset = 0.0
+    if resident and chunks:
+        fill(*chunks[0])
 
-    def step():
+    def step(timed=False):
         sc.reset()
-        sc.score_cohort_def(cohort, sdef, 0, mode)
-        nloci = sc.finish_device(offset, d_scores.data_ptr())
-        if world > 1:
-            # the one real exchange of the path: samples x scores matrix over RCCL (one score per rank)
-            step.matrix = multi.gather_scores(d_scores.view(1, n), world)
-        return nloci
+        seg = 0.0
+        for (a, b), sdef in zip(chunks, sdefs):
+            if not resident:        # regenerate the chunk (untimed), then time the scoring call alone
+                fill(a, b)
+                sc.sync()
+                t0 = time.perf_counter()
+            sc.score_cohort_def(cohort, sdef, 0, mode)
+            if not resident:
+                sc.sync()
+                seg += time.perf_counter() - t0
+        if strong:
+            # the one exchange of the row-sharded layout: sum all-reduce of sums and nloci (RCCL)
+            nl = sc.partial_device(d_scores.data_ptr())
+            _, nl = multi.all_reduce_partial(d_scores, nl)
+            sc.normalize_device(d_scores.data_ptr(), nl, offset)
+        else:
+            nl = sc.finish_device(offset, d_scores.data_ptr())
+            if world > 1:
+                # the one exchange of the score-sharded layout: samples x scores matrix over RCCL
+                step.matrix = multi.gather_scores(d_scores.view(1, n), world)
+        step.seg += seg
+        return nl
+
+    step.seg = 0.0
 
     def fence():
         torch.cuda.synchronize()
@@ -193,12 +460,15 @@ def main():
         nloci = step()
     sc.profile_enable(True)
     sc.profile_get(reset=True)
+    step.seg = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nloci = step()
     fence()
     elapsed = time.perf_counter() - t0
+    if not resident:
+        elapsed = step.seg     # chunked: the sum of the timed scoring segments (generation excluded)
     prof = sc.profile_get(reset=True)
     sc.profile_enable(False)
 
@@ -210,47 +480,57 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         genotypes_per_step = float(n) * float(m)
-        value = world * genotypes_per_step * args.steps / elapsed
-        # algorithmic bytes per step: one read of the matrix + per-row
+        value = (1 if strong else world) * genotypes_per_step * args.steps / elapsed
+        # algorithmic bytes per step of THIS rank: one read of the matrix + per-row
         # params + one write of the scores
-        alg_bytes = (4 * m * n if is_ds else m * ((n + 15) // 16) * 4) + 40 * m + 8 * n
+        my_m = r1 - r0
+        alg_bytes = (4 * my_m * n if is_ds else my_m * ((n + 15) // 16) * 4) + 40 * my_m + 8 * n
         kern_ms = {"tally": prof.ms_tally, "params": prof.ms_params,
                    "accumulate": prof.ms_accumulate, "fused": prof.ms_fused,
                    "finish": prof.ms_reduce}
         hot_ms_per_step = (prof.ms_tally + prof.ms_params + prof.ms_accumulate + prof.ms_fused) / steps
         dominant = max(("tally", "accumulate", "fused"), key=lambda k: kern_ms[k])
         achieved = alg_bytes / (hot_ms_per_step * 1e-3) / 1e9 if hot_ms_per_step > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_ds.json" if is_ds else "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not strong:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("samples") == n and tj.get("variants") == m:
                     traffic = tj.get("hbm_bytes_per_step")
+                    traffic_source = ("profiles/%s (replayed: PMC passes of this command, %s; not measured "
+                                      "in this run)" % (os.path.basename(tpath), tj.get("round", "round 1")))
             except Exception:
                 traffic = None
+        if strong:
+            parallelism = "one score, rows sharded x%d + RCCL all-reduce of sums and nloci" % world
+        elif world > 1:
+            parallelism = "score-sharded x%d + RCCL all-gather" % world
+        else:
+            parallelism = "single GPU"
         out = {
             "metric": "genotype-dosage accumulations/s (samples x variants / s)",
             "value": value,
             "unit": "genotype-dosage accumulations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": ("synthetic %d-variant PRS on %d-sample float32 FORMAT/DS matrix "
-                                    "resident in HBM (BASELINE.json configs[4] shape, rows limited to "
-                                    "what fits one GPU), CLI-default imputation flags" if is_ds else
+                                    "(BASELINE.json configs[4]), 5 %% mean missingness, --imp-locus=ps" if is_ds else
                                     "synthetic %d-variant PRS on %d-sample 2-bit GT matrix resident in "
                                     "HBM (BASELINE.json configs[2]), CLI-default imputation flags")
                                    % (m, n),
                        "samples": n, "variants": m, "nloci": int(nloci),
+                       "resident_chunks": len(chunks), "chunk_rows": chunk,
+                       "persistent_grid": {"slices": geometry[0], "teams": geometry[1],
+                                           "samples_per_slice": geometry[2]},
                        "cohort_layout": "plain" if (args.no_optimize or is_ds) else
                                         "nps_cohort_optimize (one-time, untimed: per group of 4 rows the row "
                                         "with the most dosage-2/missing codes in the bank-selecting slot)",
-                       "mode": args.mode, "parallelism": "score-sharded x%d + RCCL all-gather" % world
-                       if world > 1 else "single GPU"},
+                       "mode": args.mode, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dominant,
                          "algorithmic_bytes_per_step": alg_bytes,
                          "kernel_ms_per_step": {k: v / steps for k, v in kern_ms.items()},
@@ -259,12 +539,40 @@ def main():
                                                "accumulate": prof.n_accumulate / steps,
                                                "fused": prof.n_fused / steps}},
         }
-        if world == 1 and not args.no_cpu_baseline and not is_ds:
-            out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)
-            out["score_delta_vs_reference"] = score_delta(
-                lambda: capi.Scorer(n, capi.make_params(), device=local_rank), cohort, beta, eaf, miss,
-                args.seed, n, m, t_het, t_hom, t_miss)
-        print(json.dumps(out))
+        if world == 1 and not args.no_cpu_baseline:
+            if not is_ds:
+                out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)
+            if resident:
+                # one more pass with per-row statistics for the checker
+                sc.reset()
+                sc.score_cohort_def(cohort, sdefs[0], 0, mode)
+                stats = sc.flush()
+                got, nl = sc.finish(0.0)
+                out["score_delta_vs_reference"] = score_delta(
+                    stats, got, nl, args.format, beta, eaf, args.seed, n, m, t_het, t_hom, t_miss, geometry)
+        if world == 1 and not args.no_extras and not is_ds and resident:
+            sc.close()
+            for d in sdefs:
+                d.close()
+            cohort.close()      # frees the 125 GB matrix: the DS chunks need the room
+            torch.cuda.empty_cache()
+            import tempfile
+            secondary = {}
+            try:
+                secondary["config5_ds"] = ds_config5(capi, local_rank, args)
+            except Exception as e:      # a secondary measurement never takes the headline down
+                secondary["config5_ds"] = {"error": repr(e)[:300]}
+            try:
+                secondary["streaming"] = streaming_rates(capi, local_rank, n, args.seed)
+            except Exception as e:
+                secondary["streaming"] = {"error": repr(e)[:300]}
+            try:
+                with tempfile.TemporaryDirectory() as td:
+                    secondary["config2"] = config2_e2e(td)
+            except Exception as e:
+                secondary["config2"] = {"error": repr(e)[:300]}
+            out["secondary"] = secondary
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -242,6 +242,10 @@ int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const ui
 int nps_cohort_optimize(nps_cohort *c);
 int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
                      const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss);
+/* Same, but cohort rows [row0, row0+nrows) receive the generator's rows gen_row0, gen_row0+1, ...: a
+ * cohort that holds a block or a chunk of a larger matrix (row-sharded runs, matrices larger than HBM). */
+int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t gen_row0, uint64_t seed,
+                          const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss);
 void nps_cohort_destroy(nps_cohort *c);
 
 /* Score n_desc rows in order; PRESENT rows take cohort rows cohort_row0, cohort_row0+1, ...
@@ -270,6 +274,12 @@ int nps_profile_enable(nps_ctx *ctx, int on); /* record HIP events around every 
 int nps_profile_get(nps_ctx *ctx, nps_profile *out, int reset);
 /* the HIP stream (hipStream_t) the context launches on, for callers that add their own events */
 void *nps_stream(nps_ctx *ctx);
+/* How NPS_MODE_AUTO would lay a resident run of n_rows rows of `format` over the chip: `slices`
+ * workgroups side by side over the samples (samples_per_slice each) times `teams` taking row batches in
+ * turn; all zero when the shape does not fit the persistent grid (two-pass kernels are used).  For
+ * reports and for tests that want to look at every slice. */
+int nps_fused_geometry(nps_ctx *ctx, int format, uint64_t n_rows, uint32_t *slices, uint32_t *teams,
+                       uint32_t *samples_per_slice);
 
 #ifdef __cplusplus
 }

@@ -52,9 +52,10 @@ SYMBOLS = [
     "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
     "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
-    "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_optimize",
+    "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_synth_rows",
+    "nps_cohort_optimize",
     "nps_cohort_destroy",
-    "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream",
+    "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream", "nps_fused_geometry",
 ]
 
 
@@ -67,6 +68,43 @@ class NpsError(RuntimeError):
 _lib = None
 
 
+def _hip_runtimes_mapped():
+    """paths of the libamdhip64 copies mapped into this process"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if line.count("/") else ""
+                if "libamdhip64" in path and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  libnps.so needs `libamdhip64.so.7`; the PyTorch wheel ships its own
+    copy of that library (same SONAME) next to libtorch_hip.so.  If libnps.so were loaded first it would
+    pull in /opt/rocm's copy, a later `import torch` would map the wheel's copy as well, and device
+    pointers handed from torch to libnps (nps_finish_device into a tensor, the RCCL path) would cross two
+    runtimes.  So when torch is installed and not imported yet, its copy is loaded FIRST, by path: the
+    loader then resolves libnps.so's NEEDED entry and torch's own to that one mapping, whatever the
+    import order.  Without torch (the C++ command line, C callers) /opt/rocm's copy is the only one."""
+    import sys
+    if "torch" in sys.modules or _hip_runtimes_mapped():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen libnps.so (raises if it has not been built -- there is no fallback)."""
     global _lib
@@ -75,7 +113,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NpsError(-2, "libnps.so not built (%s); run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` -- the HIP library is the only compute path" % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise NpsError(-5, "two HIP runtimes are mapped into this process (%s): device pointers cannot "
+                           "be shared between them; import nimpress_amd.capi (or torch) before anything "
+                           "else loads a libamdhip64" % ", ".join(rts))
     vp, u64, i32, dbl = C.c_void_p, C.c_uint64, C.c_int, C.c_double
     L.nps_abi_version.restype = C.c_int
     L.nps_last_error.restype = C.c_char_p
@@ -110,6 +154,7 @@ def load():
     L.nps_cohort_upload.argtypes = [vp, u64, u64, vp, C.c_size_t]
     L.nps_cohort_download.argtypes = [vp, u64, u64, vp, C.c_size_t]
     L.nps_cohort_synth.argtypes = [vp, u64, u64, u64, vp, vp, vp]
+    L.nps_cohort_synth_rows.argtypes = [vp, u64, u64, u64, u64, vp, vp, vp]
     L.nps_cohort_optimize.argtypes = [vp]
     L.nps_cohort_destroy.argtypes = [vp]
     L.nps_cohort_destroy.restype = None
@@ -118,6 +163,8 @@ def load():
     L.nps_profile_get.argtypes = [vp, C.POINTER(NpsProfile), i32]
     L.nps_stream.argtypes = [vp]
     L.nps_stream.restype = vp
+    u32p = C.POINTER(C.c_uint32)
+    L.nps_fused_geometry.argtypes = [vp, i32, u64, u32p, u32p, u32p]
     _lib = L
     return L
 
@@ -179,6 +226,13 @@ class Cohort:
         assert th.size == tm.size == tmi.size
         _check(load().nps_cohort_synth(self._h, row0, th.size, seed, th.ctypes.data, tm.ctypes.data,
                                        tmi.ctypes.data))
+
+    def synth_at(self, row0: int, gen_row0: int, seed: int, t_het, t_hom, t_miss):
+        """cohort rows row0.. receive the generator's rows gen_row0.. (a block / chunk of a larger matrix)"""
+        th, tm, tmi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (t_het, t_hom, t_miss))
+        assert th.size == tm.size == tmi.size
+        _check(load().nps_cohort_synth_rows(self._h, row0, th.size, gen_row0, seed, th.ctypes.data,
+                                            tm.ctypes.data, tmi.ctypes.data))
 
     def optimize(self):
         """one-time layout optimisation (nps_cohort_optimize): the row of every group of 4 with the most
@@ -339,6 +393,12 @@ class Scorer:
     @property
     def stream(self) -> int:
         return int(load().nps_stream(self._h) or 0)
+
+    def fused_geometry(self, n_rows: int, fmt: int = FMT_GT2) -> Tuple[int, int, int]:
+        """(slices, teams, samples per slice) of the persistent grid for n_rows rows; zeros = two-pass"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(load().nps_fused_geometry(self._h, fmt, int(n_rows), C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def close(self):
         if self._h:

@@ -1706,6 +1706,23 @@ void *nh_vcf_open_streaming(const char *path, const char *score_path, long windo
         return nullptr;
     }
 }
+// header (sample names) only: indexed files keep just header + index, others are read without keeping
+// a record
+void *nh_vcf_open_header(const char *path) {
+    try {
+        nh_vcf *h = new nh_vcf;
+        const std::vector<ScoreEntry> none;
+        if (!h->vcf.openStreaming(path) && !h->vcf.open(path, &none)) {
+            delete h;
+            g_nh_error = "cannot open";
+            return nullptr;
+        }
+        return h;
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return nullptr;
+    }
+}
 void nh_vcf_close(void *h) { delete (nh_vcf *)h; }
 long nh_vcf_n_samples(void *h) { return (long)((nh_vcf *)h)->vcf.samples.size(); }
 int nh_vcf_indexed(void *h) { return ((nh_vcf *)h)->vcf.indexed ? 1 : 0; }

@@ -236,14 +236,15 @@ static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 
 __global__ __launch_bounds__(256) void synth_ds_kernel(float *__restrict__ ds, uint64_t stride_f,
-                                                       uint64_t n, uint64_t row0, uint64_t seed,
+                                                       uint64_t n, uint64_t row0, uint64_t gen_row0,
+                                                       uint64_t seed,
                                                        const uint32_t *__restrict__ t_het,
                                                        const uint32_t *__restrict__ t_hom,
                                                        const uint32_t *__restrict__ t_miss) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r = blockIdx.y;
     if (i >= n) return;
-    const uint64_t h = mix64(mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull)) + i);
+    const uint64_t h = mix64(mix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull)) + i);
     const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
     float d;
     if (ms < t_miss[r]) {
@@ -292,13 +293,13 @@ hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stri
 }
 
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
-                           uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                           uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss) {
     if (n_rows == 0 || n == 0) return hipSuccess;
     if (n_rows > 65535) return hipErrorInvalidValue;
     (void)hipGetLastError();
     hipLaunchKernelGGL(synth_ds_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)n_rows), dim3(256),
-                       0, st, d_ds, stride_f, n, row0, seed, d_t_het, d_t_hom, d_t_miss);
+                       0, st, d_ds, stride_f, n, row0, gen_row0, seed, d_t_het, d_t_hom, d_t_miss);
     return hipGetLastError();
 }
 

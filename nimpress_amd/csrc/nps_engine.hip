@@ -1097,9 +1097,9 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
     return NPS_OK;
 }
 
-extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
-                                const uint32_t *t_het, const uint32_t *t_hom,
-                                const uint32_t *t_miss) {
+extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t gen_row0,
+                                     uint64_t seed, const uint32_t *t_het, const uint32_t *t_hom,
+                                     const uint32_t *t_miss) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
     if (nrows == 0) return NPS_OK;
@@ -1120,15 +1120,20 @@ extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, ui
         const uint64_t k = std::min(step, nrows - r);
         if (c->format == NPS_FMT_DS32)
             e = launch_synth_ds(nullptr, (float *)c->d_data, c->stride_bytes / 4, c->n_samples,
-                                row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
+                                row0 + r, gen_row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
         else
             e = launch_synth_gt(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
-                                row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
+                                row0 + r, gen_row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_t);
     if (e != hipSuccess) return fail(NPS_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
     return NPS_OK;
+}
+
+extern "C" int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
+                                const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss) {
+    return nps_cohort_synth_rows(c, row0, nrows, row0, seed, t_het, t_hom, t_miss);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1574,3 +1579,20 @@ extern "C" int nps_profile_get(nps_ctx *c, nps_profile *out, int reset) {
 }
 
 extern "C" void *nps_stream(nps_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint32_t *slices,
+                                  uint32_t *teams, uint32_t *samples_per_slice) {
+    if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32) return fail(NPS_E_INVAL, "unknown format %d", format);
+    HIP_TRY(hipSetDevice(c->device));
+    FusedPlan plan;
+    if (format == NPS_FMT_DS32)
+        HIP_TRY(ds_fused_plan(c->device, c->n, n_rows, 0, 0, &plan));
+    else
+        HIP_TRY(fused_plan(c->device, c->n, n_rows, 0, 0, &plan));
+    if (slices) *slices = plan.ok ? plan.P : 0;
+    if (teams) *teams = plan.ok ? plan.Q : 0;
+    if (samples_per_slice)
+        *samples_per_slice = !plan.ok ? 0 : (format == NPS_FMT_DS32 ? (plan.threads - 64) * 8 : (plan.threads - 64) * 16);
+    return NPS_OK;
+}

@@ -117,9 +117,10 @@ hipError_t launch_finish(hipStream_t st, const double *d_part, uint32_t n_chunks
                          const unsigned long long *d_nloci, uint64_t host_nloci, int normalise,
                          double offset, double *d_scores);
 
-// synthetic cohort rows (counter-based generator shared with oracle/refcpu.c)
+// synthetic cohort rows (counter-based generator shared with oracle/refcpu.c): rows [row0, row0+n_rows)
+// of the buffer are filled with the generator's rows gen_row0, gen_row0+1, ...
 hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
-                           uint64_t n_samples, uint64_t row0, uint64_t n_rows, uint64_t seed,
+                           uint64_t n_samples, uint64_t row0, uint64_t gen_row0, uint64_t n_rows, uint64_t seed,
                            const uint32_t *d_t_het, const uint32_t *d_t_hom,
                            const uint32_t *d_t_miss);
 
@@ -182,7 +183,7 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
 hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n,
                                   int ploidy, int eaidx, float *d_out);
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
-                           uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                           uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss);
 
 }  // namespace nps

@@ -657,8 +657,8 @@ static __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 
 __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ codes,
                                                        uint64_t stride_words, uint64_t n_samples,
-                                                       uint32_t n_words, uint64_t row0, uint64_t n_rows,
-                                                       uint64_t seed,
+                                                       uint32_t n_words, uint64_t row0, uint64_t gen_row0,
+                                                       uint64_t n_rows, uint64_t seed,
                                                        const uint32_t *__restrict__ t_het,
                                                        const uint32_t *__restrict__ t_hom,
                                                        const uint32_t *__restrict__ t_miss) {
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ co
     for (int rr = 0; rr < 4; ++rr) {
         const uint64_t r = g * 4 + rr;  // row relative to row0 = index into the threshold arrays
         if (r < n_rows) {
-            const uint64_t key = mix64(seed ^ ((row0 + r) * 0xD1B54A32D192ED03ull));
+            const uint64_t key = mix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull));
             const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
             uint32_t w = 0;
 #pragma unroll
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void synth_gt_kernel(uint32_t *__restrict__ co
 }
 
 hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
-                           uint64_t n_samples, uint64_t row0, uint64_t n_rows, uint64_t seed,
+                           uint64_t n_samples, uint64_t row0, uint64_t gen_row0, uint64_t n_rows, uint64_t seed,
                            const uint32_t *d_t_het, const uint32_t *d_t_hom,
                            const uint32_t *d_t_miss) {
     const uint64_t n_words = words_for(n_samples);
@@ -702,7 +702,7 @@ hipError_t launch_synth_gt(hipStream_t st, uint32_t *d_codes, uint64_t stride_wo
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(synth_gt_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)n_groups),
                        dim3(256), 0, st, d_codes, stride_words, n_samples, (uint32_t)n_words, row0,
-                       n_rows, seed, d_t_het, d_t_hom, d_t_miss);
+                       gen_row0, n_rows, seed, d_t_het, d_t_hom, d_t_miss);
     return hipGetLastError();
 }
 

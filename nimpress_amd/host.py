@@ -32,6 +32,12 @@ def load():
         L.nh_vcf_close.argtypes = [C.c_void_p]
         L.nh_vcf_n_samples.restype = C.c_long
         L.nh_vcf_n_samples.argtypes = [C.c_void_p]
+        L.nh_vcf_open_header.restype = C.c_void_p
+        L.nh_vcf_open_header.argtypes = [C.c_char_p]
+        L.nh_vcf_sample.restype = C.c_char_p
+        L.nh_vcf_sample.argtypes = [C.c_void_p, C.c_long]
+        L.nh_format_float.restype = None
+        L.nh_format_float.argtypes = [C.c_double, C.c_char_p, C.c_long]
         _lib = L
     return _lib
 
@@ -53,3 +59,22 @@ def compute_polygenic_scores(score_path: str, vcf_path: str, cov: Optional[str] 
     if n < 0:
         raise capi.NpsError(-3 if n == -2 else -1, L.nh_last_error().decode("utf-8", "replace"))
     return scores[:n].copy(), int(nloci.value), [l for l in log.value.decode().split("\n") if l]
+
+
+def sample_names(vcf_path: str) -> List[str]:
+    """samples(vcf) of the reference (nimpress.nim:753): the header's sample names, in order"""
+    L = load()
+    h = L.nh_vcf_open_header(vcf_path.encode())
+    if not h:
+        raise capi.NpsError(-1, "cannot open %s: %s" % (vcf_path, L.nh_last_error().decode("utf-8", "replace")))
+    try:
+        return [L.nh_vcf_sample(h, i).decode() for i in range(L.nh_vcf_n_samples(h))]
+    finally:
+        L.nh_vcf_close(h)
+
+
+def format_score(x: float) -> str:
+    """Nim's `$float` as the reference prints it (nimpress.nim:753; "%.16g", ".0" for integers, "nan")"""
+    buf = C.create_string_buffer(64)
+    load().nh_format_float(float(x), buf, len(buf))
+    return buf.value.decode()

@@ -28,6 +28,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* enum values follow declaration order of nimpress.nim:412-414 */
 enum { REF_LOCUS_PS = 0, REF_LOCUS_HOMREF = 1, REF_LOCUS_FAIL = 2, REF_LOCUS_IGNORE = 3 };
@@ -463,21 +466,232 @@ void ref_synth_rows_ds(float *ds, size_t stride, size_t n, size_t row0, size_t n
 }
 
 /* ------------------------------------------------------------------------- */
+/* Full-size checks (bench.py score_delta leg, tests/test_gpu_parity.py): a SUBSET of the samples of a
+ * synthetic cohort scored over ALL its rows with the restated procs above.
+ *
+ * In the reference the per-sample work of a row depends on the other samples only through the row's
+ * tally: imputeSampleDosages receives (neffectallele, ngenotyped) as arguments (nimpress.nim:450-452,
+ * call at :582-583) and the maxmis decision is nmissing / nsamples (:565).  So the k chosen samples
+ * can be scored exactly as the reference scores them inside the whole cohort, given every row's
+ * whole-row tally -- which ref_tally_synth_rows recounts literally (decode :367-391 + tally :32-47
+ * over all n samples) for as many rows as the caller wants to pay for; for the other rows the caller
+ * passes the tallies the device reported.  OpenMP only splits the SAMPLES (every sample keeps the
+ * reference's row order and operations) or the ROWS of the recount. */
+static void subset_row_gt(double *dos, int32_t *gts, const uint64_t *samples, size_t k, uint64_t seed,
+                          uint64_t row, uint32_t th, uint32_t tm, uint32_t tmi) {
+    for (size_t i = 0; i < k; ++i) {
+        const unsigned c = ref_synth_code(seed, row, samples[i], th, tm, tmi);
+        /* the bcf_get_genotypes pair of ref_codes_to_gt: effect allele index 1 */
+        gts[2 * i] = (c == 3u) ? 4 : (c == 2u ? 0 : 2);
+        gts[2 * i + 1] = (c == 0u) ? 2 : (c == 2u ? 0 : 4);
+    }
+    ref_raw_dosages_gt(dos, gts, k, 2, 1);
+}
+
+/* the decision chain of getImputedDosages :565-583 for a PRESENT row whose whole-row tally is given */
+static int subset_impute(double *dos, size_t k, size_t n_total, double ngen, double nmiss, double neff,
+                         double eaf, int rie, const ref_params *p) {
+    const double missingrate = nmiss / (double)n_total; /* :565 */
+    if (missingrate > p->max_missing_rate) return ref_impute_locus(dos, k, eaf, rie, p->imp_locus);
+    ref_impute_sample(dos, k, eaf, rie, neff, ngen, p->min_cs, p->imp_sample);
+    return 1;
+}
+
+void ref_score_subset(int is_ds, const uint64_t *samples, size_t k, size_t n_total, size_t row0, size_t m,
+                      uint64_t seed, const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss,
+                      const double *beta, const double *eaf, const int32_t *rie, const double *row_ngen,
+                      const double *row_nmiss, const double *row_neff, const ref_params *p, int threads,
+                      double *sums_out /* k un-normalised sums */, int64_t *nloci_out) {
+    int64_t nloci = 0;
+    for (size_t j = 0; j < m; ++j) { /* which rows are used does not depend on the sample */
+        const double missingrate = row_nmiss[j] / (double)n_total;
+        if (!(missingrate > p->max_missing_rate) || p->imp_locus != REF_LOCUS_IGNORE) nloci += 1;
+    }
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        int nt = 1, me = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads();
+        me = omp_get_thread_num();
+#endif
+        const size_t per = (k + (size_t)nt - 1) / (size_t)nt;
+        const size_t i0 = (size_t)me * per < k ? (size_t)me * per : k;
+        const size_t i1 = i0 + per < k ? i0 + per : k;
+        const size_t kk = i1 - i0;
+        if (kk) {
+            double *dos = (double *)malloc(sizeof(double) * kk);
+            int32_t *gts = (int32_t *)malloc(sizeof(int32_t) * 2 * kk);
+            float *ds = (float *)malloc(sizeof(float) * kk);
+            double *sc = sums_out + i0;
+            for (size_t i = 0; i < kk; ++i) sc[i] = 0.0;
+            for (size_t j = 0; j < m; ++j) {
+                if (is_ds) {
+                    for (size_t i = 0; i < kk; ++i)
+                        ds[i] = ref_synth_ds(seed, row0 + j, samples[i0 + i], t_het[j], t_hom[j], t_miss[j]);
+                    ref_raw_dosages_ds(dos, ds, kk, rie[j]);
+                } else {
+                    subset_row_gt(dos, gts, samples + i0, kk, seed, row0 + j, t_het[j], t_hom[j], t_miss[j]);
+                }
+                if (subset_impute(dos, kk, n_total, row_ngen[j], row_nmiss[j], row_neff[j], eaf[j], rie[j], p))
+                    for (size_t i = 0; i < kk; ++i) sc[i] += dos[i] * beta[j]; /* :639-640 */
+            }
+            free(dos);
+            free(gts);
+            free(ds);
+        }
+    }
+    if (nloci_out) *nloci_out = nloci;
+}
+
+/* literal whole-row recount (decode + tallyAlleles over all n samples) of selected rows */
+void ref_tally_synth_rows(int is_ds, const uint64_t *rows, size_t nr, size_t n, uint64_t seed,
+                          const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss,
+                          const int32_t *rie /* per selected row */, int threads, double *ngen,
+                          double *nmiss, double *neff) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        double *dos = (double *)malloc(sizeof(double) * (n ? n : 1));
+        int32_t *gts = is_ds ? NULL : (int32_t *)malloc(sizeof(int32_t) * 2 * (n ? n : 1));
+        float *ds = is_ds ? (float *)malloc(sizeof(float) * (n ? n : 1)) : NULL;
+        uint64_t *ids = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+        for (size_t i = 0; i < n; ++i) ids[i] = i;
+#pragma omp for schedule(dynamic, 1)
+        for (size_t r = 0; r < nr; ++r) {
+            if (is_ds) {
+                for (size_t i = 0; i < n; ++i) ds[i] = ref_synth_ds(seed, rows[r], i, t_het[r], t_hom[r], t_miss[r]);
+                ref_raw_dosages_ds(dos, ds, n, rie[r]);
+            } else {
+                subset_row_gt(dos, gts, ids, n, seed, rows[r], t_het[r], t_hom[r], t_miss[r]);
+            }
+            ref_tally_alleles(dos, n, &ngen[r], &nmiss[r], &neff[r]);
+        }
+        free(dos);
+        free(gts);
+        free(ds);
+        free(ids);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* CPU baseline for bench.py: the literal per-row path (decode, tally, impute, accumulate;
  * nimpress.nim:561-583, 639-641) over m rows whose bcf_get_genotypes buffers cycle through
- * n_distinct pre-built rows.  Returns wall seconds measured around the loop only. */
+ * n_distinct pre-built rows.  Returns wall seconds measured around the loop only.
+ * with_binomtest != 0 adds what the reference ALWAYS executes between the maxmis decision and the
+ * sample imputation (nimpress.nim:573): binomTest(neffect, 2*ngenotyped, eaf), the O(N) enumeration of
+ * :155-188, whose result only gates a warning (*warned_out counts p < afmisp). */
 #include <time.h>
+static double ref_now(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+double ref_bench_gt_full(const int32_t *gts_rows, size_t n_distinct, size_t n, size_t m,
+                         const double *beta, const double *eaf, const ref_params *p,
+                         int with_binomtest, double afmisp, double *scores_out, int64_t *nloci_out,
+                         int64_t *warned_out) {
+    ref_state *s = ref_begin(n, p);
+    int64_t warned = 0;
+    const double t0 = ref_now();
+    for (size_t j = 0; j < m; ++j) {
+        ref_locus_stat st;
+        const int32_t *gts = gts_rows + (j % n_distinct) * 2 * n;
+        if (!with_binomtest) {
+            ref_row_gt(s, gts, 2, 1, 0, beta[j], eaf[j], &st);
+            continue;
+        }
+        /* the same row with the binomTest call in its place (:561-583) */
+        ref_raw_dosages_gt(s->dosages, gts, n, 2, 1);
+        ref_tally_alleles(s->dosages, n, &st.ngenotyped, &st.nmissing, &st.neffect);
+        const double missingrate = st.nmissing / (double)n;
+        if (missingrate > p->max_missing_rate) {
+            if (ref_impute_locus(s->dosages, n, eaf[j], 0, p->imp_locus)) ref_accumulate(s, beta[j]);
+            continue;
+        }
+        if (!isnan(eaf[j]) &&
+            ref_binom_test((int64_t)st.neffect, ((int64_t)n - (int64_t)st.nmissing) * 2, eaf[j]) < afmisp)
+            warned += 1;
+        ref_impute_sample(s->dosages, n, eaf[j], 0, st.neffect, st.ngenotyped, p->min_cs,
+                          p->imp_sample);
+        ref_accumulate(s, beta[j]);
+    }
+    const double t1 = ref_now();
+    ref_finish(s, 0.0, scores_out, nloci_out);
+    if (warned_out) *warned_out = warned;
+    return t1 - t0;
+}
+
 double ref_bench_gt(const int32_t *gts_rows, size_t n_distinct, size_t n, size_t m,
                     const double *beta, const double *eaf, const ref_params *p,
                     double *scores_out, int64_t *nloci_out) {
-    ref_state *s = ref_begin(n, p);
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
+    return ref_bench_gt_full(gts_rows, n_distinct, n, m, beta, eaf, p, 0, 0.0, scores_out, nloci_out,
+                             NULL);
+}
+
+/* The "whole socket" figure BASELINE.md asks for beside the single-threaded one: the same four passes
+ * per row (decode :383-391, tally :41-46, impute :479-481 / :444-445, accumulate :639-640), each split
+ * over the samples with OpenMP.  NOT a restatement of the reference (which has one thread): tallies are
+ * integer-valued, so the reduction order does not change them, and every sample's score is still the
+ * same sequence of operations.  Default CLI methods only (imp-locus ps, imp-sample int_ps).  The thread
+ * count is an argument (libgomp reads OMP_NUM_THREADS once, when it is first loaded -- usually by numpy or
+ * torch long before).  Returns seconds; *threads_out = threads used. */
+double ref_bench_gt_allcores(const int32_t *gts_rows, size_t n_distinct, size_t n, size_t m,
+                             const double *beta, const double *eaf, const ref_params *p, int threads,
+                             double *scores_out, int64_t *nloci_out, int *threads_out) {
+    double *scores = (double *)malloc(sizeof(double) * (n ? n : 1));
+    double *dos = (double *)malloc(sizeof(double) * (n ? n : 1));
+    int64_t nloci = 0;
+    if (threads < 1) threads = 1;
+#ifndef _OPENMP
+    threads = 1;
+#endif
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t i = 0; i < n; ++i) scores[i] = 0.0;
+    const double t0 = ref_now();
     for (size_t j = 0; j < m; ++j) {
-        ref_locus_stat st;
-        ref_row_gt(s, gts_rows + (j % n_distinct) * 2 * n, 2, 1, 0, beta[j], eaf[j], &st);
+        const int32_t *gts = gts_rows + (j % n_distinct) * 2 * n;
+        double ngen = 0.0, nmiss = 0.0, neff = 0.0;
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (size_t i = 0; i < n; ++i) { /* :383-391 */
+            double d = 0.0;
+            for (int a = 0; a < 2; ++a) {
+                const int64_t v = allele_value(gts[2 * i + a]);
+                if (v == 1) d += 1.0;
+                else if (v == -1) d = NAN;
+            }
+            dos[i] = d;
+        }
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : ngen, nmiss, neff)
+        for (size_t i = 0; i < n; ++i) { /* :41-46 */
+            if (isnan(dos[i])) nmiss += 1.0;
+            else { ngen += 1.0; neff += dos[i]; }
+        }
+        const double missingrate = nmiss / (double)n;
+        double fill;
+        int all;
+        if (missingrate > p->max_missing_rate) { /* :565-571, imp-locus ps */
+            fill = eaf[j] * 2.0;
+            all = 1;
+        } else { /* :470-477, imp-sample int_ps */
+            fill = ngen >= (double)p->min_cs ? neff / ngen : eaf[j] * 2.0;
+            all = 0;
+        }
+        const double b = beta[j];
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (size_t i = 0; i < n; ++i) { /* :479-481 / :444-445, then :639-640 */
+            const double d = (all || isnan(dos[i])) ? fill : dos[i];
+            scores[i] += d * b;
+        }
+        nloci += 1;
     }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    ref_finish(s, 0.0, scores_out, nloci_out);
-    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    const double t1 = ref_now();
+    for (size_t i = 0; i < n; ++i) scores[i] = scores[i] / ((double)nloci * 2.0);
+    if (scores_out) memcpy(scores_out, scores, sizeof(double) * n);
+    if (nloci_out) *nloci_out = nloci;
+    if (threads_out) *threads_out = threads;
+    free(scores);
+    free(dos);
+    return t1 - t0;
 }

@@ -114,8 +114,34 @@ def lib():
     L.ref_bench_gt.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp,
                                C.POINTER(RefParams), dp, C.POINTER(C.c_int64)]
     L.ref_bench_gt.restype = C.c_double
+    u64p = C.POINTER(C.c_uint64)
+    L.ref_score_subset.argtypes = [C.c_int, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                   C.c_uint64, u32p, u32p, u32p, dp, dp, i32p, dp, dp, dp,
+                                   C.POINTER(RefParams), C.c_int, dp, C.POINTER(C.c_int64)]
+    L.ref_score_subset.restype = None
+    L.ref_tally_synth_rows.argtypes = [C.c_int, u64p, C.c_size_t, C.c_size_t, C.c_uint64, u32p, u32p,
+                                       u32p, i32p, C.c_int, dp, dp, dp]
+    L.ref_tally_synth_rows.restype = None
+    L.ref_bench_gt_full.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp,
+                                    C.POINTER(RefParams), C.c_int, C.c_double, dp,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ref_bench_gt_full.restype = C.c_double
+    L.ref_bench_gt_allcores.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp,
+                                        C.POINTER(RefParams), C.c_int, dp, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int)]
+    L.ref_bench_gt_allcores.restype = C.c_double
     _lib = L
     return L
+
+
+def host_threads(cap: int = 16) -> int:
+    """threads for the checker's OpenMP helpers: the CPUs this process may use, at most `cap` (a GPU box
+    gives one GPU's job 16 cores)"""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return max(1, min(usable, cap))
 
 
 def make_params(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05,
@@ -243,6 +269,42 @@ def synth_rows_ds(n: int, row0: int, nrows: int, seed: int, t_het, t_hom, t_miss
     return out[:, :n]
 
 
+def score_subset(samples, n_total: int, row0: int, seed: int, t_het, t_hom, t_miss, beta, eaf, rie,
+                 row_ngen, row_nmiss, row_neff, params: RefParams, is_ds: bool = False):
+    """The chosen samples of a synthetic cohort scored over rows [row0, row0 + m) with the restated procs,
+    given every row's whole-row tally (see refcpu.c "Full-size checks").  Returns (un-normalised sums,
+    nloci): the state of the reference's loop at nimpress.nim:641."""
+    samples = np.ascontiguousarray(samples, dtype=np.uint64)
+    th, tm, tmi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (t_het, t_hom, t_miss))
+    m = th.size
+    beta, eaf, g, ms, ne = (np.ascontiguousarray(a, dtype=np.float64)
+                            for a in (beta, eaf, row_ngen, row_nmiss, row_neff))
+    rie = np.ascontiguousarray(np.broadcast_to(np.asarray(rie, dtype=np.int32), (m,)))
+    assert beta.size == eaf.size == g.size == ms.size == ne.size == m
+    sums = np.zeros(max(samples.size, 1), dtype=np.float64)
+    nloci = C.c_int64(0)
+    lib().ref_score_subset(int(is_ds), _p(samples, C.c_uint64), samples.size, n_total, row0, m, seed,
+                           _p(th, C.c_uint32), _p(tm, C.c_uint32), _p(tmi, C.c_uint32),
+                           _p(beta, C.c_double), _p(eaf, C.c_double), _p(rie, C.c_int32),
+                           _p(g, C.c_double), _p(ms, C.c_double), _p(ne, C.c_double), C.byref(params),
+                           host_threads(), _p(sums, C.c_double), C.byref(nloci))
+    return sums[: samples.size], int(nloci.value)
+
+
+def tally_synth_rows(rows, n: int, seed: int, t_het, t_hom, t_miss, rie=0, is_ds: bool = False):
+    """Literal whole-row recount (decode + tallyAlleles over all n samples) of the given rows; the
+    threshold arrays hold one entry per SELECTED row.  Returns (ngenotyped, nmissing, neffect)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    th, tm, tmi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (t_het, t_hom, t_miss))
+    assert th.size == tm.size == tmi.size == rows.size
+    rie = np.ascontiguousarray(np.broadcast_to(np.asarray(rie, dtype=np.int32), (rows.size,)))
+    out = [np.zeros(max(rows.size, 1), dtype=np.float64) for _ in range(3)]
+    lib().ref_tally_synth_rows(int(is_ds), _p(rows, C.c_uint64), rows.size, n, seed,
+                               _p(th, C.c_uint32), _p(tm, C.c_uint32), _p(tmi, C.c_uint32),
+                               _p(rie, C.c_int32), host_threads(), *(_p(o, C.c_double) for o in out))
+    return tuple(o[: rows.size] for o in out)
+
+
 def codes_to_gt(row: np.ndarray, n: int) -> np.ndarray:
     row = np.ascontiguousarray(row, dtype=np.uint32)
     out = np.empty(2 * max(n, 1), dtype=np.int32)
@@ -263,6 +325,38 @@ def bench_gt(gts_rows: np.ndarray, n: int, m: int, beta, eaf, params: RefParams)
                               _p(eaf, C.c_double), C.byref(params), _p(scores, C.c_double),
                               C.byref(nloci))
     return float(secs), scores[:n], int(nloci.value)
+
+
+def bench_gt_full(gts_rows: np.ndarray, n: int, m: int, beta, eaf, params: RefParams,
+                  with_binomtest: bool, afmisp: float = 0.001):
+    """As bench_gt, optionally with the binomTest call of nimpress.nim:573 in its place.
+    Returns (seconds, scores, nloci, rows that would have been warned about)."""
+    gts_rows = np.ascontiguousarray(gts_rows, dtype=np.int32)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    eaf = np.ascontiguousarray(eaf, dtype=np.float64)
+    scores = np.empty(max(n, 1), dtype=np.float64)
+    nloci, warned = C.c_int64(0), C.c_int64(0)
+    secs = lib().ref_bench_gt_full(_p(gts_rows, C.c_int32), gts_rows.shape[0], n, m,
+                                   _p(beta, C.c_double), _p(eaf, C.c_double), C.byref(params),
+                                   int(bool(with_binomtest)), float(afmisp), _p(scores, C.c_double),
+                                   C.byref(nloci), C.byref(warned))
+    return float(secs), scores[:n], int(nloci.value), int(warned.value)
+
+
+def bench_gt_allcores(gts_rows: np.ndarray, n: int, m: int, beta, eaf, params: RefParams,
+                      threads: Optional[int] = None):
+    """The same passes split over the samples with OpenMP on all host cores (NOT a restatement: the
+    reference is single-threaded).  Returns (seconds, scores, nloci, threads)."""
+    gts_rows = np.ascontiguousarray(gts_rows, dtype=np.int32)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    eaf = np.ascontiguousarray(eaf, dtype=np.float64)
+    scores = np.empty(max(n, 1), dtype=np.float64)
+    nloci, used = C.c_int64(0), C.c_int(0)
+    secs = lib().ref_bench_gt_allcores(_p(gts_rows, C.c_int32), gts_rows.shape[0], n, m,
+                                       _p(beta, C.c_double), _p(eaf, C.c_double), C.byref(params),
+                                       int(threads or host_threads()), _p(scores, C.c_double),
+                                       C.byref(nloci), C.byref(used))
+    return float(secs), scores[:n], int(nloci.value), int(used.value)
 
 
 # ----------------------------------------------------------------------------------------

@@ -9,10 +9,11 @@ import zlib
 import numpy as np
 
 INT8_END, INT16_END, INT32_END = -127, -32767, -2147483647
+LEVEL = 6  # deflate level of the BGZF blocks (bench.py lowers it: the fixture is written once per run)
 
 
 def bgzf_block(data: bytes) -> bytes:
-    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    c = zlib.compressobj(LEVEL, zlib.DEFLATED, -15)
     comp = c.compress(data) + c.flush()
     bsize = len(comp) + 25
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)

@@ -153,33 +153,11 @@ def test_config2_wood_height_on_100k_sample_bcf(tmp_path):
     import sys
     import time
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import bcfwriter
-    n, seed = 100_000, 20250102
+    import config2
     wood = os.path.join(G, "scores", "wood-25282103-height.scores")
     score = refcpu.read_score_file(wood)
-    rng = np.random.default_rng(seed)
-    samples = ["S%06d" % i for i in range(n)]
-    contigs, recs, truth = [], [], []
-    def ckey(e):
-        return ((0, int(e.contig)) if e.contig.isdigit() else (1, e.contig)), e.pos
-    for j, e in enumerate(sorted(score.entries, key=ckey)):
-        if e.contig not in contigs:
-            contigs.append(e.contig)
-        if j % 41 == 7:
-            truth.append((e, None, None))                 # absent from the file
-            continue
-        rie = e.easeq == e.refseq
-        alt = e.easeq if not rie else next(b for b in "ACGT" if b != e.refseq[0])
-        p_alt = (1.0 - e.eaf) if rie else e.eaf           # eaf is the frequency of the EFFECT allele
-        p_alt = min(max(p_alt, 0.0), 1.0)
-        a = (rng.uniform(size=(n, 2)) < p_alt).astype(np.int64)
-        gts = (a + 1) << 1                                # bcf GT encoding, unphased
-        gts[rng.uniform(size=n) < rng.uniform(0.0, 0.02)] = 0   # both alleles missing
-        filt = ["FAIL"] if j % 53 == 11 else (["PASS"] if j % 2 else [])
-        recs.append(dict(contig=e.contig, pos=e.pos, id=".", ref=e.refseq, alts=[alt], filters=filt, gts=gts))
-        truth.append((e, gts.astype(np.int32), filt))
-    path = str(tmp_path / "cohort.bcf")
-    bcfwriter.write_bcf(path, contigs, samples, recs, gt_dtype=np.int8)
+    path, n_rec, n, samples, truth_by_row = config2.write_cohort(tmp_path, wood)
+    truth = [(e,) + truth_by_row[k] for k, e in enumerate(score.entries)]
     t0 = time.perf_counter()
     r = subprocess.run([CLI, "--afmisp=0", wood, path], capture_output=True, text=True)
     wall = time.perf_counter() - t0
@@ -203,6 +181,5 @@ def test_config2_wood_height_on_100k_sample_bcf(tmp_path):
     assert nloci == len(score.entries)
     scale = float(np.sum(np.abs([e.beta for e in score.entries]))) / (2.0 * nloci)
     assert np.max(np.abs(got - ref)) <= 1e-6 * max(float(np.max(np.abs(ref))), 1e-12 * scale)
-    n_rec = len(recs)
     print("\n[config 2] nimpress on a 100000-sample BCF, %d loci (%d records, %.0f MB of int8 GT): %.2f s end to end "
           "= %.3g genotypes/s" % (len(score.entries), n_rec, n_rec * n * 2 / 1e6, wall, n_rec * n / wall))

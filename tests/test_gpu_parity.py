@@ -456,10 +456,11 @@ def test_full_size_config3_properties():
     """BASELINE.json configs[2] at its full size (500 000 samples x 1 000 000 rows, 125 GB of 2-bit
     codes resident in HBM): far beyond what the oracle can score, so parity goes through
     size-independent properties plus the oracle on what it CAN reach:
-      * every row's decision (1000 rows over --maxmis, nloci = M), tallies of spot rows recounted by
-        the oracle's generator over the full width;
-      * the first 16 samples scored on the CPU over ALL rows (the reference's per-row arithmetic,
-        nimpress.nim:565-583,639-649, fed with the recounted-and-spot-checked row tallies);
+      * every row's decision (1000 rows over --maxmis, nloci = M); the whole-row tallies of 1000 random
+        rows recounted by the oracle over all 500 000 samples;
+      * 2 800 samples taken from every one of the 35 slices of the persistent grid (and the last ragged
+        word) scored over ALL rows by oracle/refcpu.c (ref_score_subset: the restated procs of
+        nimpress.nim:367-391, 565-583, 639-649, fed with every row's whole-row tally);
       * fused single-read kernel == two-pass kernels for every sample;
       * scores(2 beta) == 2 scores(beta) bit for bit (scaling by 2 is exact in every step);
       * the two row halves scored separately add up to the whole."""
@@ -494,29 +495,42 @@ def test_full_size_config3_properties():
     over = stats["reason"] == capi.REASON_MAXMIS
     assert int(over.sum()) == m // 1000 and bool(over[::1000].all())
     assert int(stats["used"].sum()) == m
-    # spot rows: the oracle's generator over the full width
-    for j in (0, 1000, 499_999, 999_999):
-        codes = refcpu.synth_rows(n, j, 1, seed, th[j:j + 1], tm[j:j + 1], tmi[j:j + 1])
-        c = np.unpackbits(codes.view(np.uint8), bitorder="little").reshape(-1, 2)
-        code = (c[:, 0] + 2 * c[:, 1])[:n]
-        assert int((code == 2).sum()) == int(stats["nmissing"][j])
-        assert int((code == 1).sum() + 2 * (code == 3).sum()) == int(stats["neffect"][j])
-        assert int(stats["ngenotyped"][j]) + int(stats["nmissing"][j]) == n
-    # the first 16 samples over all rows, on the CPU
-    codes16 = refcpu.synth_rows(16, 0, m, seed, th, tm, tmi)[:, 0]
-    nmiss = stats["nmissing"].astype(np.float64)
-    ngen = float(n) - nmiss
-    imp = np.where(ngen >= 100.0, stats["neffect"] / np.maximum(ngen, 1.0), eaf * 2.0)  # :470-477
-    locus = (nmiss / float(n)) > 0.05                                                     # :565-566
-    expect = np.empty(16)
-    for i in range(16):
-        code = (codes16 >> np.uint32(2 * i)) & np.uint32(3)
-        d = np.choose(code, [np.zeros(m), np.ones(m), imp, np.full(m, 2.0)])
-        d = np.where(locus, eaf * 2.0, d)                                                 # :417-447
-        expect[i] = np.cumsum(d * beta)[-1] / (2.0 * m)                                   # :639-645
-    got = (whole[:16] / (2.0 * nloci)).cpu().numpy()
+    # whole-row tallies of 1000 random rows (+ first, last, an over-maxmis one) recounted by the oracle
+    # over all 500 000 samples: decode nim:367-391 + tallyAlleles nim:32-47, bit for bit
+    rows = np.unique(np.concatenate([np.random.default_rng(1).choice(m, 1000, replace=False),
+                                     [0, 1000, 499_999, m - 1]])).astype(np.uint64)
+    ri = rows.astype(np.int64)
+    g, ms, ne = refcpu.tally_synth_rows(rows, n, seed, th[ri], tm[ri], tmi[ri])
+    assert np.array_equal(g, stats["ngenotyped"][ri].astype(np.float64))
+    assert np.array_equal(ms, stats["nmissing"][ri].astype(np.float64))
+    assert np.array_equal(ne, stats["neffect"][ri])
+    assert np.array_equal(stats["ngenotyped"] + stats["nmissing"], np.full(m, n, dtype=np.uint64))
+    # samples from EVERY slice of the persistent grid (first / lane 31 / lane 63 / middle / last thread
+    # of each of the 35 slices, and the last ragged word with sample 499 999) scored over ALL rows by
+    # oracle/refcpu.c: the restated decode, maxmis decision, imputeLocus/SampleDosages and accumulation
+    # in row order, fed with every row's whole-row tally
+    sc0 = capi.Scorer(n, capi.make_params())
+    slices, teams, sps = sc0.fused_geometry(m)
+    sc0.close()
+    assert slices * teams > 200 and sps % 16 == 0, (slices, teams, sps)  # the single-read kernel is in use
+    units, per_slice = (n + 15) // 16, sps // 16
+    cols = {units - 1}
+    for p_ in range(slices):
+        first, last = p_ * per_slice, min(units, (p_ + 1) * per_slice) - 1
+        cols.update(c for c in (first, first + 31, first + 63, (first + last) // 2, last) if first <= c <= last)
+    assert len({c // per_slice for c in cols}) == slices == (units + per_slice - 1) // per_slice
+    samples = np.concatenate([np.arange(c * 16, min(n, (c + 1) * 16)) for c in sorted(cols)]).astype(np.uint64)
+    assert samples[-1] == n - 1 and samples.size >= 64 * 16
+    sums, ref_nloci = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, 0,
+                                          stats["ngenotyped"].astype(np.float64),
+                                          stats["nmissing"].astype(np.float64), stats["neffect"],
+                                          refcpu.make_params())
+    assert ref_nloci == nloci == m
+    expect = sums / (2.0 * ref_nloci)
+    got = (whole / (2.0 * nloci)).cpu().numpy()[samples.astype(np.int64)]
     scale = float(np.sum(np.abs(beta))) / (2.0 * m)
     assert np.max(np.abs(got - expect)) <= 1e-12 * scale
+    assert np.max(np.abs(got - expect) / np.maximum(np.abs(expect), 1e-12 * scale)) <= 1e-6
     # the two HIP paths agree for every sample
     twopass, nloci2, _ = run(descs, mode=capi.MODE_TWOPASS)
     assert nloci2 == m
@@ -741,6 +755,90 @@ def test_ds_large_fused_equals_twopass_and_scaling():
     dose = np.where(rie[j], 2.0 - row.astype(np.float64), row.astype(np.float64))
     assert abs(float(np.nansum(dose)) - float(st_f["neffect"][j])) <= 1e-9 * float(np.nansum(dose))
     dev.close()
+
+
+def test_ds_config5_resident_chunks_vs_oracle_subset():
+    """BASELINE.json configs[4] (200 000 samples, FORMAT/DS float32, 5 % mean missingness, --imp-locus=ps)
+    at the largest size one GPU holds (300 000 rows = 240 GB; the full 2 000 000 rows are scored by
+    bench.py in chunks of exactly this size):
+      * samples from every slice of the DS kernel's persistent grid scored over ALL rows by
+        oracle/refcpu.c (ref_score_subset), whole-row tallies of 300 random rows recounted by the oracle;
+      * the rows scored as two resident chunks of half the size, each regenerated into the same buffer
+        (nps_cohort_synth_rows) with the sums carried inside the context == the one resident run;
+      * scores(2 beta) == 2 scores(beta) bit for bit on the chunked path."""
+    import torch
+    n, m, seed = 200_000, 300_000, 20250105
+    free, _total = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip("needs 250 GB of free HBM")
+    rng = np.random.default_rng(seed)
+    beta = np.round(rng.normal(0.0, 0.02, m), 4)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.10, m)
+    rie = (rng.uniform(size=m) < 0.3).astype(np.int32)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    prm = dict(imp_locus="ps")
+
+    def fill(dev, a, b):
+        for x in range(a, b, 1 << 14):
+            y = min(b, x + (1 << 14))
+            dev.synth_at(x - a, x, seed, th[x:y], tm[x:y], tmi[x:y])
+
+    def chunked(bb, bounds, want_stats=False):
+        dev = capi.Cohort(n, max(b - a for a, b in bounds), fmt=capi.FMT_DS32)
+        sc = capi.Scorer(n, capi.make_params(**prm))
+        stats = []
+        for a, b in bounds:
+            fill(dev, a, b)
+            sc.score_cohort(dev, capi.row_descs(bb[a:b], eaf[a:b], None, rie[a:b]), 0, capi.MODE_AUTO)
+            if want_stats:
+                stats.append(sc.flush())
+        part = torch.empty(n, dtype=torch.float64, device="cuda")
+        nloci = sc.partial_device(part.data_ptr())
+        geo = sc.fused_geometry(bounds[0][1] - bounds[0][0], capi.FMT_DS32)
+        sc.close()
+        dev.close()
+        return part.cpu().numpy(), nloci, (np.concatenate(stats) if want_stats else None), geo
+
+    whole, nloci, stats, geo = chunked(beta, [(0, m)], want_stats=True)
+    assert nloci == m == int(stats["used"].sum())
+    over = int((stats["reason"] == capi.REASON_MAXMIS).sum())
+    assert 0.35 * m < over < 0.65 * m
+    slices, teams, sps = geo
+    assert slices * teams > 200 and sps % 8 == 0, geo   # the single-read DS kernel is in use
+    # whole-row recount of 300 random rows (+ first and last)
+    rows = np.unique(np.concatenate([np.random.default_rng(2).choice(m, 300, replace=False), [0, m - 1]])).astype(np.uint64)
+    ri = rows.astype(np.int64)
+    g, ms, ne = refcpu.tally_synth_rows(rows, n, seed, th[ri], tm[ri], tmi[ri], rie=rie[ri], is_ds=True)
+    assert np.array_equal(g, stats["ngenotyped"][ri].astype(np.float64))
+    assert np.array_equal(ms, stats["nmissing"][ri].astype(np.float64))
+    assert np.allclose(ne, stats["neffect"][ri], rtol=1e-9, atol=0.0)
+    # every slice: first / lane 31 / lane 63 / middle / last thread (8 samples each), and the last sample
+    units, per_slice = (n + 7) // 8, sps // 8
+    cols = {units - 1}
+    for p_ in range(slices):
+        first, last = p_ * per_slice, min(units, (p_ + 1) * per_slice) - 1
+        cols.update(c for c in (first, first + 31, first + 63, (first + last) // 2, last) if first <= c <= last)
+    assert len({c // per_slice for c in cols}) == slices
+    samples = np.concatenate([np.arange(c * 8, min(n, (c + 1) * 8)) for c in sorted(cols)]).astype(np.uint64)
+    sums, ref_nloci = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, rie,
+                                          stats["ngenotyped"].astype(np.float64),
+                                          stats["nmissing"].astype(np.float64), stats["neffect"],
+                                          refcpu.make_params(**prm), is_ds=True)
+    assert ref_nloci == m
+    scale = float(np.sum(np.abs(beta)))
+    got = whole[samples.astype(np.int64)]
+    # (the device's float64 dosage sums differ from the oracle's sequential sums in the last bits, and
+    # with them the imputed value of a row: bar 1e-9 of sum|beta|, far inside the 1e-6 of the north star)
+    assert np.max(np.abs(got - sums)) <= 1e-9 * scale
+    assert np.max(np.abs(got - sums) / np.maximum(np.abs(sums), 1e-12 * scale)) <= 1e-6
+    # two resident chunks == one resident run; exact scaling
+    h = m // 2
+    two, nloci2, _, _ = chunked(beta, [(0, h), (h, m)])
+    assert nloci2 == m
+    assert np.max(np.abs(two - whole)) <= 1e-12 * scale
+    dbl, _, _, _ = chunked(2.0 * beta, [(0, h), (h, m)])
+    assert np.array_equal(dbl, 2.0 * two)
 
 
 def test_row_sharded_partial_sums_and_normalise():

@@ -106,3 +106,37 @@ def test_eight_scores_sharded_and_gathered(cohort_vcf):
         ref, _, _ = oracle_run(f, vcf)
         assert np.allclose(full[i].numpy(), ref, rtol=0, atol=1e-9 + 1e-6 * np.max(np.abs(ref)),
                            equal_nan=True), f
+
+
+def test_score_many_eight_files_on_500k_sample_bcf(tmp_path):
+    """BASELINE.json configs[3] at its cohort size: the 8 score-format files of the reference tree on ONE
+    500 000-sample BCF2 (+CSI) holding the union of their loci, through tools/score_many.py (one score
+    definition per rank at a time; a single rank here, the gather is exercised with 2 ranks on the CPU in
+    test_multi_gloo.py) -- every score against the oracle's own driver (findVariant + getImputedDosages +
+    accumulate over the same records), all 500 000 samples."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config2
+    n = 500_000
+    files = SCORES                     # 4 scores/*.scores + 3 makescore examples + tests/set1.score
+    assert len(files) == 8
+    path, samples, recs = config2.write_union_cohort(tmp_path, files, n)
+    out = str(tmp_path / "matrix.tsv")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1",
+                        "--afmisp=0", "--out", out] + files + [path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert [x[0] for x in rows] == samples
+    got = np.array([[float(v) for v in x[1:]] for x in rows]).T           # [scores, samples]
+    assert got.shape == (8, n)
+    vcf = refcpu.Vcf(samples=samples, records=[
+        refcpu.VcfRecord(contig=q["contig"], pos=q["pos"], ref=q["ref"], alts=q["alts"],
+                         filt=";".join(q["filters"]) if q["filters"] else ".",
+                         gts=q["gts"].reshape(-1), ploidy=2) for q in recs])
+    for i, f in enumerate(files):
+        ref, nloci, stats = oracle_run(f, vcf)
+        assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), f
+        ok = ~np.isnan(ref)
+        scale = 1e-12 + (np.max(np.abs(ref[ok])) if ok.any() else 0.0)
+        assert np.max(np.abs(got[i][ok] - ref[ok]), initial=0.0) <= 1e-6 * scale, f

@@ -166,3 +166,62 @@ def test_packed_matrix_path_equals_row_path():
     s2, nl2 = sc.finish(0.5)
     assert nl1 == nl2
     assert np.array_equal(s1, s2, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------
+# the full-size checker (ref_score_subset / ref_tally_synth_rows) against the literal whole-cohort path
+@pytest.mark.parametrize("kw", [dict(), dict(imp_locus="ignore", imp_sample="int_fail", maxmis=0.03, mincs=10),
+                                dict(imp_locus="homref", imp_sample="ps"), dict(imp_locus="fail", imp_sample="homref")])
+def test_subset_scorer_equals_whole_cohort_path(kw):
+    """Scoring a few samples with every row's whole-row tally handed in (how bench.py and the full-size GPU
+    tests use the oracle at 500 000 x 1 000 000) gives bit for bit what the literal per-row path over the
+    whole cohort gives for those samples."""
+    n, m, seed = 3001, 257, 99
+    rng = np.random.default_rng(5)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0, 0.08, m)
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    prm = refcpu.make_params(**kw)
+    codes = refcpu.synth_rows(n, 0, m, seed, th, tm, tmi)
+    ref, st, nloci = refcpu.score_packed(codes, n, np.zeros(m, np.int32), np.zeros(m, np.int32), beta, eaf, prm, 0.0)
+    g, ms, ne = refcpu.tally_synth_rows(np.arange(m), n, seed, th, tm, tmi)
+    assert np.array_equal(g, st["ngenotyped"]) and np.array_equal(ms, st["nmissing"]) and np.array_equal(ne, st["neffect"])
+    samples = np.array([0, 1, 15, 16, 17, 1500, 2999, 3000], dtype=np.uint64)
+    sums, nl = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, 0, g, ms, ne, prm)
+    assert nl == nloci
+    with np.errstate(invalid="ignore", divide="ignore"):
+        got = sums / (2.0 * nl)
+    assert np.array_equal(got, ref[samples.astype(int)], equal_nan=True)
+    # FORMAT/DS rows, a third of them with the REF allele as effect allele
+    rie = (np.arange(m) % 3 == 0).astype(np.int32)
+    ds = refcpu.synth_rows_ds(n, 0, m, seed, th, tm, tmi)
+    sc = refcpu.RefScorer(n, prm)
+    for j in range(m):
+        sc.row_ds(ds[j], bool(rie[j]), beta[j], eaf[j])
+    ref, nloci = sc.finish(0.0)
+    g, ms, ne = refcpu.tally_synth_rows(np.arange(m), n, seed, th, tm, tmi, rie=rie, is_ds=True)
+    sums, nl = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, rie, g, ms, ne, prm, is_ds=True)
+    assert nl == nloci
+    with np.errstate(invalid="ignore", divide="ignore"):
+        got = sums / (2.0 * nl)
+    assert np.array_equal(got, ref[samples.astype(int)], equal_nan=True)
+
+
+def test_cpu_baseline_variants_agree():
+    """the timed CPU-baseline loops of bench.py (with the binomTest call; split over all cores) compute the
+    same scores as the plain literal loop"""
+    n, rows, nd = 4000, 40, 4
+    rng = np.random.default_rng(3)
+    eaf = np.round(rng.uniform(0.05, 0.5, nd), 4)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, np.array([0.0, 0.01, 0.02, 0.2]))
+    codes = refcpu.synth_rows(n, 0, nd, 1, th, tm, tmi)
+    gts = np.stack([refcpu.codes_to_gt(codes[j], n) for j in range(nd)])
+    beta = np.round(rng.normal(0, 0.02, rows), 4)
+    e = np.resize(eaf, rows)
+    prm = refcpu.make_params()
+    _, s0, n0 = refcpu.bench_gt(gts, n, rows, beta, e, prm)
+    _, s1, n1, warned = refcpu.bench_gt_full(gts, n, rows, beta, e, prm, True, 0.001)
+    _, s2, n2, threads = refcpu.bench_gt_allcores(gts, n, rows, beta, e, prm)
+    assert n0 == n1 == n2 == rows and threads >= 1 and warned >= 0
+    assert np.array_equal(s0, s1) and np.array_equal(s0, s2)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""score_many.py -- BASELINE.json configs[3]: several score files evaluated on ONE cohort file, one score
+definition per GPU at a time, the samples x scores matrix gathered over RCCL.
+
+    python tools/score_many.py [--gpus N] [nimpress options] --out matrix.tsv  a.scores b.scores ...  cohort.bcf
+
+Each rank (one process per GPU; torch.distributed, backend nccl = RCCL on ROCm) runs the reference's
+computePolygenicScores (nimpress.nim:592-649, C++ host + libnps) for the score files
+i = rank, rank + N, ... against the same cohort file; the only exchange is the all-gather of the
+[scores, samples] matrix (nimpress_amd/multi.py).  Rank 0 writes one line per sample:
+    <sample> TAB <score of file 1> TAB <score of file 2> ...
+in the reference's float format (nimpress.nim:752-753).  With --gpus N > 1 and no launcher
+(torch.distributed.run) this process starts the N ranks itself, before anything touches a GPU.
+"""
+import argparse
+import os
+import socket
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--out", default="-", help="output TSV (default: stdout)")
+    ap.add_argument("--cov", default=None)
+    ap.add_argument("--imp-locus", default="ps", choices=["ps", "homref", "fail", "ignore"])
+    ap.add_argument("--imp-missing", default="homref", choices=["homref", "ignore"])
+    ap.add_argument("--imp-sample", default="int_ps", choices=["ps", "homref", "fail", "int_ps", "int_fail"])
+    ap.add_argument("--maxmis", type=float, default=0.05)
+    ap.add_argument("--mincs", type=int, default=100)
+    ap.add_argument("--afmisp", type=float, default=0.001)
+    ap.add_argument("--ignorefilt", action="store_true")
+    ap.add_argument("files", nargs="+", help="score files ..., then the genotype file (last)")
+    a = ap.parse_args(argv)
+    if len(a.files) < 2:
+        ap.error("need at least one score file and the genotype file")
+    return a
+
+
+def spawn_ranks(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    try:
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from nimpress_amd import capi, host, multi
+    capi.load()
+    import torch
+    import torch.distributed as dist
+    if capi.device_count() < 1:
+        sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=device)
+    score_files, cohort = args.files[:-1], args.files[-1]
+    names = host.sample_names(cohort)
+    n = len(names)
+    logs = {}
+
+    def score_fn(i, out_row):
+        s, nloci, log = host.compute_polygenic_scores(
+            score_files[i], cohort, cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing,
+            imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp,
+            ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1))
+        logs[i] = log
+        out_row.copy_(torch.from_numpy(s).to(out_row.device))
+
+    t0 = time.perf_counter()
+    full = multi.evaluate_sharded(len(score_files), n, score_fn, device if world > 1 else torch.device("cpu"))
+    elapsed = time.perf_counter() - t0
+    for i in sorted(logs):
+        for line in logs[i]:
+            sys.stderr.write("[%s] %s\n" % (os.path.basename(score_files[i]), line))
+    if rank == 0:
+        from nimpress_amd.host import format_score
+        mat = full.cpu().numpy()
+        out = sys.stdout if args.out == "-" else open(args.out, "w")
+        for j, name in enumerate(names):
+            out.write(name + "\t" + "\t".join(format_score(float(mat[i, j])) for i in range(mat.shape[0])) + "\n")
+        if out is not sys.stdout:
+            out.close()
+        sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s\n"
+                         % (len(score_files), n, world, elapsed))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
