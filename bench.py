@@ -368,10 +368,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
 
-    from nimpress_amd import capi, multi   # (capi.load() makes libnps.so and torch share one HIP runtime)
-    capi.load()
     import torch
     import torch.distributed as dist
+    from nimpress_amd import capi, multi   # (either import order works: capi.load() sees to one HIP runtime)
+    capi.load()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to time)")
     torch.cuda.set_device(local_rank)

@@ -87,22 +87,21 @@ def _preload_torch_hip_runtime():
     copy of that library (same SONAME) next to libtorch_hip.so.  If libnps.so were loaded first it would
     pull in /opt/rocm's copy, a later `import torch` would map the wheel's copy as well, and device
     pointers handed from torch to libnps (nps_finish_device into a tensor, the RCCL path) would cross two
-    runtimes.  So when torch is installed and not imported yet, its copy is loaded FIRST, by path: the
-    loader then resolves libnps.so's NEEDED entry and torch's own to that one mapping, whatever the
-    import order.  Without torch (the C++ command line, C callers) /opt/rocm's copy is the only one."""
+    runtimes.  So when torch is installed it is imported FIRST, here: the loader then resolves
+    libnps.so's NEEDED entry to the copy torch has mapped, whatever order the caller imports things in.
+    (Loading the wheel's libamdhip64.so alone by path works too, but changes the order in which the
+    libraries are torn down at exit, which rocprofv3's tool library does not survive.)  Without torch
+    (the C++ command line, C callers) /opt/rocm's copy is the only one."""
     import sys
     if "torch" in sys.modules or _hip_runtimes_mapped():
         return
     try:
         import importlib.util
-        spec = importlib.util.find_spec("torch")
+        if importlib.util.find_spec("torch") is None:
+            return
+        import torch  # noqa: F401
     except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def load():

@@ -183,3 +183,89 @@ def test_config2_wood_height_on_100k_sample_bcf(tmp_path):
     assert np.max(np.abs(got - ref)) <= 1e-6 * max(float(np.max(np.abs(ref))), 1e-12 * scale)
     print("\n[config 2] nimpress on a 100000-sample BCF, %d loci (%d records, %.0f MB of int8 GT): %.2f s end to end "
           "= %.3g genotypes/s" % (len(score.entries), n_rec, n_rec * n * 2 / 1e6, wall, n_rec * n / wall))
+
+
+def test_af_mismatch_warnings_at_default_afmisp_100k_samples(tmp_path):
+    """SURVEY.md section 8 f3, end to end: the command line at its DEFAULT --afmisp=0.001 on a
+    100 000-sample BCF whose cohort allele counts sit at chosen distances from the score file's eaf.  The
+    rows warned about, and the text of every warning (nimpress.nim:538-541, 575-579), must be exactly what
+    the oracle's literal binomTest (nim:155-188, the O(n) enumeration) decides -- including
+      * both sides of the 0.001 threshold on both sides of the mean,
+      * a row near the mean where betacf runs out of its 100 iterations (nim:117): the p-value is NaN,
+        `NaN < afmisp` is false, no warning,
+      * a row exactly at the mean (p = 1), a row whose eaf is NaN (test skipped, nim:573),
+      * absent variants (binomTest(0, 2N, eaf), nim:537) with a plausible and an implausible eaf,
+      * a row over --maxmis (locus-imputed BEFORE the test is reached, nim:565-571) and a FILTER-failed one,
+      * a row with the REF allele as effect allele, and one with missing samples (2 * ngenotyped trials)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bcfwriter
+    n = 100_000
+    # (pos, ref, ea, eaf, ALT allele count, missing samples, FILTER, in file?)
+    rows = [
+        (1000, "A", "C", 0.30, 60000, 0, [], True),        # exactly the expectation: p = 1
+        (1100, "A", "C", 0.30, 60050, 0, ["PASS"], True),  # near the mean: betacf -> NaN -> no warning
+        (1200, "A", "C", 0.30, 60600, 0, [], True),        # p = 0.0034
+        (1300, "A", "C", 0.30, 60700, 0, [], True),        # p = 0.00065 -> warned
+        (1400, "A", "C", 0.30, 59300, 0, [], True),        # p = 0.00063 -> warned (x below the mean)
+        (1500, "A", "C", 0.30, 59400, 0, [], True),        # p = 0.0034
+        (1600, "G", "C", 0.10, 40000, 0, [], True),        # far off: p = 0 -> warned
+        (1700, "A", "A", 0.70, 60700, 0, [], True),        # effect allele = REF, 139 300 REF alleles: warned
+        (1800, "A", "C", 0.30, 0, 0, [], False),           # absent, eaf 0.3: "cohort EAF is 0" warned
+        (1900, "A", "C", 1e-7, 0, 0, [], False),           # absent, eaf 1e-7: p = 1
+        (2000, "A", "C", float("nan"), 90000, 0, [], True),  # eaf NaN: no test
+        (2100, "A", "C", 0.30, 10000, 10000, [], True),    # 10 % missing: over --maxmis, no AF test
+        (2200, "A", "C", 0.30, 60120, 1000, [], True),     # 1 % missing: 198 000 trials, p = 0.00042 -> warned
+        (2300, "A", "C", 0.30, 60000, 1000, [], True),     # 1 % missing: p = 0.0033
+        (2400, "A", "C", 0.30, 10000, 0, ["FAIL"], True),  # FILTER: locus-imputed, no AF test
+        (2500, "A", "G", 0.30, 60700, 0, [], True),        # ea not among the ALT alleles -> absent -> warned
+    ]
+    lines = ["af-mismatch", "", "", "GRCh37", "0.5"]
+    recs = []
+    for pos, ref, ea, eaf, x, nmiss, filt, present in rows:
+        lines.append("7\t%d\t%s\t%s\t0.01\t%s" % (pos, ref, ea, "NaN" if eaf != eaf else repr(eaf)))
+        if not present:
+            continue
+        a = np.zeros(2 * n, dtype=np.int64)
+        a[:x] = 1                                          # x ALT alleles, at the front
+        gts = ((a + 1) << 1).reshape(n, 2)
+        if nmiss:
+            gts[n - nmiss:] = 0                            # missing samples at the back (REF/REF before)
+        recs.append(dict(contig="7", pos=pos, id=".", ref=ref, alts=["C"], filters=filt, gts=gts))
+    (tmp_path / "af.score").write_text("\n".join(lines))
+    path = str(tmp_path / "af.bcf")
+    samples = ["S%06d" % i for i in range(n)]
+    bcfwriter.write_bcf(path, ["7"], samples, recs, gt_dtype=np.int8)
+    r = subprocess.run([CLI, str(tmp_path / "af.score"), path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    warns = [l[5:] for l in r.stdout.splitlines() if l.startswith("WARN ")]
+    assert sum(1 for l in r.stdout.splitlines() if not l.startswith("WARN ")) == n
+
+    # the oracle's decisions and texts, in score-file order
+    fmt = refcpu.format_score
+    expected, n_nan = [], 0
+    for pos, ref, ea, eaf, x, nmiss, filt, present in rows:
+        var = "7:%d:%s:%s" % (pos, ref, ea)
+        if not present or (ea != ref and ea != "C"):       # findVariant returns nil (nim:536-541)
+            if eaf == eaf and refcpu.binom_test(0, 2 * n, eaf) < 0.001:
+                expected.append("Variant %s cohort EAF is 0 in %d samples.  This is highly unlikely given "
+                                "polygenic score EAF of %s" % (var, n, fmt(eaf)))
+            continue
+        if filt == ["FAIL"]:
+            expected.append('Variant %s has a FILTER flag set (value "FAIL").  Imputing all dosages at this locus.' % var)
+            continue
+        if nmiss / n > 0.05:
+            expected.append("Locus 7:%d-%d has %s%% of samples missing a genotype. This exceeds the missingness "
+                            "threshold; imputing all dosages at this locus." % (pos, pos, fmt(nmiss / n * 100)))
+            continue
+        neff = (2 * (n - nmiss) - x) if ea == ref else x   # tallyAlleles counts the EFFECT allele
+        nobs = (n - nmiss) * 2
+        if eaf == eaf:
+            p = refcpu.binom_test(neff, nobs, eaf)
+            n_nan += int(p != p)
+            if p < 0.001:
+                expected.append("Variant %s cohort EAF is %s in %d samples.  This is highly unlikely given "
+                                "polygenic score EAF of %s" % (var, fmt(neff / nobs), n, fmt(eaf)))
+    assert n_nan == 1                                      # the MAXIT case really is in the fixture
+    assert sum("cohort EAF is" in w for w in expected) == 7
+    assert warns == expected

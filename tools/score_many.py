@@ -81,10 +81,10 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    from nimpress_amd import capi, host, multi
-    capi.load()
     import torch
     import torch.distributed as dist
+    from nimpress_amd import capi, host, multi
+    capi.load()
     if capi.device_count() < 1:
         sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
     device = torch.device("cuda", local_rank)
