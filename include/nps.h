@@ -214,6 +214,10 @@ void nps_destroy(nps_ctx *ctx);
 #define NPS_CODE_MISSING 2u
 #define NPS_CODE_DOSAGE2 3u
 #define NPS_FMT_DS32 1 /* float32 dosages, NaN = missing, variant-major / sample-minor */
+/* 2-bit codes in the layout of the multi-score (matrix-core) path: superblocks of 128 rows x groups of 32
+ * samples, 16 ROWS of one sample per 32-bit word; carries its whole-row tallies.  Filled by
+ * nps_cohort_convert (from a NPS_FMT_GT2 cohort) or nps_cohort_synth[_rows]; scored by nps_score_cohort_multi. */
+#define NPS_FMT_GT2M 2
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
                       int format);
@@ -268,6 +272,42 @@ void nps_scoredef_destroy(nps_scoredef *d);
  * context's sums undefined: every later call returns NPS_E_STATE until nps_reset. */
 int nps_score_cohort_def(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
                          const nps_scoredef *def, int mode);
+
+/* ---- several score definitions in ONE pass over a resident cohort --------------------------
+ * The reference evaluates one score per run (nimpress.nim:634-641); S scores over the same cohort are S
+ * passes over the genotypes.  Here the S definitions are applied together: scores[N x S] =
+ * dosage[N x M] . weights[M x S] on the matrix cores (int8 dosages x base-128 digits of the fixed-point
+ * weights, exact integer accumulation: DESIGN.md), the genotypes are read once for all S.
+ *
+ * Position j of every definition refers to cohort row cohort_row0 + j (a cohort holding the union of
+ * the scores' loci); per (score, position) `kind` says what that score does with the row:
+ * NPS_ROW_PRESENT (the genotypes count), UNCOVERED / ABSENT / FILTERED (the host's early returns of
+ * getImputedDosages, nimpress.nim:526-558: a constant, no genotypes) or NPS_ROW_NOT_IN_SCORE (the score
+ * file does not list the locus).  Results per score are those of the single-score entry points
+ * (same decisions, nloci bit-exact, scores within ~1e-13 relative: the weights are quantised to 2^-49 of
+ * the largest one).  beta must be finite (NPS_E_UNSUPPORTED otherwise). */
+#define NPS_ROW_NOT_IN_SCORE 4
+#define NPS_MULTI_MAX_SCORES 8
+typedef struct nps_multi nps_multi;
+typedef struct nps_multidef nps_multidef;
+/* rows: [n_scores][n_desc], score-major */
+int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc);
+void nps_multidef_destroy(nps_multidef *d);
+int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_params *params, int n_scores);
+/* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset */
+int nps_score_cohort_multi(nps_multi *m, const nps_cohort *c, uint64_t cohort_row0, const nps_multidef *def);
+/* scores_out: [n_scores][n_samples]; nloci_out: [n_scores]; offsets: [n_scores]  (nimpress.nim:643-649) */
+int nps_multi_finish(nps_multi *m, const double *offsets, double *scores_out, uint64_t *nloci_out);
+int nps_multi_finish_device(nps_multi *m, const double *offsets, double *d_scores_out, uint64_t *nloci_out);
+int nps_multi_reset(nps_multi *m, const nps_params *params /* NULL = keep */);
+void nps_multi_destroy(nps_multi *m);
+/* device time (HIP events) of the calls since the last reset: weight digits, the product, the fold */
+int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold);
+/* NPS_FMT_GT2 cohort (plain order) -> NPS_FMT_GT2M cohort of the same shape, with its row tallies */
+int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src);
+/* the whole-row tallies a NPS_FMT_GT2M cohort carries (tallyAlleles, nimpress.nim:32-47), for warnings */
+int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t *nmissing_out,
+                           uint64_t *neffect_out);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 int nps_profile_enable(nps_ctx *ctx, int on); /* record HIP events around every launch */

@@ -20,7 +20,9 @@ MISSING = {"homref": 0, "ignore": 1}
 SAMPLE = {"ps": 0, "homref": 1, "fail": 2, "int_ps": 3, "int_fail": 4}
 ROW_PRESENT, ROW_UNCOVERED, ROW_ABSENT, ROW_FILTERED = 0, 1, 2, 3
 REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMIS = range(5)
-FMT_GT2, FMT_DS32 = 0, 1
+FMT_GT2, FMT_DS32, FMT_GT2M = 0, 1, 2
+ROW_NOT_IN_SCORE = 4
+MULTI_MAX_SCORES = 8
 MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
 
 NPS_OK = 0
@@ -56,6 +58,9 @@ SYMBOLS = [
     "nps_cohort_optimize",
     "nps_cohort_destroy",
     "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream", "nps_fused_geometry",
+    "nps_multidef_create", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
+    "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
+    "nps_cohort_convert", "nps_cohort_row_tallies",
 ]
 
 
@@ -164,6 +169,20 @@ def load():
     L.nps_stream.restype = vp
     u32p = C.POINTER(C.c_uint32)
     L.nps_fused_geometry.argtypes = [vp, i32, u64, u32p, u32p, u32p]
+    L.nps_multidef_create.argtypes = [C.POINTER(vp), i32, vp, i32, u64]
+    L.nps_multidef_destroy.argtypes = [vp]
+    L.nps_multidef_destroy.restype = None
+    L.nps_multi_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams), i32]
+    L.nps_score_cohort_multi.argtypes = [vp, vp, u64, vp]
+    L.nps_multi_finish.argtypes = [vp, vp, vp, vp]
+    L.nps_multi_finish_device.argtypes = [vp, vp, vp, vp]
+    L.nps_multi_reset.argtypes = [vp, C.POINTER(NpsParams)]
+    L.nps_multi_destroy.argtypes = [vp]
+    L.nps_multi_destroy.restype = None
+    dp = C.POINTER(C.c_double)
+    L.nps_multi_timing.argtypes = [vp, dp, dp, dp]
+    L.nps_cohort_convert.argtypes = [vp, vp]
+    L.nps_cohort_row_tallies.argtypes = [vp, u64, u64, vp, vp]
     _lib = L
     return L
 
@@ -232,6 +251,17 @@ class Cohort:
         assert th.size == tm.size == tmi.size
         _check(load().nps_cohort_synth_rows(self._h, row0, th.size, gen_row0, seed, th.ctypes.data,
                                             tm.ctypes.data, tmi.ctypes.data))
+
+    def convert_from(self, src: "Cohort"):
+        """fill this FMT_GT2M cohort (and its row tallies) from a FMT_GT2 cohort of the same shape"""
+        _check(load().nps_cohort_convert(self._h, src._h))
+
+    def row_tallies(self, row0: int = 0, nrows: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """(nmissing, neffect) per row of a FMT_GT2M cohort"""
+        nrows = self.n_rows - row0 if nrows is None else nrows
+        nm, ne = np.zeros(max(nrows, 1), dtype=np.uint64), np.zeros(max(nrows, 1), dtype=np.uint64)
+        _check(load().nps_cohort_row_tallies(self._h, row0, nrows, nm.ctypes.data, ne.ctypes.data))
+        return nm[:nrows], ne[:nrows]
 
     def optimize(self):
         """one-time layout optimisation (nps_cohort_optimize): the row of every group of 4 with the most
@@ -402,6 +432,74 @@ class Scorer:
     def close(self):
         if self._h:
             load().nps_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiDef:
+    """S score definitions over the same cohort rows ([S, n_desc] row descriptors), resident on the device"""
+
+    def __init__(self, rows: np.ndarray, device: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=ROW_DESC_DTYPE)
+        assert rows.ndim == 2
+        self._h = C.c_void_p()
+        self.n_scores, self.n_desc = rows.shape
+        _check(load().nps_multidef_create(C.byref(self._h), device, rows.ctypes.data, self.n_scores, self.n_desc))
+
+    def close(self):
+        if self._h:
+            load().nps_multidef_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScorer:
+    """computePolygenicScores for S score definitions in one pass over a FMT_GT2M cohort (matrix cores)"""
+
+    def __init__(self, n_samples: int, params: NpsParams, n_scores: int, device: int = 0):
+        self._h = C.c_void_p()
+        self.n, self.n_scores = int(n_samples), int(n_scores)
+        _check(load().nps_multi_create(C.byref(self._h), device, self.n, C.byref(params), self.n_scores))
+
+    def score_cohort(self, cohort: Cohort, mdef: MultiDef, cohort_row0: int = 0):
+        _check(load().nps_score_cohort_multi(self._h, cohort._h, cohort_row0, mdef._h))
+
+    def finish(self, offsets) -> Tuple[np.ndarray, np.ndarray]:
+        off = np.ascontiguousarray(offsets, dtype=np.float64)
+        assert off.size == self.n_scores
+        scores = np.empty((self.n_scores, max(self.n, 1)), dtype=np.float64)
+        nloci = np.zeros(self.n_scores, dtype=np.uint64)
+        _check(load().nps_multi_finish(self._h, off.ctypes.data, scores.ctypes.data, nloci.ctypes.data))
+        return scores[:, : self.n], nloci
+
+    def finish_device(self, offsets, d_scores_ptr: int) -> np.ndarray:
+        off = np.ascontiguousarray(offsets, dtype=np.float64)
+        nloci = np.zeros(self.n_scores, dtype=np.uint64)
+        _check(load().nps_multi_finish_device(self._h, off.ctypes.data, C.c_void_p(d_scores_ptr),
+                                              nloci.ctypes.data))
+        return nloci
+
+    def reset(self, params: Optional[NpsParams] = None):
+        _check(load().nps_multi_reset(self._h, C.byref(params) if params is not None else None))
+
+    def timing(self) -> Tuple[float, float, float]:
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        _check(load().nps_multi_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self):
+        if self._h:
+            load().nps_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

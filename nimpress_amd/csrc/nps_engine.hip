@@ -61,6 +61,8 @@ struct nps_cohort {
     bool optimized = false;
     uint8_t *d_swap = nullptr;
     std::vector<uint8_t> h_swap;
+    // NPS_FMT_GT2M: whole-row tallies (nmissing << 32 | neffect) produced by whatever packed the rows
+    unsigned long long *d_row_tally = nullptr;
 };
 
 // slot <-> logical row inside a group (the exchange of slot 0 and slot j is its own inverse)
@@ -900,7 +902,7 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
                                  int format) {
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
-    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32)
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M)
         return fail(NPS_E_INVAL, "unknown cohort format %d", format);
     if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
     int rc = select_device(device);
@@ -914,7 +916,17 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     c->stride_bytes = format == NPS_FMT_DS32 ? ds_stride_floats(n_samples) * 4
                                               : stride_words_for(n_samples) * 4;
     const uint64_t rows_alloc = format == NPS_FMT_GT2 ? (n_rows + 3) / 4 * 4 : n_rows;
-    const uint64_t bytes = std::max<uint64_t>(c->stride_bytes * rows_alloc, 256);
+    uint64_t bytes = std::max<uint64_t>(c->stride_bytes * rows_alloc, 256);
+    if (format == NPS_FMT_GT2M) {
+        c->stride_bytes = 0;  // not row-major: 1 KiB units of 128 rows x 32 samples
+        bytes = std::max<uint64_t>(gt2m_bytes(n_samples, n_rows), 256);
+        const uint64_t tb = sizeof(unsigned long long) * std::max<uint64_t>(gt2m_superblocks(n_rows) * 128, 1);
+        if (hipMalloc(&c->d_row_tally, tb) != hipSuccess || hipMemset(c->d_row_tally, 0, tb) != hipSuccess) {
+            (void)hipFree(c->d_row_tally);
+            delete c;
+            return fail(NPS_E_NOMEM, "hipMalloc of the row tallies failed");
+        }
+    }
     hipError_t e = hipMalloc(&c->d_data, bytes);
     if (e != hipSuccess) {
         delete c;
@@ -940,6 +952,7 @@ extern "C" void nps_cohort_destroy(nps_cohort *c) {
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_data);
     (void)hipFree(c->d_swap);
+    (void)hipFree(c->d_row_tally);
     delete c;
 }
 
@@ -1068,6 +1081,9 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
+    if (c->format == NPS_FMT_GT2M)
+        return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are filled by nps_cohort_convert (from a "
+                                       "NPS_FMT_GT2 cohort) or by the synthetic generator");
     const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
@@ -1087,6 +1103,7 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
                                    void *host_rows, size_t host_stride) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
+    if (c->format == NPS_FMT_GT2M) return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts cannot be downloaded");
     const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
@@ -1106,6 +1123,8 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (!t_het || !t_hom || !t_miss) return fail(NPS_E_INVAL, "threshold arrays are NULL");
     if (c->format == NPS_FMT_GT2 && (row0 & 3))
         return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
+    if (c->format == NPS_FMT_GT2M && (row0 & 127))
+        return fail(NPS_E_INVAL, "row0 must be a multiple of 128 for NPS_FMT_GT2M cohorts");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     rc = cohort_unoptimize(c);
@@ -1118,7 +1137,10 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
     const uint64_t step = 32768;
     for (uint64_t r = 0; e == hipSuccess && r < nrows; r += step) {
         const uint64_t k = std::min(step, nrows - r);
-        if (c->format == NPS_FMT_DS32)
+        if (c->format == NPS_FMT_GT2M)
+            e = launch_synth_gt2m(nullptr, c->d_data, c->n_samples, row0 + r, gen_row0 + r, k, seed, d_t + r,
+                                  d_t + nrows + r, d_t + 2 * nrows + r, c->d_row_tally);
+        else if (c->format == NPS_FMT_DS32)
             e = launch_synth_ds(nullptr, (float *)c->d_data, c->stride_bytes / 4, c->n_samples,
                                 row0 + r, gen_row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
         else
@@ -1296,6 +1318,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     const uint64_t m = def->m;
     rc = check_range(co, cohort_row0, m);
     if (rc) return rc;
+    if (co->format == NPS_FMT_GT2M)
+        return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are scored with nps_score_cohort_multi");
     const bool is_ds = co->format == NPS_FMT_DS32;
     if (!is_ds && (cohort_row0 & 3))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
@@ -1559,6 +1583,306 @@ extern "C" int nps_score_cohort(nps_ctx *c, const nps_cohort *co, uint64_t cohor
     }
     nps_scoredef_destroy(def);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// several score definitions in one pass over a NPS_FMT_GT2M cohort (nps_multi.hip)
+extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
+    if (!dst || !src) return fail(NPS_E_INVAL, "cohort is NULL");
+    if (dst->format != NPS_FMT_GT2M || src->format != NPS_FMT_GT2)
+        return fail(NPS_E_INVAL, "nps_cohort_convert goes from a NPS_FMT_GT2 to a NPS_FMT_GT2M cohort");
+    if (dst->device != src->device || dst->n_samples != src->n_samples || dst->n_rows != src->n_rows)
+        return fail(NPS_E_INVAL, "source and destination differ in device, samples or rows");
+    if (src->optimized)
+        return fail(NPS_E_STATE, "the source cohort is in nps_cohort_optimize order; convert it before optimising");
+    HIP_TRY(hipSetDevice(dst->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;
+    HIP_TRY(launch_convert_gt2m(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
+                                src->n_rows, dst->d_data));
+    // whole-row tallies, computed while packing (tallyAlleles nimpress.nim:32-47; same kernel as the two-pass path)
+    HIP_TRY(launch_tally_packed(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
+                                src->n_rows, dst->d_row_tally));
+    HIP_TRY(hipDeviceSynchronize());
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t *nmissing_out,
+                                      uint64_t *neffect_out) {
+    int rc = check_range(c, row0, nrows);
+    if (rc) return rc;
+    if (c->format != NPS_FMT_GT2M) return fail(NPS_E_UNSUPPORTED, "row tallies are kept with NPS_FMT_GT2M cohorts only");
+    if (nrows == 0) return NPS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned long long> t(nrows);
+    HIP_TRY(hipMemcpy(t.data(), c->d_row_tally + row0, sizeof(unsigned long long) * nrows, hipMemcpyDeviceToHost));
+    for (uint64_t j = 0; j < nrows; ++j) {
+        if (nmissing_out) nmissing_out[j] = t[j] >> 32;
+        if (neffect_out) neffect_out[j] = t[j] & 0xffffffffull;
+    }
+    return NPS_OK;
+}
+
+struct nps_multidef {
+    int device = 0;
+    int S = 0;
+    uint64_t n_desc = 0;
+    nps_row_desc *d_desc = nullptr;  // [S][n_desc]
+    int *d_F = nullptr;              // fixed-point exponent per score: weight * 2^F is an integer below 2^47
+};
+
+extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores,
+                                   uint64_t n_desc) {
+    if (!out) return fail(NPS_E_INVAL, "out is NULL");
+    *out = nullptr;
+    if (n_scores < 1 || n_scores > NPS_MULTI_MAX_SCORES)
+        return fail(NPS_E_INVAL, "n_scores %d outside 1..%d", n_scores, NPS_MULTI_MAX_SCORES);
+    if (n_desc && !rows) return fail(NPS_E_INVAL, "rows is NULL");
+    if (n_desc > 0xfffffff0ull) return fail(NPS_E_UNSUPPORTED, "too many rows");
+    int F[NPS_MULTI_MAX_SCORES];
+    for (int s = 0; s < n_scores; ++s) {
+        double maxb = 0.0, maxe = 0.0;
+        for (uint64_t j = 0; j < n_desc; ++j) {
+            const nps_row_desc &r = rows[(uint64_t)s * n_desc + j];
+            if (r.kind < NPS_ROW_PRESENT || r.kind > NPS_ROW_NOT_IN_SCORE)
+                return fail(NPS_E_INVAL, "score %d row %llu: bad kind %d", s, (unsigned long long)j, r.kind);
+            if (r.kind == NPS_ROW_NOT_IN_SCORE) continue;
+            if (!std::isfinite(r.beta))
+                return fail(NPS_E_UNSUPPORTED, "score %d row %llu: beta is not finite (use the single-score path)",
+                            s, (unsigned long long)j);
+            maxb = std::max(maxb, std::fabs(r.beta));
+            if (std::isfinite(r.eaf)) maxe = std::max(maxe, std::fabs(r.eaf));
+        }
+        // largest weight a row can have: |beta| * max(|imputed - 3|, |locus constant|)
+        const double bound = maxb * (3.0 + std::max(2.0, 2.0 * maxe));
+        int e = 0;
+        if (bound > 0.0) (void)std::frexp(bound, &e);  // bound < 2^e
+        F[s] = 47 - e;
+    }
+    int rc = select_device(device);
+    if (rc) return rc;
+    nps_multidef *d = new (std::nothrow) nps_multidef;
+    if (!d) return fail(NPS_E_NOMEM, "out of host memory");
+    d->device = device;
+    d->S = n_scores;
+    d->n_desc = n_desc;
+    hipError_t e = hipMalloc(&d->d_F, sizeof(int) * NPS_MULTI_MAX_SCORES);
+    if (e == hipSuccess) e = hipMemcpy(d->d_F, F, sizeof(int) * n_scores, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_desc) {
+        e = hipMalloc(&d->d_desc, sizeof(nps_row_desc) * n_desc * n_scores);
+        if (e == hipSuccess)
+            e = hipMemcpy(d->d_desc, rows, sizeof(nps_row_desc) * n_desc * n_scores, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(d->d_F);
+        (void)hipFree(d->d_desc);
+        delete d;
+        return fail(e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP, "uploading the score definitions failed: %s",
+                    hipGetErrorString(e));
+    }
+    *out = d;
+    return NPS_OK;
+}
+
+extern "C" void nps_multidef_destroy(nps_multidef *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d->d_desc);
+    (void)hipFree(d->d_F);
+    delete d;
+}
+
+struct nps_multi {
+    int device = 0, S = 0, cus = 0;
+    hipStream_t stream = nullptr;
+    uint64_t n = 0;
+    nps_params params{};
+    void *d_state = nullptr;      // MultiState[S]
+    double *d_part = nullptr;     // [S][n] float64 running sums
+    bool have_sums = false;
+    void *d_table = nullptr;
+    uint64_t table_cap = 0;
+    int32_t *d_partial = nullptr;
+    uint64_t partial_cap = 0;
+    double *d_offsets = nullptr, *d_scores = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double ms[3] = {0.0, 0.0, 0.0};  // params, product, fold of all calls since the last reset
+    bool timed = false;
+};
+
+// add the device time of the last call (if its events have not been read yet) to the running totals
+static void multi_drain_timing(nps_multi *m) {
+    if (!m->timed) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (hipEventSynchronize(m->ev[3]) == hipSuccess) {
+        (void)hipEventElapsedTime(&a, m->ev[0], m->ev[1]);
+        (void)hipEventElapsedTime(&b, m->ev[1], m->ev[2]);
+        (void)hipEventElapsedTime(&c, m->ev[2], m->ev[3]);
+        m->ms[0] += a;
+        m->ms[1] += b;
+        m->ms[2] += c;
+    }
+    m->timed = false;
+}
+
+static void free_multi(nps_multi *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(m->d_state);
+    (void)hipFree(m->d_part);
+    (void)hipFree(m->d_table);
+    (void)hipFree(m->d_partial);
+    (void)hipFree(m->d_offsets);
+    (void)hipFree(m->d_scores);
+    for (hipEvent_t e : m->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_params *params,
+                                int n_scores) {
+    if (!out) return fail(NPS_E_INVAL, "out is NULL");
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n_scores < 1 || n_scores > NPS_MULTI_MAX_SCORES)
+        return fail(NPS_E_INVAL, "n_scores %d outside 1..%d", n_scores, NPS_MULTI_MAX_SCORES);
+    if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
+    rc = select_device(device);
+    if (rc) return rc;
+    nps_multi *m = new (std::nothrow) nps_multi;
+    if (!m) return fail(NPS_E_NOMEM, "out of host memory");
+    m->device = device;
+    m->S = n_scores;
+    m->n = n_samples;
+    m->params = *params;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    m->cus = e == hipSuccess ? prop.multiProcessorCount : 256;
+    const size_t sb = multi_state_bytes() * NPS_MULTI_MAX_SCORES;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&m->d_state, sb);
+    if (e == hipSuccess) e = hipMemset(m->d_state, 0, sb);
+    if (e == hipSuccess) e = hipMalloc(&m->d_part, sizeof(double) * std::max<uint64_t>(n_samples, 1) * n_scores);
+    if (e == hipSuccess) e = hipMalloc(&m->d_scores, sizeof(double) * std::max<uint64_t>(n_samples, 1) * n_scores);
+    if (e == hipSuccess) e = hipMalloc(&m->d_offsets, sizeof(double) * NPS_MULTI_MAX_SCORES);
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&m->ev[k]);
+    if (e != hipSuccess) {
+        free_multi(m);
+        return fail(e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP, "nps_multi_create: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return NPS_OK;
+}
+
+extern "C" void nps_multi_destroy(nps_multi *m) { free_multi(m); }
+
+extern "C" int nps_multi_reset(nps_multi *m, const nps_params *params) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (params) {
+        int rc = check_params(params);
+        if (rc) return rc;
+        m->params = *params;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    multi_drain_timing(m);
+    HIP_TRY(hipMemsetAsync(m->d_state, 0, multi_state_bytes() * NPS_MULTI_MAX_SCORES, m->stream));
+    m->have_sums = false;
+    m->ms[0] = m->ms[1] = m->ms[2] = 0.0;
+    return NPS_OK;
+}
+
+extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64_t cohort_row0,
+                                      const nps_multidef *def) {
+    if (!m || !co || !def) return fail(NPS_E_INVAL, "ctx, cohort or definitions is NULL");
+    if (co->format != NPS_FMT_GT2M) return fail(NPS_E_INVAL, "nps_score_cohort_multi needs a NPS_FMT_GT2M cohort");
+    if (co->device != m->device || def->device != m->device)
+        return fail(NPS_E_INVAL, "cohort / definitions / context on different devices");
+    if (co->n_samples != m->n)
+        return fail(NPS_E_INVAL, "cohort has %llu samples, context %llu", (unsigned long long)co->n_samples,
+                    (unsigned long long)m->n);
+    if (def->S != m->S) return fail(NPS_E_INVAL, "definitions hold %d scores, context %d", def->S, m->S);
+    if (cohort_row0 & 127) return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 128");
+    int rc = check_range(co, cohort_row0, def->n_desc);
+    if (rc) return rc;
+    if (def->n_desc == 0) return NPS_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const MultiPlan pl = multi_plan(m->n, def->n_desc, m->S, m->cus);
+    if (pl.table_bytes() > m->table_cap) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        (void)hipFree(m->d_table);
+        m->d_table = nullptr;
+        m->table_cap = 0;
+        HIP_TRY(hipMalloc(&m->d_table, pl.table_bytes()));
+        m->table_cap = pl.table_bytes();
+    }
+    if (pl.partial_elems() > m->partial_cap) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        (void)hipFree(m->d_partial);
+        m->d_partial = nullptr;
+        m->partial_cap = 0;
+        HIP_TRY(hipMalloc(&m->d_partial, sizeof(int32_t) * std::max<uint64_t>(pl.partial_elems(), 1)));
+        m->partial_cap = pl.partial_elems();
+    }
+    multi_drain_timing(m);  // (the events are about to be re-recorded)
+    // unused columns of the last tile and the rows that pad the last superblock stay zero
+    HIP_TRY(hipMemsetAsync(m->d_table, 0, pl.table_bytes(), m->stream));
+    HIP_TRY(hipEventRecord(m->ev[0], m->stream));
+    HIP_TRY(launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
+                                dev_params(m->params), def->d_F, m->d_table, m->d_state));
+    HIP_TRY(hipEventRecord(m->ev[1], m->stream));
+    if (m->n) HIP_TRY(launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial));
+    HIP_TRY(hipEventRecord(m->ev[2], m->stream));
+    HIP_TRY(launch_multi_fold(m->stream, pl, m->d_partial, m->n, m->S, def->d_F, m->d_part, m->have_sums ? 0 : 1,
+                              m->d_state));
+    HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+    m->have_sums = true;
+    m->timed = true;
+    return NPS_OK;
+}
+
+static int multi_finish_common(nps_multi *m, const double *offsets, double *d_dst, double *h_scores_out,
+                               uint64_t *nloci_out) {
+    if (!offsets) return fail(NPS_E_INVAL, "offsets is NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(m->d_offsets, offsets, sizeof(double) * m->S, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(launch_multi_finish(m->stream, m->d_part, m->n, m->S, m->d_state, m->d_offsets, m->have_sums ? 1 : 0,
+                                d_dst));
+    std::vector<char> st(multi_state_bytes() * m->S);
+    HIP_TRY(hipMemcpyAsync(st.data(), m->d_state, st.size(), hipMemcpyDeviceToHost, m->stream));
+    if (h_scores_out && m->n)
+        HIP_TRY(hipMemcpyAsync(h_scores_out, d_dst, sizeof(double) * m->n * m->S, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (nloci_out)
+        for (int s = 0; s < m->S; ++s)
+            memcpy(&nloci_out[s], st.data() + multi_state_bytes() * s, sizeof(uint64_t));  // first field
+    return NPS_OK;
+}
+
+extern "C" int nps_multi_finish(nps_multi *m, const double *offsets, double *scores_out, uint64_t *nloci_out) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (m->n && !scores_out) return fail(NPS_E_INVAL, "scores_out is NULL");
+    return multi_finish_common(m, offsets, m->d_scores, scores_out, nloci_out);
+}
+
+extern "C" int nps_multi_finish_device(nps_multi *m, const double *offsets, double *d_scores_out,
+                                       uint64_t *nloci_out) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (m->n && !d_scores_out) return fail(NPS_E_INVAL, "d_scores_out is NULL");
+    return multi_finish_common(m, offsets, d_scores_out, nullptr, nloci_out);
+}
+
+extern "C" int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    multi_drain_timing(m);
+    if (ms_params) *ms_params = m->ms[0];
+    if (ms_product) *ms_product = m->ms[1];
+    if (ms_fold) *ms_fold = m->ms[2];
+    return NPS_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ namespace nps {
 // of 1 KiB); padding words and the rows that pad the last group are zero.
 // Tally word per row (two-pass path): (nmissing << 32) | neffect.
 constexpr uint32_t kStrideAlignWords = 64;
-static inline uint64_t g4_word_index(uint64_t row, uint64_t col, uint64_t stride_words) {
+static __host__ __device__ inline uint64_t g4_word_index(uint64_t row, uint64_t col, uint64_t stride_words) {
     return ((row >> 2) * stride_words + col) * 4 + (row & 3);
 }
 
@@ -185,5 +185,39 @@ hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_by
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
                            uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss);
+
+// ---- several scores in one pass on the matrix cores (nps_multi.hip) -----------------------------
+// NPS_FMT_GT2M cohort: ceil(rows/128) superblocks x ceil(samples/32) groups x 1 KiB units
+static inline uint64_t gt2m_groups(uint64_t n_samples) { return (n_samples + 31) / 32; }
+static inline uint64_t gt2m_superblocks(uint64_t n_rows) { return (n_rows + 127) / 128; }
+static inline uint64_t gt2m_bytes(uint64_t n_samples, uint64_t n_rows) {
+    return gt2m_superblocks(n_rows) * gt2m_groups(n_samples) * 1024;
+}
+// rows [row0, row0+n_rows) (row0 a multiple of 128) from the synthetic generator's rows gen_row0.., and
+// their whole-row tallies (nmissing << 32 | neffect) into d_tally[row0 ..]
+hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t row0, uint64_t gen_row0,
+                             uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                             const uint32_t *d_t_miss, unsigned long long *d_tally);
+// a whole 2-bit row-major cohort (plain order) -> units
+hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
+                               uint64_t n_samples, uint64_t n_rows, void *d_units);
+struct MultiPlan {
+    int NT = 0, GW = 0;          // column tiles of 32 (4 scores each); sample groups per wave
+    uint64_t n_groups = 0;
+    uint32_t n_sb = 0, tiles = 0, sb_per_chunk = 0, n_chunks = 0;
+    uint64_t table_bytes() const { return (uint64_t)n_sb * 4 * NT * 2 * 64 * 16; }
+    uint64_t partial_elems() const { return (uint64_t)n_chunks * n_groups * 32 * NT * 32; }
+};
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus);
+size_t multi_state_bytes();
+hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
+                               uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
+                               void *d_table, void *d_state);
+hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
+                             const void *d_table, int32_t *d_partial);
+hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
+                             const int *d_F, double *d_part, int overwrite, void *d_state);
+hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,
+                               const double *d_offsets, int have_sums, double *d_scores);
 
 }  // namespace nps

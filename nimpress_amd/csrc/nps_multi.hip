@@ -1,0 +1,525 @@
+// nps_multi.hip -- several score definitions evaluated in ONE pass over a resident cohort, on the
+// matrix cores (reference loop nimpress.nim:634-641 run S times).
+//
+// For ONE score the inner loop is a weighted reduction: one table lookup per four genotypes, bound by
+// the LDS (nps_fused.hip).  For S scores over the same rows it is a matrix product
+//
+//        scores[N x S]  =  dosage[N x M] . beta[M x S]   (+ imputed values of the missing genotypes)
+//
+// and that belongs on MFMA -- provided the arithmetic stays exact enough for the 1e-6 bar.  float64
+// MFMA runs at the vector rate and would need every genotype converted to a double.  Instead:
+//
+//   * the per-row weights are turned into FIXED-POINT integers (49 bits) and split into seven signed
+//     base-128 digits: w = sum_k d_k 128^k / 2^F.  dosage (0,1,2 as int8) x digit (int8) accumulated in
+//     int32 by v_mfma_i32_32x32x32_i8 is EXACT integer arithmetic, independent of the summation order;
+//     the seven digit sums of a sample are recombined in float64 at the very end.  The only error is
+//     the quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score).
+//   * a missing genotype has code 3 in this layout: it contributes 3 x beta through the dosage
+//     matrix, and (imputed - 3) x beta through a second 0/1 matrix "is missing" (same accumulators).
+//     A weight that is NaN in the reference (imp-sample fail / int_fail below --mincs, NaN eaf) sets a
+//     flag digit instead: any sample that meets it comes out NaN, as in the reference.
+//   * rows the reference imputes as a whole locus (over --maxmis, uncovered, absent, FILTER) add the
+//     same constant to every sample: summed exactly in fixed point on the side, no matrix work.
+//
+// Data layout NPS_FMT_GT2M (the A operand wants 16 ROWS of one sample per lane): superblocks of 128
+// rows x groups of 32 samples; unit (superblock, group) = 64 lanes x 16 bytes = 1 KiB contiguous;
+// lane l = sample (l & 31), row half h = l >> 5; its four words w = 0..3 hold rows 64h + 16w + j
+// (j = 0..15, code of row j in bits 2j, 2j+1); codes 0, 1, 2 = dosage, 3 = missing.
+// Whole-row tallies (tallyAlleles, nimpress.nim:32-47) are produced when the cohort is packed (by the
+// generator / the converter, as the streaming decode kernel does for pushed rows) and kept with it.
+#include <algorithm>
+#include <cmath>
+
+#include "nps_kernels.h"
+
+namespace nps {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// packing: synthetic generator, converter from the 2-bit row-major cohort layout, tallies
+static __device__ __forceinline__ uint64_t mmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// NPS_CODE_* (0, 1, 3 = dosage 2, 2 = missing) -> layout code (0, 1, 2, 3 = missing)
+static __device__ __forceinline__ uint32_t m_code(uint32_t c) { return c ^ (c >> 1); }
+
+// one thread = one lane of one unit: (sample, row half) x 64 rows.  grid = (units chunks, superblocks)
+__global__ __launch_bounds__(256) void synth_gt2m_kernel(uint4 *__restrict__ units, uint64_t n_groups,
+                                                         uint64_t n_samples, uint64_t sb0,
+                                                         uint64_t gen_row0, uint64_t n_rows, uint64_t seed,
+                                                         const uint32_t *__restrict__ t_het,
+                                                         const uint32_t *__restrict__ t_hom,
+                                                         const uint32_t *__restrict__ t_miss) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // lane index inside the superblock
+    const uint64_t sb = blockIdx.y;                                // relative to sb0
+    if (u >= n_groups * 64) return;
+    const uint64_t g = u >> 6;
+    const uint32_t lane = (uint32_t)(u & 63);
+    const uint64_t s = g * 32 + (lane & 31);
+    const uint32_t h = lane >> 5;
+    uint32_t out[4] = {0, 0, 0, 0};
+    if (s < n_samples) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t word = 0;
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t r = sb * 128 + 64 * h + 16 * w + j;  // row relative to the first row written
+                if (r < n_rows) {
+                    const uint64_t key = mmix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull));
+                    const uint64_t hsh = mmix64(key + s);
+                    const uint32_t gq = (uint32_t)hsh, ms = (uint32_t)(hsh >> 32);
+                    const uint32_t c = ms < t_miss[r] ? NPS_CODE_MISSING
+                                                      : (gq < t_hom[r] ? NPS_CODE_DOSAGE2 : (gq < t_het[r] ? 1u : 0u));
+                    word |= m_code(c) << (2 * j);
+                }
+            }
+            out[w] = word;
+        }
+    }
+    units[(sb0 + sb) * n_groups * 64 + u] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// whole-row tallies of generator rows, recomputed row-major (one thread = 16 samples of one row):
+// tally[r] = nmissing << 32 | neffect.  grid = (sample chunks of 4096, rows)
+__global__ __launch_bounds__(256) void synth_tally_kernel(unsigned long long *__restrict__ tally,
+                                                          uint64_t n_samples, uint64_t gen_row0, uint64_t seed,
+                                                          const uint32_t *__restrict__ t_het,
+                                                          const uint32_t *__restrict__ t_hom,
+                                                          const uint32_t *__restrict__ t_miss) {
+    __shared__ uint32_t red[8];
+    const uint64_t r = blockIdx.y;
+    const uint64_t key = mmix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull));
+    const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
+    uint32_t nm = 0, ne = 0;
+    const uint64_t s0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t s = s0 + k;
+        if (s < n_samples) {
+            const uint64_t hsh = mmix64(key + s);
+            const uint32_t gq = (uint32_t)hsh, ms = (uint32_t)(hsh >> 32);
+            if (ms < tmi)
+                nm += 1;
+            else
+                ne += gq < tm ? 2u : (gq < th ? 1u : 0u);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nm += __shfl_down(nm, o, 64);
+        ne += __shfl_down(ne, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wv * 2] = nm;
+        red[wv * 2 + 1] = ne;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long m = (unsigned long long)red[0] + red[2] + red[4] + red[6];
+        const unsigned long long e = (unsigned long long)red[1] + red[3] + red[5] + red[7];
+        if (m | e) atomicAdd(&tally[r], (m << 32) | e);
+    }
+}
+
+// rows [0, n_rows) of a 2-bit row-major cohort (group-interleaved device layout of nps_kernels.h) ->
+// units of superblocks [0, ceil(n_rows/128)).  One thread per output lane; a one-time repack.
+__global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint32_t *__restrict__ src,
+                                                           uint64_t src_stride_words, uint64_t n_samples,
+                                                           uint64_t n_rows, uint4 *__restrict__ units,
+                                                           uint64_t n_groups) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t sb = blockIdx.y;
+    if (u >= n_groups * 64) return;
+    const uint64_t g = u >> 6;
+    const uint32_t lane = (uint32_t)(u & 63);
+    const uint64_t s = g * 32 + (lane & 31);
+    const uint32_t h = lane >> 5;
+    uint32_t out[4] = {0, 0, 0, 0};
+    if (s < n_samples) {
+        const int pb = plane_bit((int)(s & 15));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t word = 0;
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t r = sb * 128 + 64 * h + 16 * w + j;
+                if (r < n_rows) {
+                    const uint32_t x = src[g4_word_index(r, s >> 4, src_stride_words)];
+                    const uint32_t c = ((x >> pb) & 1u) | (((x >> (pb + 4)) & 1u) << 1);
+                    word |= m_code(c) << (2 * j);
+                }
+            }
+            out[w] = word;
+        }
+    }
+    units[sb * n_groups * 64 + u] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t row0, uint64_t gen_row0,
+                             uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                             const uint32_t *d_t_miss, unsigned long long *d_tally /* [row0 ..) */) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    if (row0 % 128) return hipErrorInvalidValue;
+    const uint64_t n_groups = (n_samples + 31) / 32, n_sb = (n_rows + 127) / 128;
+    if (n_sb > 65535) return hipErrorInvalidValue;  // caller splits row ranges
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_gt2m_kernel, dim3((uint32_t)((n_groups * 64 + 255) / 256), (uint32_t)n_sb), dim3(256),
+                       0, st, (uint4 *)d_units, n_groups, n_samples, row0 / 128, gen_row0, n_rows, seed, d_t_het,
+                       d_t_hom, d_t_miss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_tally + row0, 0, sizeof(unsigned long long) * n_rows, st);
+    if (e != hipSuccess) return e;
+    for (uint64_t r = 0; r < n_rows; r += 65535) {
+        const uint64_t k = std::min<uint64_t>(65535, n_rows - r);
+        hipLaunchKernelGGL(synth_tally_kernel, dim3((uint32_t)((n_samples + 4095) / 4096), (uint32_t)k), dim3(256), 0,
+                           st, d_tally + row0 + r, n_samples, gen_row0 + r, seed, d_t_het + r, d_t_hom + r,
+                           d_t_miss + r);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
+                               uint64_t n_samples, uint64_t n_rows, void *d_units) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    const uint64_t n_groups = (n_samples + 31) / 32, n_sb = (n_rows + 127) / 128;
+    (void)hipGetLastError();
+    for (uint64_t sb = 0; sb < n_sb; sb += 65535) {
+        const uint64_t k = std::min<uint64_t>(65535, n_sb - sb);
+        const uint64_t rows_left = n_rows - sb * 128;
+        hipLaunchKernelGGL(convert_gt2m_kernel, dim3((uint32_t)((n_groups * 64 + 255) / 256), (uint32_t)k), dim3(256),
+                           0, st, d_src + (sb * 32) * src_stride_words * 4, src_stride_words, n_samples, rows_left,
+                           (uint4 *)d_units + sb * n_groups * 64, n_groups);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// per (position, score): the decision chain of getImputedDosages for this row (nimpress.nim:523-585)
+// and the weights as base-128 digits in MFMA-fragment order.
+//   table bytes: index(sb, w, t, dm, lane, j) = ((((sb*4 + w)*NT + t)*2 + dm)*64 + lane)*16 + j
+//   row r = 128 sb + 64 h + 16 w + j ; column c = 8 s + k ; t = c / 32 ; lane = c % 32 + 32 h
+static __device__ __forceinline__ void put_digits(int8_t *__restrict__ table, int NT, uint64_t r, int s,
+                                                  int dm, long long V, int flag) {
+    const uint64_t sb = r >> 7;
+    const int h = (int)((r >> 6) & 1), w = (int)((r >> 4) & 3), j = (int)(r & 15);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int d;
+        if (k < 7) {
+            d = (int)((V + 64) & 127) - 64;
+            V = (V - d) >> 7;
+        } else {
+            d = flag;
+        }
+        const int c = 8 * s + k, t = c >> 5, lane = (c & 31) + 32 * h;
+        table[((((sb * 4 + w) * NT + t) * 2 + dm) * 64 + lane) * 16 + j] = (int8_t)d;
+    }
+}
+
+struct MultiState {          // per score, on the device
+    unsigned long long nloci;  // rows for which getImputedDosages returned true
+    long long const_lo, const_hi;  // whole-locus constants of this call in fixed point: (hi << 32) + lo
+    unsigned long long const_nan;  // a whole-locus constant was NaN (imp-locus fail / NaN eaf)
+    double const_sum;          // float64 sum over the calls so far
+    double pad[3];
+};
+
+__global__ __launch_bounds__(256) void multi_params_kernel(
+    const unsigned long long *__restrict__ tally /* first cohort row of this call */,
+    const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int NT, uint64_t n_samples,
+    DevParams p, const int *__restrict__ F /* [S] */, int8_t *__restrict__ table, MultiState *__restrict__ state) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (j >= n_desc) return;
+    const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
+    int used = 0, has_const = 0;
+    const bool rie = d.ref_is_effect != 0;
+    auto locus = [&]() {  // imputeLocusDosages nimpress.nim:417-447
+        if (p.imp_locus == NPS_LOCUS_IGNORE) return;
+        used = 1;
+        has_const = 1;
+        cst = (p.imp_locus == NPS_LOCUS_PS ? d.eaf * 2.0 : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0) : nan) *
+              d.beta;
+    };
+    if (d.kind == NPS_ROW_PRESENT) {
+        const unsigned long long t = tally[j];
+        const uint64_t nmiss = t >> 32, neff = t & 0xffffffffull, ngen = n_samples - nmiss;
+        const double missingrate = (double)nmiss / (double)n_samples;
+        if (missingrate > p.max_missing_rate) {  // :565-571
+            locus();
+        } else {  // :582-585 -> imputeSampleDosages :450-481
+            used = 1;
+            double imp;
+            switch (p.imp_sample) {
+            case NPS_SAMPLE_PS: imp = d.eaf * 2.0; break;
+            case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
+            case NPS_SAMPLE_FAIL: imp = nan; break;
+            default:
+                if ((double)ngen >= p.min_cs)
+                    imp = (double)neff / (double)ngen;
+                else
+                    imp = p.imp_sample == NPS_SAMPLE_INT_PS ? d.eaf * 2.0 : nan;
+                break;
+            }
+            wD = d.beta;
+            // a missing genotype has code 3: it already got 3 x beta from the dosage matrix
+            wM = imp * d.beta - 3.0 * d.beta;
+        }
+    } else if (d.kind == NPS_ROW_ABSENT) {  // :536-551
+        if (p.imp_missing == NPS_MISSING_HOMREF) {
+            used = 1;
+            has_const = 1;
+            cst = (rie ? 2.0 : 0.0) * d.beta;
+        }
+    } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
+        locus();
+    }  // else: the row is not part of this score
+    const int f = F[s];
+    const bool m_nan = wM != wM;
+    put_digits(table, NT, j, s, 0, llrint(ldexp(wD, f)), 0);
+    put_digits(table, NT, j, s, 1, m_nan ? 0ll : llrint(ldexp(wM, f)), m_nan ? 1 : 0);
+    if (used) atomicAdd(&state[s].nloci, 1ull);
+    if (has_const) {
+        if (cst != cst) {
+            atomicOr(&state[s].const_nan, 1ull);
+        } else {
+            const long long V = llrint(ldexp(cst, f));  // exact, order-independent sums of both halves
+            atomicAdd((unsigned long long *)&state[s].const_lo, (unsigned long long)(V & 0xffffffffll));
+            atomicAdd((unsigned long long *)&state[s].const_hi, (unsigned long long)(V >> 32));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The product.  Workgroup = 16 waves; wave v owns GW groups of 32 samples; the workgroup walks the
+// superblocks of its row chunk: per superblock one 16 B load per lane and group (1 KiB per wave
+// instruction, contiguous) and the superblock's digit tables (NT x 8 KiB) staged through LDS, double
+// buffered, one barrier per superblock.  Per word: 16 2-bit codes -> 16 int8 codes (dosage matrix) and
+// 16 0/1 bytes (is-missing matrix), 6 VALU ops per four genotypes, then NT x 2 MFMAs.
+template <int NT>
+struct __attribute__((aligned(16))) MultiLds {
+    uint4 tab[2][4 * NT * 2 * 64];
+};
+
+static __device__ __forceinline__ void expand_word(uint32_t w, v4i &D, v4i &M) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t = (w >> (8 * q)) & 0xFFu;
+        const uint32_t x1 = t | (t << 12);
+        const uint32_t sel = (x1 | (x1 << 6)) & 0x03030303u;  // byte b = code of row 4q + b
+        D[q] = (int)sel;
+        M[q] = (int)((sel >> 1) & sel & 0x01010101u);       // 1 where the code is 3 (missing)
+    }
+}
+
+template <int NT, int GW>
+__global__ __launch_bounds__(1024) void multi_mfma_kernel(const uint4 *__restrict__ units, uint64_t n_groups,
+                                                          uint64_t sb_first, uint32_t n_sb, uint32_t sb_per_chunk,
+                                                          const uint4 *__restrict__ table,
+                                                          int32_t *__restrict__ partial) {
+    constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock
+    __shared__ MultiLds<NT> lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t sb_a = chunk * sb_per_chunk, sb_b = min(n_sb, sb_a + sb_per_chunk);
+    const uint64_t g0 = ((uint64_t)blockIdx.x * 16 + wave) * GW;
+
+    v16i acc[GW][NT];
+#pragma unroll
+    for (int a = 0; a < GW; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0;
+
+    auto load_units = [&](uint32_t sb, uint4 (&dst)[GW]) {
+#pragma unroll
+        for (int a = 0; a < GW; ++a) {
+            dst[a] = make_uint4(0, 0, 0, 0);
+            if (sb < sb_b && g0 + a < n_groups) dst[a] = units[((sb_first + sb) * n_groups + g0 + a) * 64 + lane];
+        }
+    };
+    auto load_table = [&](uint32_t sb, uint4 (&dst)[(kTab + 1023) / 1024]) {
+#pragma unroll
+        for (int i = 0; i < (kTab + 1023) / 1024; ++i) {
+            const int e = i * 1024 + tid;
+            dst[i] = make_uint4(0, 0, 0, 0);
+            if (sb < sb_b && e < kTab) dst[i] = table[(uint64_t)sb * kTab + e];
+        }
+    };
+    auto store_table = [&](int buf, const uint4 (&src)[(kTab + 1023) / 1024]) {
+#pragma unroll
+        for (int i = 0; i < (kTab + 1023) / 1024; ++i) {
+            const int e = i * 1024 + tid;
+            if (e < kTab) lds.tab[buf][e] = src[i];
+        }
+    };
+
+    uint4 cur[GW], nxt[GW];
+    uint4 treg[(kTab + 1023) / 1024];
+    load_table(sb_a, treg);
+    load_units(sb_a, cur);
+    store_table(0, treg);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t sb = sb_a; sb < sb_b; ++sb, buf ^= 1) {
+        load_table(sb + 1, treg);  // in flight during the MFMAs below
+        load_units(sb + 1, nxt);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            v4i D[GW], M[GW];
+#pragma unroll
+            for (int a = 0; a < GW; ++a) {
+                const uint32_t word = w == 0 ? cur[a].x : w == 1 ? cur[a].y : w == 2 ? cur[a].z : cur[a].w;
+                expand_word(word, D[a], M[a]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint4 bd = lds.tab[buf][((w * NT + t) * 2 + 0) * 64 + lane];
+                const uint4 bm = lds.tab[buf][((w * NT + t) * 2 + 1) * 64 + lane];
+                const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
+                const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+                for (int a = 0; a < GW; ++a) {
+                    acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
+                    acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+                }
+            }
+        }
+        store_table(buf ^ 1, treg);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < GW; ++a) cur[a] = nxt[a];
+    }
+    // C/D map of the 32x32 MFMA shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < GW; ++a) {
+        if (g0 + a >= n_groups) continue;
+        int32_t *dst = partial + (((uint64_t)chunk * n_groups + g0 + a) * 32) * (NT * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int samp = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                dst[(uint64_t)samp * (NT * 32) + 32 * t + (lane & 31)] = acc[a][t][r];
+            }
+    }
+}
+
+// per (sample, score): the digit sums of all row chunks -> float64, added to the running sums
+__global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restrict__ partial, uint32_t n_chunks,
+                                                         uint64_t n_groups, uint64_t n_samples, int S, int NT,
+                                                         const int *__restrict__ F, double *__restrict__ part,
+                                                         int overwrite, MultiState *__restrict__ state) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i == 0) {  // this call's whole-locus constants -> the float64 running constant of the score
+        MultiState &st = state[s];
+        const double c = ldexp((double)st.const_hi * 4294967296.0 + (double)st.const_lo, -F[s]);
+        st.const_sum = (overwrite ? 0.0 : st.const_sum) + (st.const_nan ? __longlong_as_double(0x7ff8000000000000ll) : c);
+        st.const_lo = st.const_hi = 0;
+        st.const_nan = 0;
+    }
+    if (i >= n_samples) return;
+    const uint64_t g = i >> 5, si = i & 31;
+    long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const int32_t *src = partial + (((uint64_t)c * n_groups + g) * 32 + si) * (NT * 32) + 8 * s;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] += src[k];
+    }
+    double v = (double)sum[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) v = v * 128.0 + (double)sum[k];
+    v = ldexp(v, -F[s]);
+    if (sum[7] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
+    double *dst = part + (uint64_t)s * n_samples + i;
+    *dst = overwrite ? v : *dst + v;
+}
+
+// nimpress.nim:643-649 per score: (sum + constants) / (2 nloci) + offset
+__global__ __launch_bounds__(256) void multi_finish_kernel(const double *__restrict__ part, uint64_t n_samples, int S,
+                                                           const MultiState *__restrict__ state,
+                                                           const double *__restrict__ offsets, int have_sums,
+                                                           double *__restrict__ scores) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= n_samples) return;
+    double v = have_sums ? part[(uint64_t)s * n_samples + i] : 0.0;
+    v += state[s].const_sum;
+    v /= (double)state[s].nloci * 2.0;
+    v += offsets[s];
+    scores[(uint64_t)s * n_samples + i] = v;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
+                               uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
+                               void *d_table, void *d_state) {
+    if (n_desc == 0 || S == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)((n_desc + 255) / 256), (uint32_t)S), dim3(256), 0, st,
+                       d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (int8_t *)d_table, (MultiState *)d_state);
+    return hipGetLastError();
+}
+
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
+    MultiPlan pl;
+    pl.NT = (8 * S + 31) / 32;
+    pl.GW = 2;
+    pl.n_groups = (n_samples + 31) / 32;
+    pl.n_sb = (uint32_t)((n_rows + 127) / 128);
+    pl.tiles = (uint32_t)((pl.n_groups + 16 * pl.GW - 1) / (16 * pl.GW));
+    // enough workgroups to fill the chip a few times over, every chunk at least 8 superblocks long
+    uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 4 + pl.tiles - 1) / pl.tiles);
+    q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 8));
+    q = std::min<uint32_t>(q, 64);
+    pl.sb_per_chunk = (pl.n_sb + q - 1) / q;
+    pl.n_chunks = pl.sb_per_chunk ? (pl.n_sb + pl.sb_per_chunk - 1) / pl.sb_per_chunk : 0;
+    return pl;
+}
+
+hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
+                             const void *d_table, int32_t *d_partial) {
+    if (pl.n_sb == 0 || pl.n_groups == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const dim3 grid(pl.tiles, pl.n_chunks), block(1024);
+    if (pl.NT == 1)
+        hipLaunchKernelGGL((multi_mfma_kernel<1, 2>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups, sb_first,
+                           pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial);
+    else if (pl.NT == 2)
+        hipLaunchKernelGGL((multi_mfma_kernel<2, 2>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups, sb_first,
+                           pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
+                             const int *d_F, double *d_part, int overwrite, void *d_state) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_fold_kernel, dim3((uint32_t)std::max<uint64_t>(1, (n_samples + 255) / 256), (uint32_t)S),
+                       dim3(256), 0, st, d_partial, pl.n_chunks, pl.n_groups, n_samples, S, pl.NT, d_F, d_part, overwrite,
+                       (MultiState *)d_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,
+                               const double *d_offsets, int have_sums, double *d_scores) {
+    if (n_samples == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_finish_kernel, dim3((uint32_t)((n_samples + 255) / 256), (uint32_t)S), dim3(256), 0, st,
+                       d_part, n_samples, S, (const MultiState *)d_state, d_offsets, have_sums, d_scores);
+    return hipGetLastError();
+}
+
+size_t multi_state_bytes() { return sizeof(MultiState); }
+
+}  // namespace nps
