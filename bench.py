@@ -523,6 +523,7 @@ def main():
             if world > 1:
                 # the one exchange of the score-sharded layout: samples x scores matrix over RCCL
                 step.matrix = multi.gather_scores(d_scores.view(1, n), world)
+                torch.cuda.current_stream().synchronize()  # d_scores is rewritten by the next step
         step.seg += seg
         return nl
 

@@ -99,10 +99,10 @@ struct nps_ctx {
     nps_locus_stat *d_stats = nullptr;      // [batch_cap]
     nps_locus_stat *h_stats = nullptr;      // pinned [batch_cap]
     int32_t *d_raw = nullptr;               // raw FORMAT staging for one row (n*2 int32)
-    static constexpr int kRawSlots = 2;
-    int32_t *h_raw[kRawSlots] = {nullptr, nullptr};  // pinned staging ring for caller buffers
+    static constexpr int kRawSlots = 8;  // rows in flight between the caller's buffer and the device
+    int32_t *h_raw[kRawSlots] = {};  // pinned staging ring for caller buffers
     void *h_arena = nullptr;  // ONE pinned allocation holding h_desc, h_stats and h_raw[]
-    hipEvent_t ev_raw[kRawSlots] = {nullptr, nullptr};
+    hipEvent_t ev_raw[kRawSlots] = {};
     int raw_next = 0;
 
     // FORMAT/DS streaming batch (allocated on the first nps_push_ds)

@@ -196,7 +196,9 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
     return hipGetLastError();
 }
 
-// one contiguous packed row (nps_push_packed staging): tally + scatter into the interleaved batch
+// one contiguous packed row (nps_push_packed staging): tally + scatter into the interleaved batch.
+// grid = chunks of 2048 words; every block adds its part with one 64-bit atomic (`tally` is zero before
+// the first row of a batch slot is pushed, as for the decode kernel)
 __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *__restrict__ row,
                                                                 uint32_t n_words,
                                                                 uint32_t *__restrict__ out_group,
@@ -204,22 +206,29 @@ __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *
                                                                 unsigned long long *__restrict__ tally) {
     __shared__ uint32_t red[4 * 3];
     uint32_t cw = 0, cm = 0, cz = 0;
-    for (uint32_t c = threadIdx.x; c < n_words; c += 256) {
-        const uint32_t w = word_to_planes(row[c]);  // the staging row is in the C-ABI's bit order
-        tally_word(w, cw, cm);
-        out_group[(uint64_t)c * 4 + row_in_group] = w;
+    const uint32_t c0 = blockIdx.x * 2048u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t c = c0 + u * 256 + threadIdx.x;
+        if (c < n_words) {
+            const uint32_t w = word_to_planes(row[c]);  // the staging row is in the C-ABI's bit order
+            tally_word(w, cw, cm);
+            out_group[(uint64_t)c * 4 + row_in_group] = w;
+        }
     }
     group_sum3<4>(cw, cm, cz, red, threadIdx.x);
-    if (threadIdx.x == 0) *tally = ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm);
+    if (threadIdx.x == 0 && (cw | cm))
+        atomicAdd(tally, ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm));
 }
 
 hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
                                     uint32_t *d_group, int row_in_group,
                                     unsigned long long *d_tally) {
     const uint64_t n_words = words_for(n_samples);
+    if (n_words == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(tally_scatter_row_kernel, dim3(1), dim3(256), 0, st, d_row, (uint32_t)n_words,
-                       d_group, row_in_group, d_tally);
+    hipLaunchKernelGGL(tally_scatter_row_kernel, dim3((uint32_t)((n_words + 2047) / 2048)), dim3(256), 0, st, d_row,
+                       (uint32_t)n_words, d_group, row_in_group, d_tally);
     return hipGetLastError();
 }
 

@@ -300,12 +300,20 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
 // ------------------------------------------------------------------------------------------
 // The product.  Workgroup = 16 waves; wave v owns GW groups of 32 samples; the workgroup walks the
 // superblocks of its row chunk: per superblock one 16 B load per lane and group (1 KiB per wave
-// instruction, contiguous) and the superblock's digit tables (NT x 8 KiB) staged through LDS, double
-// buffered, one barrier per superblock.  Per word: 16 2-bit codes -> 16 int8 codes (dosage matrix) and
-// 16 0/1 bytes (is-missing matrix), 6 VALU ops per four genotypes, then NT x 2 MFMAs.
+// instruction, contiguous, prefetched one superblock ahead in registers) and the superblock's digit
+// tables (NT x 8 KiB) staged through LDS.  Per word: 16 2-bit codes -> 16 int8 codes (dosage matrix)
+// and 16 0/1 bytes (is-missing matrix), 6 VALU ops per four genotypes, then NT x 2 MFMAs per group.
+//
+// The vector work (expansion) of one wave overlaps the matrix work of the other three waves of its SIMD
+// only while the waves are out of step; a workgroup barrier puts them back in step.  With one barrier per
+// superblock (4 words) the two pipes took turns: 51.5 ms per pass = matrix time (29 ms) + vector time
+// (22 ms).  So the tables are staged kStage superblocks at a time (two LDS buffers of kStage x NT x 8 KiB)
+// and the workgroup meets once per stage.
+constexpr int kStage = 4;  // superblocks per barrier
+
 template <int NT>
 struct __attribute__((aligned(16))) MultiLds {
-    uint4 tab[2][4 * NT * 2 * 64];
+    uint4 tab[2][kStage][4 * NT * 2 * 64];
 };
 
 static __device__ __forceinline__ void expand_word(uint32_t w, v4i &D, v4i &M) {
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(1024) void multi_mfma_kernel(const uint4 *__restric
                                                           const uint4 *__restrict__ table,
                                                           int32_t *__restrict__ partial) {
     constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock
+    constexpr int kTregs = (kTab + 1023) / 1024;
     __shared__ MultiLds<NT> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t chunk = blockIdx.y;
@@ -346,57 +355,65 @@ __global__ __launch_bounds__(1024) void multi_mfma_kernel(const uint4 *__restric
             if (sb < sb_b && g0 + a < n_groups) dst[a] = units[((sb_first + sb) * n_groups + g0 + a) * 64 + lane];
         }
     };
-    auto load_table = [&](uint32_t sb, uint4 (&dst)[(kTab + 1023) / 1024]) {
+    auto load_table = [&](uint32_t sb, uint4 (&dst)[kTregs]) {
 #pragma unroll
-        for (int i = 0; i < (kTab + 1023) / 1024; ++i) {
+        for (int i = 0; i < kTregs; ++i) {
             const int e = i * 1024 + tid;
             dst[i] = make_uint4(0, 0, 0, 0);
             if (sb < sb_b && e < kTab) dst[i] = table[(uint64_t)sb * kTab + e];
         }
     };
-    auto store_table = [&](int buf, const uint4 (&src)[(kTab + 1023) / 1024]) {
+    auto store_table = [&](int buf, int slot, const uint4 (&src)[kTregs]) {
 #pragma unroll
-        for (int i = 0; i < (kTab + 1023) / 1024; ++i) {
+        for (int i = 0; i < kTregs; ++i) {
             const int e = i * 1024 + tid;
-            if (e < kTab) lds.tab[buf][e] = src[i];
+            if (e < kTab) lds.tab[buf][slot][e] = src[i];
         }
     };
 
     uint4 cur[GW], nxt[GW];
-    uint4 treg[(kTab + 1023) / 1024];
-    load_table(sb_a, treg);
+    uint4 treg[kTregs];
+    // first stage of tables
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+        load_table(sb_a + k, treg);
+        store_table(0, k, treg);
+    }
     load_units(sb_a, cur);
-    store_table(0, treg);
     __syncthreads();
     int buf = 0;
-    for (uint32_t sb = sb_a; sb < sb_b; ++sb, buf ^= 1) {
-        load_table(sb + 1, treg);  // in flight during the MFMAs below
-        load_units(sb + 1, nxt);
+    for (uint32_t s0 = sb_a; s0 < sb_b; s0 += kStage, buf ^= 1) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            v4i D[GW], M[GW];
+        for (int k = 0; k < kStage; ++k) {
+            const uint32_t sb = s0 + k;
+            load_table(sb + kStage, treg);  // the same slot of the next stage; in flight during the MFMAs below
+            load_units(sb + 1, nxt);
 #pragma unroll
-            for (int a = 0; a < GW; ++a) {
-                const uint32_t word = w == 0 ? cur[a].x : w == 1 ? cur[a].y : w == 2 ? cur[a].z : cur[a].w;
-                expand_word(word, D[a], M[a]);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4 bd = lds.tab[buf][((w * NT + t) * 2 + 0) * 64 + lane];
-                const uint4 bm = lds.tab[buf][((w * NT + t) * 2 + 1) * 64 + lane];
-                const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
-                const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+            for (int w = 0; w < 4; ++w) {
+                v4i D[GW], M[GW];
 #pragma unroll
                 for (int a = 0; a < GW; ++a) {
-                    acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
-                    acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+                    const uint32_t word = w == 0 ? cur[a].x : w == 1 ? cur[a].y : w == 2 ? cur[a].z : cur[a].w;
+                    expand_word(word, D[a], M[a]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const uint4 bd = lds.tab[buf][k][((w * NT + t) * 2 + 0) * 64 + lane];
+                    const uint4 bm = lds.tab[buf][k][((w * NT + t) * 2 + 1) * 64 + lane];
+                    const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
+                    const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+                    for (int a = 0; a < GW; ++a) {
+                        acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
+                        acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+                    }
                 }
             }
-        }
-        store_table(buf ^ 1, treg);
-        __syncthreads();
+            store_table(buf ^ 1, k, treg);
 #pragma unroll
-        for (int a = 0; a < GW; ++a) cur[a] = nxt[a];
+            for (int a = 0; a < GW; ++a) cur[a] = nxt[a];
+        }
+        __syncthreads();
     }
     // C/D map of the 32x32 MFMA shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -477,9 +494,10 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
     pl.n_groups = (n_samples + 31) / 32;
     pl.n_sb = (uint32_t)((n_rows + 127) / 128);
     pl.tiles = (uint32_t)((pl.n_groups + 16 * pl.GW - 1) / (16 * pl.GW));
-    // enough workgroups to fill the chip a few times over, every chunk at least 8 superblocks long
-    uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 4 + pl.tiles - 1) / pl.tiles);
-    q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 8));
+    // one workgroup per CU at a time: enough of them (~12 rounds) that the last, partly filled round costs
+    // little, every chunk at least 16 superblocks long
+    uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
+    q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 16));
     q = std::min<uint32_t>(q, 64);
     pl.sb_per_chunk = (pl.n_sb + q - 1) / q;
     pl.n_chunks = pl.sb_per_chunk ? (pl.n_sb + pl.sb_per_chunk - 1) / pl.sb_per_chunk : 0;
