@@ -499,6 +499,8 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
     uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
     q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 16));
     q = std::min<uint32_t>(q, 64);
+    // int32 digit sums: |sum| <= rows x 3 x 64 per chunk, so at most 2^31 / 192 rows = 87 381 superblocks
+    q = std::max<uint32_t>(q, (pl.n_sb + 87380) / 87381);
     pl.sb_per_chunk = (pl.n_sb + q - 1) / q;
     pl.n_chunks = pl.sb_per_chunk ? (pl.n_sb + pl.sb_per_chunk - 1) / pl.sb_per_chunk : 0;
     return pl;
