@@ -929,6 +929,15 @@ static void fetchRange(const IndexedSource &src, const ScoreEntry *first, size_t
     std::vector<unsigned char> buf;
     std::vector<int32_t> tmp;
     std::string line;
+    // Where the scan of an index chunk stopped for the previous score row, so that a score file with many
+    // loci in one 16 kb bin does not inflate and parse the bin from its start for every row: the scan of
+    // chunk `beg` may resume at `at` if no record before `at` can overlap the new row, i.e. the row starts
+    // beyond the end of every record passed so far (`max_end`, 1-based inclusive).
+    struct Resume {
+        uint64_t at;
+        int64_t max_end;
+    };
+    std::unordered_map<uint64_t, Resume> resume;
     for (size_t i = 0; i < count; ++i) {
         const ScoreEntry &e = first[i];
         if (src.is_bcf) {
@@ -936,18 +945,30 @@ static void fetchRange(const IndexedSource &src, const ScoreEntry *first, size_t
             if (ci == src.bcf_contig.end()) continue;
             for (const auto &chunk : src.csi.query(ci->second, e.pos - 1, e.stop())) {
                 uint64_t v = chunk.first;
+                int64_t max_end = 0;
+                auto rs = resume.find(chunk.first);
+                if (rs != resume.end() && e.pos > rs->second.max_end) {
+                    v = rs->second.at;
+                    max_end = rs->second.max_end;
+                }
                 while (v < chunk.second) {
                     const uint64_t at = v;
                     uint32_t ls[2];
                     if (!bg.readBytes(&v, ls, 8)) break;
                     buf.resize((size_t)ls[0] + ls[1]);
                     if (!bg.readBytes(&v, buf.data(), buf.size())) throw std::runtime_error("truncated BCF record");
-                    if (found.count(at) || ls[0] < 24) continue;
-                    int32_t chrom, pos0;
+                    if (ls[0] < 24) continue;
+                    int32_t chrom, pos0, rlen;
                     memcpy(&chrom, buf.data(), 4);
                     memcpy(&pos0, buf.data() + 4, 4);
+                    memcpy(&rlen, buf.data() + 8, 4);
                     if ((size_t)chrom != ci->second) continue;
-                    if ((int64_t)pos0 + 1 > e.stop()) break;  // position sorted inside a contig
+                    if ((int64_t)pos0 + 1 > e.stop()) {  // position sorted inside a contig
+                        resume[chunk.first] = Resume{at, max_end};
+                        break;
+                    }
+                    max_end = std::max(max_end, (int64_t)pos0 + std::max(rlen, 1));
+                    if (found.count(at)) continue;
                     Variant var;
                     if (parseBcfRecord(buf.data(), ls[0], buf.data() + ls[0], ls[1], src.bcf, &wanted, var))
                         found.emplace(at, std::move(var));
@@ -956,18 +977,33 @@ static void fetchRange(const IndexedSource &src, const ScoreEntry *first, size_t
         } else {
             for (const auto &chunk : src.tbi.query(e.contig, e.pos - 1, e.stop())) {
                 uint64_t v = chunk.first;
+                int64_t max_end = 0;
+                auto rs = resume.find(chunk.first);
+                if (rs != resume.end() && e.pos > rs->second.max_end) {
+                    v = rs->second.at;
+                    max_end = rs->second.max_end;
+                }
                 while (v < chunk.second) {
                     const uint64_t at = v;
                     if (!bg.readLine(&v, line)) break;
                     if (line.empty() || line[0] == '#') continue;
-                    if (found.count(at)) continue;
                     // cheap pre-check of CHROM and POS before the full parse
                     const size_t t1 = line.find('\t');
                     const size_t t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1);
                     if (t2 == std::string::npos) continue;
                     if (line.compare(0, t1, e.contig) != 0) continue;
                     const int64_t pos = parseIntNim(line.substr(t1 + 1, t2 - t1 - 1));
-                    if (pos > e.stop()) break;  // records are position sorted inside a contig
+                    if (pos > e.stop()) {  // records are position sorted inside a contig
+                        resume[chunk.first] = Resume{at, max_end};
+                        break;
+                    }
+                    {  // end of the record: POS + len(REF) - 1 (REF is the fourth column)
+                        const size_t t3 = line.find('\t', t2 + 1);
+                        const size_t t4 = t3 == std::string::npos ? t3 : line.find('\t', t3 + 1);
+                        const int64_t reflen = t4 == std::string::npos ? 1 : (int64_t)(t4 - t3 - 1);
+                        max_end = std::max(max_end, pos + std::max<int64_t>(reflen, 1) - 1);
+                    }
+                    if (found.count(at)) continue;
                     Variant var;
                     if (parseRecordLine(line.data(), line.size(), src.n_samples, &wanted, tmp, var))
                         found.emplace(at, std::move(var));

@@ -479,6 +479,72 @@ def test_bcf_random_access_multi_block(host, tmp_path):
         assert results[0][1][-1] == other[1][-1] == (False,)
 
 
+@pytest.mark.parametrize("kind", ["bcf", "vcf.gz"])
+def test_indexed_fetch_dense_bin_resumes_correctly(host, tmp_path, kind):
+    """Many score rows inside ONE 16 kb index bin, in file order that goes back and forth, next to a record
+    whose long REF allele spans the following loci: the indexed fetch resumes its scan of the bin where the
+    previous row stopped only when no earlier record can overlap the new row; results == whole-file scan,
+    with one fetching thread (everything in one resume map) and several."""
+    import bcfwriter
+    rng = np.random.default_rng(5)
+    n = 50
+    samples = ["Q%d" % i for i in range(n)]
+    recs, vlines = [], []
+    pos_list = list(range(16400, 16400 + 60 * 37, 37))          # 60 loci inside bin [16384, 32768)
+    for j, pos in enumerate(pos_list):
+        ref = "A" * 120 if j == 10 else ("AC" if j % 7 == 3 else "A")   # j == 10 spans the next three loci
+        g = ((rng.integers(0, 2, size=(n, 2)) + 1) << 1)
+        recs.append(dict(contig="1", pos=pos, id=".", ref=ref, alts=["G"], filters=[], gts=g))
+        gts = "\t".join("%d/%d" % ((a >> 1) - 1, (b >> 1) - 1) for a, b in g)
+        vlines.append(("1", pos, ref, "1\t%d\t.\t%s\tG\t.\tPASS\t.\tGT\t%s" % (pos, ref, gts)))
+    if kind == "bcf":
+        path = str(tmp_path / "dense.bcf")
+        bcfwriter.write_bcf(path, ["1"], samples, recs, gt_dtype=np.int8)
+    else:
+        path = str(tmp_path / "dense.vcf.gz")
+        header = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)]
+        write_bgzf_vcf_with_tbi(path, header, vlines)
+    order = list(rng.permutation(len(recs)))
+    lines = ["t", "", "", "x", "0.0"]
+    for k in order:
+        r = recs[k]
+        lines.append("1\t%d\t%s\tG\t0.1\t0.2" % (r["pos"], r["ref"]))
+    # rows that only the long record overlaps: REF differs there, so findVariant must walk past it
+    lines.append("1\t%d\tA\tG\t0.1\t0.2" % (pos_list[11]))
+    lines.append("1\t%d\tC\tG\t0.1\t0.2" % (pos_list[10] + 50))
+    score_path = str(tmp_path / "s.score")
+    open(score_path, "w").write("\n".join(lines))
+    results = []
+    for no_index, window, threads in ((True, 0, None), (False, 0, "1"), (False, 0, "4"), (False, 5, "1"), (False, 5, "3")):
+        if no_index:
+            os.environ["NIMPRESS_NO_INDEX"] = "1"
+        if threads:
+            os.environ["NIMPRESS_THREADS"] = threads
+        try:
+            h = (host.nh_vcf_open_streaming(path.encode(), score_path.encode(), window) if window
+                 else host.nh_vcf_open(path.encode(), score_path.encode()))
+            assert h, host.nh_last_error()
+            got = []
+            gts = np.zeros(2 * n, np.int32)
+            for ln in lines[5:]:
+                c, pos, ref, ea, _, _ = ln.split("\t")
+                rp, pl = C.c_long(), C.c_int()
+                idx = host.nh_vcf_find(h, c.encode(), int(pos), ref.encode(), ea.encode(), C.byref(rp),
+                                       C.byref(pl), None, 0, gts.ctypes.data, 2 * n)
+                got.append((idx >= 0, rp.value if idx >= 0 else -1, gts.copy() if idx >= 0 else None))
+            results.append(got)
+            host.nh_vcf_close(h)
+        finally:
+            os.environ.pop("NIMPRESS_NO_INDEX", None)
+            os.environ.pop("NIMPRESS_THREADS", None)
+    assert sum(1 for a in results[0] if a[0]) >= len(recs)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert a[0] == b[0] and a[1] == b[1]
+            if a[0]:
+                assert np.array_equal(a[2], b[2])
+
+
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
 def test_ingest_under_sanitizers(tmp_path, san):
     """the host ingest (BGZF inflate, tabix / CSI random access, BCF decode, the per-contig record index,
