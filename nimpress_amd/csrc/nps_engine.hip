@@ -126,8 +126,12 @@ struct nps_ctx {
     double *d_rds_psum = nullptr;  // fused DS kernel: per (row, slice) partial dosage sums
     uint64_t psum_cap = 0;
 
-    int32_t *d_poly = nullptr;  // raw GT staging for ploidy > 2
+    // raw GT staging for ploidy > 2: device buffer + a ring of two pinned host buffers (grown on demand)
+    int32_t *d_poly = nullptr;
     size_t poly_cap = 0;
+    void *h_poly[2] = {nullptr, nullptr};
+    hipEvent_t ev_poly[2] = {nullptr, nullptr};
+    int poly_next = 0;
 
     // accumulators
     AccumGeom geom{};         // streaming geometry (groups_per_chunk for a full batch)
@@ -285,6 +289,10 @@ static void free_ctx(nps_ctx *c) {
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
     (void)hipFree(c->d_ds);
     (void)hipFree(c->d_poly);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipHostFree(c->h_poly[k]);
+        if (c->ev_poly[k]) (void)hipEventDestroy(c->ev_poly[k]);
+    }
     (void)hipFree(c->d_ds_desc);
     (void)hipFree(c->d_ds_tally);
     (void)hipFree(c->d_ds_rowp);
@@ -598,16 +606,29 @@ static int push_gt_polyploid(nps_ctx *c, const void *gts, int elem_bytes, int pl
     d.ref_is_effect = (ref_is_effect ? 1 : 0) | 2;
     if (c->n) {
         const size_t bytes = (size_t)elem_bytes * (size_t)ploidy * c->n;
-        if (bytes > c->poly_cap) {
+        if (bytes > c->poly_cap) {  // the staging grows to the widest record seen (rare: once per context)
             HIP_TRY(hipStreamSynchronize(c->stream));
             (void)hipFree(c->d_poly);
             c->d_poly = nullptr;
             c->poly_cap = 0;
+            for (int k = 0; k < 2; ++k) {
+                (void)hipHostFree(c->h_poly[k]);
+                c->h_poly[k] = nullptr;
+                if (!c->ev_poly[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_poly[k], hipEventDisableTiming));
+            }
             HIP_TRY(hipMalloc(&c->d_poly, bytes));
+            HIP_TRY(hipHostMalloc(&c->h_poly[0], bytes));
+            HIP_TRY(hipHostMalloc(&c->h_poly[1], bytes));
             c->poly_cap = bytes;
         }
-        HIP_TRY(hipMemcpyAsync(c->d_poly, gts, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // pageable source: the caller may reuse it on return
+        // as for diploid rows: the caller may reuse `gts` on return, so it is copied into a pinned ring
+        // slot first; no stream synchronisation per row
+        const int k = c->poly_next;
+        c->poly_next ^= 1;
+        HIP_TRY(hipEventSynchronize(c->ev_poly[k]));
+        memcpy(c->h_poly[k], gts, bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_poly, c->h_poly[k], bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_poly[k], c->stream));
         ProfScope ps(c, P_DECODE);
         HIP_TRY(launch_decode_gt_to_ds(c->stream, c->d_poly, elem_bytes, c->n, ploidy, eaidx,
                                        c->d_ds + (uint64_t)slot * c->ds_stride_f));

@@ -9,6 +9,7 @@ ap.add_argument("--samples", type=int, default=500_000)
 ap.add_argument("--variants", type=int, default=1_000_000)
 ap.add_argument("--scores", type=int, default=8)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--zero", action="store_true", help="all genotypes 0 (clock / power experiment)")
 a = ap.parse_args()
 import torch
 from nimpress_amd import capi
@@ -16,6 +17,8 @@ import bench
 n, m, S, seed = a.samples, a.variants, a.scores, 20250103
 _, eaf, miss = bench.synth_score(m, seed)
 th, tm, tmi = bench.hwe_thresholds(eaf, miss)
+if a.zero:
+    th[:] = 0; tm[:] = 0; tmi[:] = 0
 t0 = time.perf_counter()
 co = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
 for x in range(0, m, 1 << 15):
