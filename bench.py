@@ -60,8 +60,8 @@ def parse_args():
                     help="skip the secondary measurements (config 5 DS pass, streaming entry points, "
                          "config 2 end to end)")
     ap.add_argument("--no-optimize", action="store_true",
-                    help="skip nps_cohort_optimize (the row of each group of 4 with the most dosage-2 / "
-                         "missing codes in the bank-selecting slot)")
+                    help="skip nps_cohort_optimize (the parity layout of the high-bit planes: the table lookups "
+                         "spread over twice as many LDS banks)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20250103)
     return ap.parse_args()
@@ -606,8 +606,8 @@ def main():
                        "persistent_grid": {"slices": geometry[0], "teams": geometry[1],
                                            "samples_per_slice": geometry[2]},
                        "cohort_layout": "plain" if (args.no_optimize or is_ds) else
-                                        "nps_cohort_optimize (one-time, untimed: per group of 4 rows the row "
-                                        "with the most dosage-2/missing codes in the bank-selecting slot)",
+                                        "nps_cohort_optimize (one-time, untimed, data independent: parity layout of "
+                                        "the high-bit planes, table lookups over twice as many LDS banks)",
                        "mode": args.mode, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -237,12 +237,12 @@ int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const ui
                           size_t row_stride_bytes, const uint8_t *effect_is_a1);
 /* Fill rows on the device with the counter-based synthetic generator (DESIGN.md "Synthetic
  * cohorts"): per-row uint32 thresholds, code(seed,row,sample) reproducible on the CPU. */
-/* One-time layout optimisation of a resident 2-bit cohort (no-op for NPS_FMT_DS32): inside every group
- * of four rows the row with the most dosage-2 / missing codes moves to the slot whose high code bit
- * selects the LDS bank of the accumulation tables (fewer bank conflicts: 4.5 % of a pass on HWE
- * genotypes).  Results, statistics order and nps_cohort_download are unchanged; a later upload / synth
- * puts the cohort back into plain order first.  While optimised, a scored range must end on a
- * multiple of 4 rows or at the end of the cohort (NPS_E_UNSUPPORTED otherwise). */
+/* One-time layout change of a resident 2-bit cohort (no-op for the other formats): inside every group of
+ * four rows the high-bit plane of the first row is replaced by the XOR of the four rows' planes, which
+ * spreads the accumulation kernels' table lookups over twice as many LDS banks (~14 % fewer LDS
+ * cycles per lookup on HWE genotypes, independent of which rows are frequent).  Results, statistics and
+ * nps_cohort_download are unchanged; a later upload / synth puts the cohort back into the plain layout
+ * first.  The transform is its own inverse. */
 int nps_cohort_optimize(nps_cohort *c);
 int nps_cohort_synth(nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t seed,
                      const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss);

@@ -264,8 +264,8 @@ class Cohort:
         return nm[:nrows], ne[:nrows]
 
     def optimize(self):
-        """one-time layout optimisation (nps_cohort_optimize): the row of every group of 4 with the most
-        dosage-2 / missing codes moves to the slot that selects the LDS bank; results unchanged"""
+        """one-time layout change (nps_cohort_optimize): parity layout of the high-bit planes, fewer LDS bank
+        conflicts in the accumulation kernels; results unchanged, its own inverse"""
         _check(load().nps_cohort_optimize(self._h))
 
     def close(self):

@@ -56,20 +56,12 @@ struct nps_cohort {
     uint64_t n_samples = 0, n_rows = 0;
     uint64_t stride_bytes = 0;  // per row (GT2: rows are interleaved in groups of 4, a group is 4*stride_bytes)
     void *d_data = nullptr;
-    // nps_cohort_optimize (GT2): per group the logical row (0..3) that sits in slot 0 (and logical row 0
-    // in that slot); host copy for downloads and for putting per-row results back in row order
+    // nps_cohort_optimize (GT2): the rows are in the parity layout (nps_kernels.h: the high-bit plane of
+    // slot 0 of every group holds the XOR of the four rows' planes)
     bool optimized = false;
-    uint8_t *d_swap = nullptr;
-    std::vector<uint8_t> h_swap;
     // NPS_FMT_GT2M: whole-row tallies (nmissing << 32 | neffect) produced by whatever packed the rows
     unsigned long long *d_row_tally = nullptr;
 };
-
-// slot <-> logical row inside a group (the exchange of slot 0 and slot j is its own inverse)
-static inline uint64_t swapped_row(uint64_t row, uint8_t j) {
-    const uint64_t s = row & 3;
-    return (row & ~3ull) + (s == 0 ? j : (s == j ? 0 : s));
-}
 
 struct PendingRow {
     int32_t batch_idx;  // >= 0: index into the open GT / DS batch's device stats; -1: host stat
@@ -78,9 +70,6 @@ struct PendingRow {
 };
 
 struct nps_ctx {
-    nps_row_desc *d_desc_perm = nullptr;  // row descriptors in slot order (optimized cohorts)
-    uint64_t desc_perm_cap = 0;
-    std::vector<uint8_t> res_swap;        // swap bytes of the range scored last (empty: not optimized)
     int device = 0;
     hipStream_t stream = nullptr;
     uint64_t n = 0;         // samples
@@ -304,7 +293,6 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_rds_rowp);
     (void)hipFree(c->d_rds_psum);
     (void)hipFree(c->d_part_fused);
-    (void)hipFree(c->d_desc_perm);
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
@@ -972,20 +960,17 @@ extern "C" void nps_cohort_destroy(nps_cohort *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_data);
-    (void)hipFree(c->d_swap);
     (void)hipFree(c->d_row_tally);
     delete c;
 }
 
-// back to plain row order (before rows are written into an optimized cohort)
+// back to the plain layout (before rows are written into an optimised cohort); the transform is its own inverse
 static int cohort_unoptimize(nps_cohort *c) {
     if (!c->optimized) return NPS_OK;
-    hipError_t e = launch_cohort_swap(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
-                                      c->n_rows, c->d_swap);
+    hipError_t e = launch_cohort_parity(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples, c->n_rows);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(NPS_E_HIP, "cohort re-ordering failed: %s", hipGetErrorString(e));
     c->optimized = false;
-    c->h_swap.clear();
     return NPS_OK;
 }
 
@@ -993,16 +978,9 @@ extern "C" int nps_cohort_optimize(nps_cohort *c) {
     if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
     if (c->format != NPS_FMT_GT2 || c->optimized || c->n_rows == 0 || c->n_samples == 0) return NPS_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows moved here
-    const uint64_t n_groups = (c->n_rows + 3) / 4;
-    uint32_t *d_counts = nullptr;
-    if (!c->d_swap) HIP_TRY(hipMalloc(&c->d_swap, n_groups));
-    HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * 4 * n_groups));
-    hipError_t e = launch_cohort_optimize(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples,
-                                          c->n_rows, d_counts, c->d_swap);
-    c->h_swap.assign(n_groups, 0);
-    if (e == hipSuccess) e = hipMemcpy(c->h_swap.data(), c->d_swap, n_groups, hipMemcpyDeviceToHost);
-    (void)hipFree(d_counts);
+    HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows rewritten here
+    hipError_t e = launch_cohort_parity(nullptr, (uint32_t *)c->d_data, c->stride_bytes / 4, c->n_samples, c->n_rows);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(NPS_E_HIP, "cohort optimisation failed: %s", hipGetErrorString(e));
     c->optimized = true;
     return NPS_OK;
@@ -1029,13 +1007,17 @@ static int gt2_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void
         const uint64_t groups = (k + 3) / 4;
         char *dev = (char *)c->d_data + ((row0 + r) >> 2) * sw * 16;
         buf.assign(groups * sw * 4, 0u);
-        if (!to_device)
+        if (!to_device) {
             HIP_TRY(hipMemcpy(buf.data(), dev, groups * sw * 16, hipMemcpyDeviceToHost));
+            if (c->optimized)  // parity layout -> plain, on the copy
+                for (uint64_t x = 0; x < groups * sw; ++x) {
+                    uint32_t *q = buf.data() + x * 4;
+                    q[0] = parity_fix(q[0], q[1], q[2], q[3]);
+                }
+        }
         for (uint64_t j = 0; j < k; ++j) {
             uint32_t *hrow = (uint32_t *)((char *)host_rows + (r + j) * host_stride);
-            // slot of logical row row0 + r + j inside its group
-            const uint64_t slot = c->optimized ? swapped_row(j, c->h_swap[(row0 + r + j) >> 2]) : j;
-            uint32_t *g = buf.data() + (slot >> 2) * sw * 4 + (slot & 3);
+            uint32_t *g = buf.data() + (j >> 2) * sw * 4 + (j & 3);
             if (to_device)
                 for (uint64_t w = 0; w < n_words; ++w) g[w * 4] = word_to_planes(hrow[w]);
             else
@@ -1278,11 +1260,8 @@ static int materialize_resident_stats(nps_ctx *c) {
             c->ready.push_back(c->res_host_stats[h++]);
             continue;
         }
-        uint64_t at = (uint64_t)c->res_index[j];  // logical row; the kernels wrote slot order
-        if (!c->res_swap.empty()) at = swapped_row(at, c->res_swap[at >> 2]);
-        c->ready.push_back(dev[(size_t)at]);
+        c->ready.push_back(dev[(size_t)c->res_index[j]]);
     }
-    c->res_swap.clear();
     c->res_pending = false;
     c->res_index.clear();
     c->res_host_stats.clear();
@@ -1344,9 +1323,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     const bool is_ds = co->format == NPS_FMT_DS32;
     if (!is_ds && (cohort_row0 & 3))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
-    if (!is_ds && co->optimized && ((cohort_row0 + m) & 3) && cohort_row0 + m != co->n_rows)
-        return fail(NPS_E_UNSUPPORTED, "an optimised cohort is scored in whole groups of 4 rows: "
-                    "cohort_row0 + rows must be a multiple of 4 or the end of the cohort");
     HIP_TRY(hipSetDevice(c->device));
     FusedPlan plan;
     if (mode != NPS_MODE_TWOPASS && m && c->n) {
@@ -1386,10 +1362,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         c->res_index = def->data_index;
         c->res_m = m;
         c->res_pending = true;
-        c->res_swap.clear();
-        if (m && !is_ds && co->optimized)
-            c->res_swap.assign(co->h_swap.begin() + (long)(cohort_row0 >> 2),
-                               co->h_swap.begin() + (long)((cohort_row0 + m + 3) >> 2));
     };
     if (m == 0) {
         commit();
@@ -1418,9 +1390,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             rc = grow(c, (void **)&c->d_rds_psum, &c->psum_cap, m * plan.P, sizeof(double));
             if (rc) return rc;
         }
-    } else if (co->optimized) {
-        rc = grow(c, (void **)&c->d_desc_perm, &c->desc_perm_cap, m_pad, sizeof(nps_row_desc));
-        if (rc) return rc;
     }
 
     // ---- launches.  From here on an error leaves queued work behind: the context is marked broken.
@@ -1513,14 +1482,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     const uint64_t stride_words = co->stride_bytes / 4;
     const uint32_t *codes = (const uint32_t *)co->d_data + (cohort_row0 >> 2) * stride_words * 4;
     const nps_row_desc *d_desc = def->d_desc;
-    if (co->optimized) {
-        // rows of a group have changed places: the row descriptors go into slot order and the per-row
-        // results come back through the same exchange
-        ProfScope ps(c, P_PARAMS);
-        HIP_TRY(launch_permute_desc(c->stream, def->d_desc, c->d_desc_perm,
-                                    co->d_swap + (cohort_row0 >> 2), m));
-        d_desc = c->d_desc_perm;
-    }
+    const int parity = co->optimized ? 1 : 0;  // the kernels undo the parity layout for the tally
     if (fused) {
         rc = tally_ready();
         if (rc) return rc;
@@ -1529,7 +1491,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             ProfScope ps(c, P_FUSED);
             fe = launch_fused(c->stream, plan, codes, stride_words, c->n, m, d_desc,
                               dev_params(c->params), c->d_rtally, c->d_rstats, c->d_nloci,
-                              c->d_part_fused, c->d_timeout);
+                              c->d_part_fused, c->d_timeout, parity);
         }
         if (fe == hipSuccess) {
             guard.armed = true;
@@ -1570,7 +1532,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         {
             ProfScope ps(c, P_TALLY);
             HIP_TRY(launch_tally_packed(c->stream, codes + (r0 >> 2) * stride_words * 4, stride_words,
-                                        c->n, k, c->d_rtally + r0));
+                                        c->n, k, c->d_rtally + r0, parity));
         }
         {
             ProfScope ps(c, P_PARAMS);
@@ -1584,7 +1546,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             g.groups_per_chunk = std::max(1u, (groups + g.n_chunks - 1) / g.n_chunks);
             ProfScope ps(c, P_ACCUM);
             HIP_TRY(launch_accumulate(c->stream, codes + (r0 >> 2) * stride_words * 4, stride_words, k,
-                                      c->d_rlut + r0 * 4, g, c->d_part));
+                                      c->d_rlut + r0 * 4, g, c->d_part, parity));
         }
     }
     return done();
@@ -1615,7 +1577,7 @@ extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     if (dst->device != src->device || dst->n_samples != src->n_samples || dst->n_rows != src->n_rows)
         return fail(NPS_E_INVAL, "source and destination differ in device, samples or rows");
     if (src->optimized)
-        return fail(NPS_E_STATE, "the source cohort is in nps_cohort_optimize order; convert it before optimising");
+        return fail(NPS_E_STATE, "the source cohort is in the nps_cohort_optimize layout; convert it before optimising");
     HIP_TRY(hipSetDevice(dst->device));
     HIP_TRY(hipDeviceSynchronize());
     if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;

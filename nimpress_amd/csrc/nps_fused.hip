@@ -71,15 +71,8 @@ static __device__ __forceinline__ uint32_t tally_pack(uint32_t w) {
     return (t << 16) | m;
 }
 
-// Table index of a sample in a group of 4 rows with codes c0..c3: the four LOW code bits in the low
-// nibble, the four HIGH code bits in the high nibble.  Codes 0/1 (hom-ref, het) dominate real
-// genotypes, so the low nibble carries most of the entropy and lands in the LDS bank-select bits:
-// 2.6 LDS cycles per 32-lane lookup on HWE genotypes against 3.3 for the naive c0|c1<<2|c2<<4|c3<<6,
-// with no extra VALU work (this kernel is VALU-issue bound: every instruction counts).
-static __host__ __device__ __forceinline__ int table_index(int c0, int c1, int c2, int c3) {
-    return (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c3 & 1) << 3) | ((c0 >> 1) << 4) |
-           ((c1 >> 1) << 5) | ((c2 >> 1) << 6) | ((c3 >> 1) << 7);
-}
+// (table_index() -- which code bit lands in which LDS bank-select bit -- lives in nps_kernels.h: the four
+// LOW code bits in the low nibble, the high code bits, or their parity, above them.)
 
 // (a & m) | (b & ~m) as ONE instruction.  Written as asm because hipcc (ROCm 7.2) otherwise breaks
 // the three merge stages below into separate v_and / v_bitop3 ops (~70 instead of 24 per group), and
@@ -177,7 +170,8 @@ struct __attribute__((aligned(16))) FusedCwLds {
     uint32_t tslot[2][4][WAVES][64];
 };
 
-template <int T, int DBG>  // DBG: diagnostics build (bit 0 re-read rows 0..15, bit 1 skip accumulation)
+template <int T, int DBG, int PAR>  // DBG: diagnostics build (bit 0 re-read rows 0..15, bit 1 skip accumulation);
+                                    // PAR: the cohort is in the parity layout (nps_cohort_optimize)
 __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
     static_assert(T % 64 == 0 && T >= 128 && T <= 1024, "workgroup size");
     constexpr int TD = T - 64;  // data threads
@@ -293,7 +287,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
             for (int c1 = 0; c1 < 4; ++c1)
 #pragma unroll
                 for (int c0 = 0; c0 < 4; ++c0) {
-                    tab[table_index(c0, c1, c2, c3)] = ((l0[c0] + l1[c1]) + l2) + l3;
+                    tab[table_index(c0, c1, c2, c3, PAR)] = ((l0[c0] + l1[c1]) + l2) + l3;
                 }
         };
 
@@ -385,8 +379,10 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint32_t tp[4];
+            // (parity layout: the stored high-bit plane of slot 0 is the XOR of the four rows' planes)
+            tp[0] = tally_pack(PAR ? parity_fix(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]) : src[4 * g]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tp[r] = tally_pack(src[4 * g + r]);
+            for (int r = 1; r < 4; ++r) tp[r] = tally_pack(src[4 * g + r]);
             tally_reduce4(k & 1, g, tp);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -409,7 +405,9 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
                 double v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = Tg[(x[q] >> (8 * kk)) & 0xFFu];
-                tp[kk] = tally_pack(tal[4 * g + kk]);  // VALU work while the lookups are in flight
+                // VALU work while the lookups are in flight
+                tp[kk] = tally_pack(PAR && kk == 0 ? parity_fix(tal[4 * g], tal[4 * g + 1], tal[4 * g + 2], tal[4 * g + 3])
+                                                   : tal[4 * g + kk]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * kk + q] += v[q];
                 // Pin the four adds here.  Without the opaque use hipcc (ROCm 7.2) sinks the
@@ -483,7 +481,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ pa
 template <int T>
 static hipError_t plan_for(int cus, uint64_t n_words, uint64_t n_batches, int max_q, FusedPlan *plan) {
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T, 0>, T, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_cw_kernel<T, 0, 0>, T, 0);
     if (e != hipSuccess) return e;
     // the kernel needs 128 VGPRs: 16 waves per CU; never ask for more than that many workgroups
     per_cu = std::min(per_cu, T >= 768 ? 1 : 1024 / T);
@@ -544,11 +542,22 @@ hipError_t fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_
     return hipSuccess;
 }
 
+template <int PAR>
+static const void *fused_entry(int threads) {
+    return threads == 256   ? (const void *)fused_cw_kernel<256, 0, PAR>
+           : threads == 512 ? (const void *)fused_cw_kernel<512, 0, PAR>
+           : threads == 768 ? (const void *)fused_cw_kernel<768, 0, PAR>
+           : threads == 832 ? (const void *)fused_cw_kernel<832, 0, PAR>
+           : threads == 896 ? (const void *)fused_cw_kernel<896, 0, PAR>
+           : threads == 960 ? (const void *)fused_cw_kernel<960, 0, PAR>
+                            : (const void *)fused_cw_kernel<1024, 0, PAR>;
+}
+
 hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d_codes,
                         uint64_t stride_words, uint64_t n_samples, uint64_t n_rows,
                         const nps_row_desc *d_desc, DevParams prm, unsigned long long *d_tally,
                         nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
-                        unsigned int *d_timeout) {
+                        unsigned int *d_timeout, int parity) {
     FusedArgs a;
     a.codes = d_codes;
     a.stride_words = stride_words;
@@ -568,21 +577,15 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
     a.timeout = d_timeout;
     a.telemetry = reinterpret_cast<unsigned long long *>(d_timeout) + 2;  // same 256-byte block
     void *args[] = {&a};
-    const void *fn = plan.threads == 256   ? (const void *)fused_cw_kernel<256, 0>
-                     : plan.threads == 512 ? (const void *)fused_cw_kernel<512, 0>
-                     : plan.threads == 768 ? (const void *)fused_cw_kernel<768, 0>
-                     : plan.threads == 832 ? (const void *)fused_cw_kernel<832, 0>
-                     : plan.threads == 896 ? (const void *)fused_cw_kernel<896, 0>
-                     : plan.threads == 960 ? (const void *)fused_cw_kernel<960, 0>
-                                           : (const void *)fused_cw_kernel<1024, 0>;
+    const void *fn = parity ? fused_entry<1>(plan.threads) : fused_entry<0>(plan.threads);
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_DEBUG_FLAGS bit 0 = every batch
-    // re-reads rows 0..15 (L2 hits), bit 1 = skip the accumulation; instantiated for T = 1024 only
+    // re-reads rows 0..15 (L2 hits), bit 1 = skip the accumulation; instantiated for T = 1024, plain layout
     const int dbg = getenv("NPS_DEBUG_FLAGS") ? atoi(getenv("NPS_DEBUG_FLAGS")) & 3 : 0;
-    if (dbg && plan.threads == 1024)
-        fn = dbg == 1   ? (const void *)fused_cw_kernel<1024, 1>
-             : dbg == 2 ? (const void *)fused_cw_kernel<1024, 2>
-                        : (const void *)fused_cw_kernel<1024, 3>;
+    if (dbg && plan.threads == 1024 && !parity)
+        fn = dbg == 1   ? (const void *)fused_cw_kernel<1024, 1, 0>
+             : dbg == 2 ? (const void *)fused_cw_kernel<1024, 2, 0>
+                        : (const void *)fused_cw_kernel<1024, 3, 0>;
 #endif
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);

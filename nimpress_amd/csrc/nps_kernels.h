@@ -66,7 +66,8 @@ hipError_t launch_decode_gt(hipStream_t st, const void *d_gts, int elem_bytes, u
 // tally of rows [0,n_rows) of a group-interleaved matrix (d_codes = first group):
 // tally[row] = (nmiss<<32)|neff   (direct store)
 hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
-                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally);
+                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally,
+                               int parity = 0);
 
 // a plain (contiguous) packed row: tally it and scatter it into row `row_in_group` of a group
 hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
@@ -80,16 +81,29 @@ hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_
                                   uint64_t stride_words);
 hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1);
 
-// nps_cohort_optimize (nps_kernels.hip): per group, the row with the most dosage-2 / missing codes goes
-// to slot 0.  d_counts: [4 * groups] scratch; d_swap: [groups], logical row now in slot 0.
-// launch_cohort_swap applies (or, applied again, undoes) a given d_swap; launch_permute_desc puts the
-// row descriptors of a scored range into slot order.
-hipError_t launch_cohort_optimize(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
-                                  uint64_t n_samples, uint64_t n_rows, uint32_t *d_counts, uint8_t *d_swap);
-hipError_t launch_cohort_swap(hipStream_t st, uint32_t *d_codes, uint64_t stride_words, uint64_t n_samples,
-                              uint64_t n_rows, const uint8_t *d_swap);
-hipError_t launch_permute_desc(hipStream_t st, const nps_row_desc *d_src, nps_row_desc *d_dst,
-                               const uint8_t *d_swap, uint64_t m);
+// nps_cohort_optimize (nps_kernels.hip): the "parity layout".  The table index of the accumulation kernels
+// puts the four LOW code bits and index bit 4 into the five LDS bank-select bits; the other three bits
+// choose among the eight entries of a bank, and a lookup costs one LDS cycle per different entry of the
+// busiest bank.  In the plain layout bit 4 is the HIGH code bit of slot 0, so every lane whose slot 1..3
+// carries a dosage-2 / missing code shares its bank with the (many) lanes that have the same low bits and
+// no high bit at all.  In the parity layout the high-bit plane of slot 0 holds the XOR of the four rows'
+// high bits instead: lanes with exactly one high bit set -- the common case after "none" -- go to the
+// other sixteen banks.  Bank model on HWE genotypes: 2.06 LDS cycles per 32-lane lookup against 2.69 plain
+// (2.32 for round 1's "most frequent row in slot 0").  The transform is its own inverse and independent of
+// the data; the kernels undo it for the tally (two VALU ops per group of 4 words) and build their tables
+// for the index as it comes.
+static __host__ __device__ inline uint32_t parity_fix(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return w0 ^ ((w1 ^ w2 ^ w3) & 0xF0F0F0F0u);
+}
+// table address of a sample whose four rows have codes c0..c3 (bit 0 low, bit 1 high code bit)
+static __host__ __device__ inline int table_index(int c0, int c1, int c2, int c3, int parity) {
+    const int h0 = parity ? ((c0 ^ c1 ^ c2 ^ c3) >> 1) & 1 : (c0 >> 1);
+    return (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c3 & 1) << 3) | (h0 << 4) | ((c1 >> 1) << 5) |
+           ((c2 >> 1) << 6) | ((c3 >> 1) << 7);
+}
+// in place, all groups of a resident 2-bit cohort; applied again it restores the plain layout
+hipError_t launch_cohort_parity(hipStream_t st, uint32_t *d_codes, uint64_t stride_words, uint64_t n_samples,
+                                uint64_t n_rows);
 
 // per-row decision + LUT {0b,1b,2b,imp*b} (or the locus constant); rows [n_rows, n_rows_pad) get a
 // zero LUT.  Adds the number of used rows to *d_nloci.
@@ -107,7 +121,7 @@ struct AccumGeom {
 };
 hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
                              uint64_t n_rows, const double *d_lut, const AccumGeom &g,
-                             double *d_part);
+                             double *d_part, int parity = 0);
 
 // scores[i] = (sum_chunks part[c][i] + const_sum) / (2 * nloci) + offset      nimpress.nim:643-649
 // nloci = host_nloci + *d_nloci (d_nloci may be null), read on the device so that no host round
@@ -141,7 +155,7 @@ hipError_t launch_fused(hipStream_t st, const FusedPlan &plan, const uint32_t *d
                         uint64_t stride_words, uint64_t n_samples, uint64_t n_rows,
                         const nps_row_desc *d_desc, DevParams prm, unsigned long long *d_tally,
                         nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
-                        unsigned int *d_timeout);
+                        unsigned int *d_timeout, int parity = 0);
 // Epilogue of a fused pass, one launch: part0[i] (+)= sum_q part[q][i] (overwrite != 0: part0 holds
 // nothing yet and is written, not read); the n_tally tally words are zeroed again for the next pass;
 // a raised bounded-wait word is ORed into *d_status and cleared.

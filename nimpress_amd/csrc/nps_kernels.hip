@@ -153,7 +153,7 @@ static __device__ __forceinline__ void tally_word(uint32_t w, uint32_t &cw, uint
 __global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__restrict__ codes,
                                                            uint64_t stride_words, uint32_t n_words,
                                                            uint64_t n_rows,
-                                                           unsigned long long *__restrict__ tally) {
+                                                           unsigned long long *__restrict__ tally, int parity) {
     __shared__ uint32_t red[4 * 3];
     const uint64_t grp = blockIdx.x;
     const uint32_t c0 = blockIdx.y * 1024u;
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__res
     for (int u = 0; u < 4; ++u) {
         const uint32_t c = c0 + u * 256 + threadIdx.x;
         if (c < n_words) {
-            const uint4 q = p[c];  // the same 16 samples of the group's four rows
+            uint4 q = p[c];  // the same 16 samples of the group's four rows
+            if (parity) q.x = parity_fix(q.x, q.y, q.z, q.w);
             tally_word(q.x, cw[0], cm[0]);
             tally_word(q.y, cw[1], cm[1]);
             tally_word(q.z, cw[2], cm[2]);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void tally_packed_kernel(const uint32_t *__res
 }
 
 hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
-                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally) {
+                               uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally, int parity) {
     if (n_rows == 0) return hipSuccess;
     const uint64_t n_words = words_for(n_samples);
     const uint64_t n_groups = (n_rows + 3) / 4;
@@ -192,7 +193,7 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
     if (e != hipSuccess) return e;
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(tally_packed_kernel, dim3((uint32_t)n_groups, (uint32_t)chunks), dim3(256), 0,
-                       st, d_codes, stride_words, (uint32_t)n_words, n_rows, d_tally);
+                       st, d_codes, stride_words, (uint32_t)n_words, n_rows, d_tally, parity);
     return hipGetLastError();
 }
 
@@ -306,133 +307,28 @@ hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_sam
 }
 
 // ------------------------------------------------------------------------------------------
-// nps_cohort_optimize: which row of a group sits in slot 0.  The table index of the accumulation
-// kernels puts the HIGH code bit of slot 0 into the LDS bank-select bits (table_index(), bit 4), next
-// to the four low code bits; the other three high bits select among the eight entries of a bank.  The
-// more often that bit is set, the fewer different entries of one bank a wave asks for at once:
-// measured on HWE genotypes, 2.3 instead of 2.6 LDS cycles per 32-lane lookup (3.1 with the rarest
-// variant in slot 0), 4.5 % of the whole pass.  So the row of every group with the most dosage-2 /
-// missing codes is swapped into slot 0, once, when the cohort is resident; swap[g] = the logical row
-// (0..3) now in slot 0 (and logical row 0 in slot swap[g]).
-__global__ __launch_bounds__(256) void hplane_count_kernel(const uint32_t *__restrict__ codes,
-                                                           uint64_t stride_words, uint32_t n_words,
-                                                           uint32_t *__restrict__ counts) {
-    __shared__ uint32_t red[4 * 3];
-    const uint64_t grp = blockIdx.x;
-    const uint32_t c0 = blockIdx.y * 1024u;
-    uint32_t ch[4] = {0, 0, 0, 0};
-    const uint4 *p = reinterpret_cast<const uint4 *>(codes) + grp * stride_words;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t c = c0 + u * 256 + threadIdx.x;
-        if (c < n_words) {
-            const uint4 q = p[c];
-            ch[0] += __popc(q.x & 0xF0F0F0F0u);
-            ch[1] += __popc(q.y & 0xF0F0F0F0u);
-            ch[2] += __popc(q.z & 0xF0F0F0F0u);
-            ch[3] += __popc(q.w & 0xF0F0F0F0u);
-        }
-    }
-    uint32_t a = ch[0], b = ch[1], c = ch[2];
-    group_sum3<4>(a, b, c, red, threadIdx.x);
-    __syncthreads();
-    uint32_t d = ch[3], z0 = 0, z1 = 0;
-    group_sum3<4>(d, z0, z1, red, threadIdx.x);
-    if (threadIdx.x == 0) {
-        if (a) atomicAdd(&counts[grp * 4 + 0], a);
-        if (b) atomicAdd(&counts[grp * 4 + 1], b);
-        if (c) atomicAdd(&counts[grp * 4 + 2], c);
-        if (d) atomicAdd(&counts[grp * 4 + 3], d);
-    }
-}
-
-// the row whose high code bit is closest to being set in half of the samples (the most informative
-// bank-select bit; for effect-allele frequencies below 0.7 simply the row with the most such codes)
-__global__ __launch_bounds__(256) void choose_swap_kernel(const uint32_t *__restrict__ counts,
-                                                          uint64_t n_groups, uint64_t n_samples,
-                                                          uint8_t *__restrict__ swap) {
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_groups) return;
-    const long long half = (long long)(n_samples / 2);
-    long long best = llabs((long long)counts[g * 4] - half);
-    uint8_t j = 0;
-    for (uint8_t r = 1; r < 4; ++r) {
-        const long long d = llabs((long long)counts[g * 4 + r] - half);
-        if (d < best) {  // ties keep the lower row: all-zero padding rows never win
-            best = d;
-            j = r;
-        }
-    }
-    swap[g] = j;
-}
-
-// exchange slot 0 and slot swap[g] of every group (an involution: applying it again undoes it)
-__global__ __launch_bounds__(256) void swap_rows_kernel(uint32_t *__restrict__ codes, uint64_t stride_words,
-                                                        uint32_t n_words, const uint8_t *__restrict__ swap) {
+// nps_cohort_optimize: the parity layout (nps_kernels.h).  In place; its own inverse.
+__global__ __launch_bounds__(256) void cohort_parity_kernel(uint32_t *__restrict__ codes, uint64_t stride_words,
+                                                            uint32_t n_words) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     const uint64_t g = blockIdx.y;
-    const uint32_t j = swap[g];
-    if (j == 0 || c >= n_words) return;
+    if (c >= n_words) return;
     uint4 *p = reinterpret_cast<uint4 *>(codes) + g * stride_words + c;
     uint4 q = *p;
-    uint32_t t = q.x;
-    if (j == 1) { q.x = q.y; q.y = t; }
-    else if (j == 2) { q.x = q.z; q.z = t; }
-    else { q.x = q.w; q.w = t; }
+    q.x = parity_fix(q.x, q.y, q.z, q.w);
     *p = q;
 }
 
-// dst[slot] = src[logical row in that slot] for rows [0, m) of a scored range starting at a group
-// boundary (swap points at that group)
-__global__ __launch_bounds__(256) void permute_desc_kernel(const nps_row_desc *__restrict__ src,
-                                                           nps_row_desc *__restrict__ dst,
-                                                           const uint8_t *__restrict__ swap, uint64_t m) {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= m) return;
-    const uint32_t s = (uint32_t)(p & 3), j = swap[p >> 2];
-    const uint32_t ls = s == 0 ? j : (s == j ? 0 : s);
-    dst[p] = src[(p & ~3ull) + ls];
-}
-
-hipError_t launch_cohort_optimize(hipStream_t st, uint32_t *d_codes, uint64_t stride_words,
-                                  uint64_t n_samples, uint64_t n_rows, uint32_t *d_counts, uint8_t *d_swap) {
-    const uint64_t n_words = words_for(n_samples), n_groups = (n_rows + 3) / 4;
-    if (n_groups == 0 || n_words == 0) return hipSuccess;
-    const uint64_t chunks = (n_words + 1023) / 1024;
-    hipError_t e = hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * 4 * n_groups, st);
-    if (e != hipSuccess) return e;
-    (void)hipGetLastError();
-    for (uint64_t g0 = 0; g0 < n_groups; g0 += 65535 * 16) {  // grid.x is wide enough; keep launches modest
-        const uint64_t k = std::min<uint64_t>(65535ull * 16, n_groups - g0);
-        hipLaunchKernelGGL(hplane_count_kernel, dim3((uint32_t)k, (uint32_t)chunks), dim3(256), 0, st,
-                           d_codes + g0 * stride_words * 4, stride_words, (uint32_t)n_words, d_counts + g0 * 4);
-    }
-    hipLaunchKernelGGL(choose_swap_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, st, d_counts,
-                       n_groups, n_samples, d_swap);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_cohort_swap(st, d_codes, stride_words, n_samples, n_rows, d_swap);
-}
-
-hipError_t launch_cohort_swap(hipStream_t st, uint32_t *d_codes, uint64_t stride_words, uint64_t n_samples,
-                              uint64_t n_rows, const uint8_t *d_swap) {
+hipError_t launch_cohort_parity(hipStream_t st, uint32_t *d_codes, uint64_t stride_words, uint64_t n_samples,
+                                uint64_t n_rows) {
     const uint64_t n_words = words_for(n_samples), n_groups = (n_rows + 3) / 4;
     if (n_groups == 0 || n_words == 0) return hipSuccess;
     (void)hipGetLastError();
     for (uint64_t g0 = 0; g0 < n_groups; g0 += 65535) {
         const uint64_t k = std::min<uint64_t>(65535, n_groups - g0);
-        hipLaunchKernelGGL(swap_rows_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)k), dim3(256), 0,
-                           st, d_codes + g0 * stride_words * 4, stride_words, (uint32_t)n_words, d_swap + g0);
+        hipLaunchKernelGGL(cohort_parity_kernel, dim3((uint32_t)((n_words + 255) / 256), (uint32_t)k), dim3(256), 0,
+                           st, d_codes + g0 * stride_words * 4, stride_words, (uint32_t)n_words);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_permute_desc(hipStream_t st, const nps_row_desc *d_src, nps_row_desc *d_dst,
-                               const uint8_t *d_swap, uint64_t m) {
-    if (m == 0) return hipSuccess;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(permute_desc_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, d_src, d_dst,
-                       d_swap, m);
     return hipGetLastError();
 }
 
@@ -540,7 +436,7 @@ constexpr int kGps = 4;  // row groups per stage (16 rows)
 __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
     const uint32_t *__restrict__ codes, uint64_t stride_words, uint64_t n_rows, uint32_t n_words,
     const double *__restrict__ lut, uint32_t n_groups, uint32_t groups_per_chunk,
-    double *__restrict__ part, uint64_t part_chunk_stride) {
+    double *__restrict__ part, uint64_t part_chunk_stride, int parity) {
     __shared__ double T[2][kGps][256];  // 16 KiB
     const int tid = threadIdx.x;
     const uint32_t col = blockIdx.x * kAccThreads + tid;
@@ -575,8 +471,11 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
             if (gg < (int)ng) {
                 // entry tid: code of row r = bit r | bit 4+r << 1, summed in row order
                 const double *l = lut + (uint64_t)(g0 + gg) * 16;
-                const int c0 = (tid & 1) | ((tid >> 3) & 2), c1 = ((tid >> 1) & 1) | ((tid >> 4) & 2);
+                const int c1 = ((tid >> 1) & 1) | ((tid >> 4) & 2);
                 const int c2 = ((tid >> 2) & 1) | ((tid >> 5) & 2), c3 = ((tid >> 3) & 1) | ((tid >> 6) & 2);
+                // bit 4 of the address: the high code bit of slot 0, or (parity layout) the XOR of all four
+                const int h0 = parity ? ((tid >> 4) ^ (tid >> 5) ^ (tid >> 6) ^ (tid >> 7)) & 1 : (tid >> 4) & 1;
+                const int c0 = (tid & 1) | (h0 << 1);
                 T[buf][gg][tid] = ((l[c0] + l[4 + c1]) + l[8 + c2]) + l[12 + c3];
             }
         }
@@ -608,7 +507,7 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
 
 hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t stride_words,
                              uint64_t n_rows, const double *d_lut, const AccumGeom &g,
-                             double *d_part) {
+                             double *d_part, int parity) {
     if (n_rows == 0 || g.n_words == 0) return hipSuccess;
     const uint32_t n_groups = (uint32_t)((n_rows + 3) / 4);
     const uint32_t tiles = (g.n_words + kAccThreads - 1) / kAccThreads;
@@ -617,7 +516,7 @@ hipError_t launch_accumulate(hipStream_t st, const uint32_t *d_codes, uint64_t s
     (void)hipGetLastError();  // drop any stale sticky error: report this launch only
     hipLaunchKernelGGL(accumulate_kernel, dim3(tiles, g.n_chunks), dim3(kAccThreads), 0, st, d_codes,
                        stride_words, n_rows, g.n_words, d_lut, n_groups, g.groups_per_chunk, d_part,
-                       g.part_chunk_stride);
+                       g.part_chunk_stride, parity);
     return hipGetLastError();
 }
 
