@@ -387,13 +387,22 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
 def streaming_rates(capi, device, n, seed):
     """The drop-in entry points (what the command line uses): one call per score row with a HOST buffer, so
     these rates include the pinned copy + PCIe transfer + decode launch per row.  Never `value`."""
-    from oracle import refcpu  # only to build input rows (bcf_get_genotypes buffers); nothing is checked here
     rng = np.random.default_rng(seed)
     nd = 8
     eaf = np.round(rng.uniform(0.05, 0.5, nd), 4)
-    th, tm, tmi = hwe_thresholds(eaf, np.full(nd, 0.01))
-    codes = refcpu.synth_rows(n, 0, nd, seed, th, tm, tmi)
-    gt32 = [refcpu.codes_to_gt(codes[j], n) for j in range(nd)]
+    # input rows made here with numpy (the oracle is the checker, never an input generator of a measurement):
+    # NPS_CODE_* per sample -> packed words (sample i in bits 2i, 2i+1) and bcf_get_genotypes pairs
+    u = rng.uniform(size=(nd, n))
+    code = np.where(u < 0.01, 2, np.where(u < 0.01 + eaf[:, None] ** 2, 3,
+                    np.where(u < 0.01 + eaf[:, None] ** 2 + 2 * eaf[:, None] * (1 - eaf[:, None]), 1, 0))).astype(np.uint32)
+    pad = (-n) % 16
+    cp = np.pad(code, ((0, 0), (0, pad))).reshape(nd, -1, 16)
+    codes = np.zeros(cp.shape[:2], dtype=np.uint32)
+    for k in range(16):
+        codes |= cp[:, :, k] << np.uint32(2 * k)
+    a0 = np.array([2, 2, 0, 4], dtype=np.int32)[code]      # 0/0, 0/1, ./., 1/1 in the (allele+1)<<1 encoding
+    a1 = np.array([2, 4, 0, 4], dtype=np.int32)[code]
+    gt32 = [np.ascontiguousarray(np.stack([a0[j], a1[j]], axis=1).reshape(-1)) for j in range(nd)]
     gt8 = [g.astype(np.int8) for g in gt32]
     out = {}
     for name, rows, nbytes, push in (

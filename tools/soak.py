@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""dev tool: soak test of the fused kernels -- many passes over a resident cohort, every pass must give
-bit-identical scores and nloci (no float atomics, fixed combine order) and no bounded wait may expire.
+"""dev tool: soak test of the fused kernels -- many passes over a resident cohort, alternating between TWO
+score definitions (so that a value handed over too early -- a stale partial sum, a stale tally word of the
+previous pass -- is a different number, not the same bits again); every pass must give bit-identical
+scores and nloci for its definition (no float atomics, fixed combine order), no bounded wait may expire,
+and the fused result is compared with the two-pass kernels at the start.  Build with -DNPS_DIAGNOSTICS
+(tools/mkexp.sh) to have the DS kernel's partial sums poisoned with NaNs before every launch as well.
     python tools/soak.py [--format ds] [--samples N] [--variants M] [--passes K]"""
 import argparse
 import os
@@ -29,23 +33,35 @@ for r0 in range(0, m, 1 << 15):
     r1 = min(m, r0 + (1 << 15))
     co.synth(r0, 7, th[r0:r1], tm[r0:r1], tmi[r0:r1])
 co.optimize()
-beta = np.round(np.random.default_rng(8).normal(0, 0.02, m), 4)
-sdef = capi.ScoreDef(capi.row_descs(beta, eaf))
-sc = capi.Scorer(n, capi.make_params())
+params = capi.make_params(imp_locus="ps") if is_ds else capi.make_params()
+defs, refs = [], []
+for j in range(2):
+    beta = np.round(np.random.default_rng(8 + j).normal(0, 0.02 * (1 + j), m), 4)
+    eaf_j = eaf if j == 0 else np.round(np.clip(eaf * 1.5, 0.0, 1.0), 4)
+    defs.append(capi.ScoreDef(capi.row_descs(beta, eaf_j)))
+sc = capi.Scorer(n, params)
 d = torch.empty(n, dtype=torch.float64, device="cuda")
-ref = None
 t0 = time.time()
-for k in range(a.passes):
+for j in range(2):   # reference per definition: the two-pass kernels
     sc.reset()
-    sc.score_cohort_def(co, sdef, 0, capi.MODE_FUSED)
+    sc.score_cohort_def(co, defs[j], 0, capi.MODE_TWOPASS)
+    nl = sc.finish_device(0.0, d.data_ptr())
+    refs.append([d.clone(), nl, None])
+for k in range(a.passes):
+    j = k & 1
+    sc.reset()
+    sc.score_cohort_def(co, defs[j], 0, capi.MODE_FUSED)
     nloci = sc.finish_device(0.0, d.data_ptr())     # raises on NPS_E_TIMEOUT
     cur = d.clone()
-    if ref is None:
-        ref, ref_nloci = cur, nloci
+    twopass, ref_nloci, first = refs[j]
+    assert nloci == ref_nloci, (k, nloci, ref_nloci)
+    if first is None:
+        refs[j][2] = cur
+        scale = float(twopass.abs().max().item()) + 1e-300
+        assert float((cur - twopass).abs().max().item()) <= 1e-9 * scale, "fused != two-pass for definition %d" % j
     else:
-        assert nloci == ref_nloci, (k, nloci, ref_nloci)
-        assert bool(torch.equal(cur.view(torch.int64), ref.view(torch.int64))), "pass %d differs" % k
+        assert bool(torch.equal(cur.view(torch.int64), first.view(torch.int64))), "pass %d differs" % k
     if k % 200 == 0:
         print("pass %d ok (%.1f s)" % (k, time.time() - t0), flush=True)
-print("soak ok: %d passes of %s %d x %d bit-identical, nloci %d, %.1f s" % (a.passes, a.format, n, m, ref_nloci,
-                                                                          time.time() - t0))
+print("soak ok: %d passes of %s %d x %d, two definitions alternating, bit-identical per definition and equal to "
+      "the two-pass kernels, nloci %d / %d, %.1f s" % (a.passes, a.format, n, m, refs[0][1], refs[1][1], time.time() - t0))
