@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: instruction histogram of ONE batch step (between two s_barrier) of the data waves' loop of
-# fused_cw_kernel<960,0>, from the compiler's own assembly.   tools/isa_histogram.sh > profiles/rNN_isa_histogram.txt
+# fused_cw_kernel<960,0,1>, from the compiler's own assembly.   tools/isa_histogram.sh > profiles/rNN_isa_histogram.txt
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only \
@@ -8,7 +8,7 @@ T=$(mktemp -d)
 python3 - "$T/f.s" <<'PY'
 import re, sys, collections
 lines = open(sys.argv[1]).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3nps15fused_cw_kernelILi960ELi0EEEvNS_9FusedArgsE:"))
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3nps15fused_cw_kernelILi960ELi0ELi1EEEvNS_9FusedArgsE:"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 # the data loop: the innermost loop with exactly four s_barrier (ring of 4 steps)
@@ -35,7 +35,7 @@ for l in body[a + 1:b + 1]:
         continue
     hist[t.split()[0]] += 1
 valu = sum(c for k, c in hist.items() if k.startswith("v_"))
-print("# fused_cw_kernel<960,0>, one batch step of a data wave (16 rows x 16 samples per lane), hipcc -O3 gfx950")
+print("# fused_cw_kernel<960,0,1>, one batch step of a data wave (16 rows x 16 samples per lane), hipcc -O3 gfx950")
 print("# VALU %d  LDS %d  VMEM %d  SALU %d  s_waitcnt %d" % (
     valu, sum(c for k, c in hist.items() if k.startswith("ds_")),
     sum(c for k, c in hist.items() if k.startswith(("buffer_", "global_"))),
