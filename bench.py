@@ -308,8 +308,9 @@ def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=2
 def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     """SURVEY.md section 8 f2 measured: S = 8 score definitions over the same 1M rows in ONE pass over the
     cohort (nps_score_cohort_multi: int8 MFMA over the NPS_FMT_GT2M layout, row tallies from the packer),
-    against S passes of the single-score kernel.  One step = reset -> weights as base-128 digits ->
-    the product -> fold -> /(2 nloci) + offset for all S scores, result in a device buffer."""
+    against S passes of the single-score kernel.  One step = reset -> weights as base-256 digits ->
+    the product -> fold -> /(2 nloci) + offset for all S scores, result in a device buffer.  Measured with
+    full-width weights (the headline of this object) and with nps_multi_set_missing_weight_bits(32)."""
     import torch
     _, eaf, miss = synth_score(m, seed)
     th, tm, tmi = hwe_thresholds(eaf, miss)
@@ -325,37 +326,9 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     msc = capi.MultiScorer(n, capi.make_params(), S, device=device)
     d_scores = torch.empty((S, n), dtype=torch.float64, device="cuda")
     off = np.zeros(S)
-
-    def step():
-        msc.reset()
-        msc.score_cohort(co, mdef)
-        return msc.finish_device(off, d_scores.data_ptr())
-
-    nloci = step()
-    torch.cuda.synchronize()
-    msc.reset()
-    t0 = time.perf_counter()
-    prod_ms = []
-    for _ in range(steps):
-        nloci = step()
-        prod_ms.append(msc.timing())
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / steps
-    ms_params, ms_prod, ms_fold = (float(np.mean([p[k] for p in prod_ms])) for k in range(3))
-    alg = m * ((n + 15) // 16) * 4 + 40 * m * S + 8 * n * S
-    int8_ops = 2.0 * 2.0 * n * m * (32 * ((8 * S + 31) // 32))   # dosage + is-missing matrices, padded columns
-    out = {"workload": "%d score definitions x %d rows x %d samples in one pass (NPS_FMT_GT2M cohort, int8 MFMA, "
-                       "7 base-128 digits per weight), CLI-default imputation flags" % (S, m, n),
-           "scores": S, "value": S * float(n) * m / wall, "unit": "genotype-dosage accumulations/s (x scores)",
-           "ms_per_pass": wall * 1e3, "ms_per_score": wall * 1e3 / S,
-           "kernel_ms": {"weights_to_digits": ms_params, "product": ms_prod, "fold": ms_fold},
-           "hbm_bytes_per_score": alg / S, "nloci": [int(x) for x in nloci],
-           "roofline": {"bound": "mfma", "achieved": int8_ops / (ms_prod * 1e-3) / 1e12, "peak": 5000.0,
-                        "unit": "TOP/s (int8 dense)", "frac": int8_ops / (ms_prod * 1e-3) / 1e12 / 5000.0,
-                        "hbm_GBps": alg / (ms_prod * 1e-3) / 1e9, "hbm_frac": alg / (ms_prod * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    checker = None
     if not args.no_cpu_baseline:
         from oracle import refcpu
-        got = d_scores.cpu().numpy()
         nm, ne = co.row_tallies()
         rng = np.random.default_rng(seed + 11)
         rows = np.unique(np.concatenate([rng.choice(m, 300, replace=False), [0, m - 1]])).astype(np.uint64)
@@ -363,21 +336,72 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
         g, ms, neff = refcpu.tally_synth_rows(rows, n, seed, th[ri], tm[ri], tmi[ri])
         tally_ok = bool(np.array_equal(ms, nm[ri].astype(np.float64)) and np.array_equal(neff, ne[ri].astype(np.float64)))
         samples = np.unique(np.concatenate([rng.choice(n, 600, replace=False), np.arange(0, 64), np.arange(n - 64, n)])).astype(np.uint64)
-        worst_abs, worst_rel = 0.0, 0.0
+        refs = {}
         for s in (0, S - 1):
             sums, ref_nloci = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, descs[s]["beta"], eaf, 0,
                                                   float(n) - nm.astype(np.float64), nm.astype(np.float64),
                                                   ne.astype(np.float64), refcpu.make_params())
-            ref = sums / (2.0 * ref_nloci)
-            d = np.abs(got[s][samples.astype(np.int64)] - ref)
-            floor = 1e-12 * float(np.sum(np.abs(descs[s]["beta"]))) / (2.0 * ref_nloci)
-            worst_abs = max(worst_abs, float(d.max()))
-            worst_rel = max(worst_rel, float((d / np.maximum(np.abs(ref), floor)).max()))
-            tally_ok &= int(ref_nloci) == int(nloci[s])
-        out["score_delta_vs_reference"] = {"max_abs": worst_abs, "max_rel": worst_rel, "tallies_and_nloci_equal": tally_ok,
-                                           "checked": "scores 1 and %d: %d samples x all %d rows by oracle/refcpu.c "
-                                                      "(ref_score_subset); %d whole-row tallies recounted"
-                                                      % (S, samples.size, m, rows.size)}
+            refs[s] = (sums / (2.0 * ref_nloci), int(ref_nloci))
+
+        def checker(nloci):
+            got = d_scores.cpu().numpy()
+            worst_abs, worst_rel, ok = 0.0, 0.0, tally_ok
+            for s, (ref, ref_nloci) in refs.items():
+                d = np.abs(got[s][samples.astype(np.int64)] - ref)
+                floor = 1e-12 * float(np.sum(np.abs(descs[s]["beta"]))) / (2.0 * ref_nloci)
+                worst_abs = max(worst_abs, float(d.max()))
+                worst_rel = max(worst_rel, float((d / np.maximum(np.abs(ref), floor)).max()))
+                ok &= ref_nloci == int(nloci[s])
+            return {"max_abs": worst_abs, "max_rel": worst_rel, "tallies_and_nloci_equal": bool(ok),
+                    "checked": "scores 1 and %d: %d samples x all %d rows by oracle/refcpu.c (ref_score_subset); "
+                               "%d whole-row tallies recounted" % (S, samples.size, m, rows.size)}
+
+    def step():
+        msc.reset()
+        msc.score_cohort(co, mdef)
+        return msc.finish_device(off, d_scores.data_ptr())
+
+    def measure(bits):
+        msc.set_missing_weight_bits(bits)
+        nloci = step()
+        torch.cuda.synchronize()
+        msc.reset()
+        t0 = time.perf_counter()
+        prod_ms = []
+        for _ in range(steps):
+            nloci = step()
+            prod_ms.append(msc.timing())
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        ms_params, ms_prod, ms_fold = (float(np.mean([p[k] for p in prod_ms])) for k in range(3))
+        tiles = (8 * S + 31) // 32
+        # dosage matrix: every column tile; is-missing matrix: every tile, or the high-digit tile only
+        int8_ops = 2.0 * n * m * 32 * (tiles + (1 if bits == 32 and tiles == 2 else tiles))
+        r = {"ms_per_pass": wall * 1e3, "ms_per_score": wall * 1e3 / S, "value": S * float(n) * m / wall,
+             "kernel_ms": {"weights_to_digits": ms_params, "product": ms_prod, "fold": ms_fold},
+             "int8_TOPs": int8_ops / (ms_prod * 1e-3) / 1e12, "hbm_GBps": alg / (ms_prod * 1e-3) / 1e9}
+        if checker:
+            r["score_delta_vs_reference"] = checker(nloci)
+        return r, nloci
+
+    alg = m * ((n + 15) // 16) * 4 + 40 * m * S + 8 * n * S
+    full, nloci = measure(56)
+    fast, _ = measure(32)
+    out = {"workload": "%d score definitions x %d rows x %d samples in one pass (NPS_FMT_GT2M cohort, int8 MFMA, "
+                       "7 base-256 digits per weight), CLI-default imputation flags" % (S, m, n),
+           "scores": S, "value": full["value"], "unit": "genotype-dosage accumulations/s (x scores)",
+           "ms_per_pass": full["ms_per_pass"], "ms_per_score": full["ms_per_score"], "kernel_ms": full["kernel_ms"],
+           "hbm_bytes_per_score": alg / S, "nloci": [int(x) for x in nloci],
+           "roofline": {"bound": "mfma", "achieved": full["int8_TOPs"], "peak": 5000.0, "unit": "TOP/s (int8 dense)",
+                        "frac": full["int8_TOPs"] / 5000.0, "hbm_GBps": full["hbm_GBps"],
+                        "hbm_frac": full["hbm_GBps"] / HBM_PEAK_GBS,
+                        "note": "power-limited: the pass takes the same cycles at whatever clock the board's "
+                                "power cap allows under int8 MFMA load (DESIGN.md 4.3)"},
+           "missing_weight_bits_32": {k: fast[k] for k in ("ms_per_pass", "ms_per_score", "value", "kernel_ms",
+                                                            "int8_TOPs")}}
+    if checker:
+        out["score_delta_vs_reference"] = full["score_delta_vs_reference"]
+        out["missing_weight_bits_32"]["score_delta_vs_reference"] = fast["score_delta_vs_reference"]
     msc.close()
     mdef.close()
     co.close()

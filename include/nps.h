@@ -276,7 +276,7 @@ int nps_score_cohort_def(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0
 /* ---- several score definitions in ONE pass over a resident cohort --------------------------
  * The reference evaluates one score per run (nimpress.nim:634-641); S scores over the same cohort are S
  * passes over the genotypes.  Here the S definitions are applied together: scores[N x S] =
- * dosage[N x M] . weights[M x S] on the matrix cores (int8 dosages x base-128 digits of the fixed-point
+ * dosage[N x M] . weights[M x S] on the matrix cores (int8 codes x base-256 digits of the fixed-point
  * weights, exact integer accumulation: DESIGN.md), the genotypes are read once for all S.
  *
  * Position j of every definition refers to cohort row cohort_row0 + j (a cohort holding the union of
@@ -294,6 +294,14 @@ typedef struct nps_multidef nps_multidef;
 int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc);
 void nps_multidef_destroy(nps_multidef *d);
 int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_params *params, int n_scores);
+/* Width of the fixed-point weight `(imputed dosage - 3) x beta` that a MISSING genotype adds on top of the
+ * `3 x beta` its code already received (the dosage weights always carry 56 bits).  56 (default): as exact as
+ * the dosage weights.  32: that weight keeps its four leading base-256 digits -- per sample an error of at most
+ * (its missing genotypes) x 2^-30 x B before the division by 2 nloci, B = max|beta| x (3 + max(2, 2 max|eaf|)) of
+ * the score, typically the square root of that count -- and with more than 4 scores the pass needs a quarter
+ * fewer matrix instructions.  NaN imputation values
+ * (imp-sample fail / int_fail below --mincs) are exact in both modes.  Applies to the following calls. */
+int nps_multi_set_missing_weight_bits(nps_multi *m, int bits);
 /* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset */
 int nps_score_cohort_multi(nps_multi *m, const nps_cohort *c, uint64_t cohort_row0, const nps_multidef *def);
 /* scores_out: [n_scores][n_samples]; nloci_out: [n_scores]; offsets: [n_scores]  (nimpress.nim:643-649) */

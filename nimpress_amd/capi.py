@@ -60,7 +60,7 @@ SYMBOLS = [
     "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream", "nps_fused_geometry",
     "nps_multidef_create", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
-    "nps_cohort_convert", "nps_cohort_row_tallies",
+    "nps_cohort_convert", "nps_cohort_row_tallies", "nps_multi_set_missing_weight_bits",
 ]
 
 
@@ -181,6 +181,7 @@ def load():
     L.nps_multi_destroy.restype = None
     dp = C.POINTER(C.c_double)
     L.nps_multi_timing.argtypes = [vp, dp, dp, dp]
+    L.nps_multi_set_missing_weight_bits.argtypes = [vp, i32]
     L.nps_cohort_convert.argtypes = [vp, vp]
     L.nps_cohort_row_tallies.argtypes = [vp, u64, u64, vp, vp]
     _lib = L
@@ -470,6 +471,11 @@ class MultiScorer:
         self._h = C.c_void_p()
         self.n, self.n_scores = int(n_samples), int(n_scores)
         _check(load().nps_multi_create(C.byref(self._h), device, self.n, C.byref(params), self.n_scores))
+
+    def set_missing_weight_bits(self, bits: int):
+        """56 (default): full-width weights for the imputed value of a missing genotype; 32: rounded to 2^-32 of the
+        score's largest weight, a quarter fewer matrix instructions with more than 4 scores (include/nps.h)"""
+        _check(load().nps_multi_set_missing_weight_bits(self._h, int(bits)))
 
     def score_cohort(self, cohort: Cohort, mdef: MultiDef, cohort_row0: int = 0):
         _check(load().nps_score_cohort_multi(self._h, cohort._h, cohort_row0, mdef._h))

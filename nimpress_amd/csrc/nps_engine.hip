@@ -1692,6 +1692,7 @@ struct nps_multi {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms[3] = {0.0, 0.0, 0.0};  // params, product, fold of all calls since the last reset
     bool timed = false;
+    bool coarse_missing = false;     // nps_multi_set_missing_weight_bits(32)
 };
 
 // add the device time of the last call (if its events have not been read yet) to the running totals
@@ -1763,6 +1764,13 @@ extern "C" int nps_multi_create(nps_multi **out, int device, uint64_t n_samples,
 
 extern "C" void nps_multi_destroy(nps_multi *m) { free_multi(m); }
 
+extern "C" int nps_multi_set_missing_weight_bits(nps_multi *m, int bits) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (bits != 0 && bits != 32 && bits != 56) return fail(NPS_E_INVAL, "bits must be 32 or 56 (0 = default 56), not %d", bits);
+    m->coarse_missing = bits == 32;
+    return NPS_OK;
+}
+
 extern "C" int nps_multi_reset(nps_multi *m, const nps_params *params) {
     if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
     if (params) {
@@ -1815,9 +1823,11 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
     HIP_TRY(hipMemsetAsync(m->d_table, 0, pl.table_bytes(), m->stream));
     HIP_TRY(hipEventRecord(m->ev[0], m->stream));
     HIP_TRY(launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
-                                dev_params(m->params), def->d_F, m->d_table, m->d_state));
+                                dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0));
     HIP_TRY(hipEventRecord(m->ev[1], m->stream));
-    if (m->n) HIP_TRY(launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial));
+    if (m->n)
+        HIP_TRY(launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial, m->d_state,
+                                  m->coarse_missing ? 1 : 0));
     HIP_TRY(hipEventRecord(m->ev[2], m->stream));
     HIP_TRY(launch_multi_fold(m->stream, pl, m->d_partial, m->n, m->S, def->d_F, m->d_part, m->have_sums ? 0 : 1,
                               m->d_state));

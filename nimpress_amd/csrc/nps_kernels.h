@@ -226,9 +226,9 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus);
 size_t multi_state_bytes();
 hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
                                uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
-                               void *d_table, void *d_state);
+                               void *d_table, void *d_state, int coarse_missing);
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial);
+                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing);
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state);
 hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,

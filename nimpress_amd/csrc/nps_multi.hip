@@ -9,11 +9,12 @@
 // and that belongs on MFMA -- provided the arithmetic stays exact enough for the 1e-6 bar.  float64
 // MFMA runs at the vector rate and would need every genotype converted to a double.  Instead:
 //
-//   * the per-row weights are turned into FIXED-POINT integers (49 bits) and split into seven signed
-//     base-128 digits: w = sum_k d_k 128^k / 2^F.  dosage (0,1,2 as int8) x digit (int8) accumulated in
-//     int32 by v_mfma_i32_32x32x32_i8 is EXACT integer arithmetic, independent of the summation order;
-//     the seven digit sums of a sample are recombined in float64 at the very end.  The only error is
-//     the quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score).
+//   * the per-row weights are turned into FIXED-POINT integers (49 bits, times a power of two <= 128 that
+//     belongs to the operand extraction, see put_digits) and split into seven signed base-256 digits:
+//     w = sum_k d_k 256^k / 2^(F+7).  code (int8) x digit (int8) accumulated in int32 by
+//     v_mfma_i32_32x32x32_i8 is EXACT integer arithmetic, independent of the summation order; the seven
+//     digit sums of a sample are recombined in float64 at the very end.  The only error is the
+//     quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score).
 //   * a missing genotype has code 3 in this layout: it contributes 3 x beta through the dosage
 //     matrix, and (imputed - 3) x beta through a second 0/1 matrix "is missing" (same accumulators).
 //     A weight that is NaN in the reference (imp-sample fail / int_fail below --mincs, NaN eaf) sets a
@@ -200,24 +201,48 @@ hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t s
 
 // ------------------------------------------------------------------------------------------
 // per (position, score): the decision chain of getImputedDosages for this row (nimpress.nim:523-585)
-// and the weights as base-128 digits in MFMA-fragment order.
-//   table bytes: index(sb, w, t, dm, lane, j) = ((((sb*4 + w)*NT + t)*2 + dm)*64 + lane)*16 + j
-//   row r = 128 sb + 64 h + 16 w + j ; column c = 8 s + k ; t = c / 32 ; lane = c % 32 + 32 h
+// and the weights as signed base-256 digits in MFMA-fragment order.
+//
+// The product kernel never spreads 2-bit codes to bytes: a byte of a unit word holds the codes of four
+// rows (fields f = 0..3 at bits 2f) of one sample, and `word & (0x03030303 << 2f)` IS an int8 operand
+// register whose four bytes are c << 2f for the rows 4b + f of that word (the top field is shifted down
+// first so that its bytes stay positive).  The factor 4^f goes into the weight instead: all weights are kept
+// as V x 128 (|V| <= 2^47, so seven signed base-256 digits hold it) and row r's dosage digits are those of
+// V x 128 / 4^f (f < 3) or V x 128 (f = 3).  The is-missing operand is the bit `code == 3` moved to bit 0 of
+// its byte (`m = w & (w >> 1) & 0x55555555` once per word, `(m >> 2f) & 0x01010101` per field), its digits
+// those of V x 128 for every field -- the same precision for all rows, which the 32-bit option needs.  One
+// MFMA takes the field-f bytes of a lane's four words: K index k = 4 w + b  <->  row 64 h + 16 w + 4 b + f.
+// 15 VALU ops per 16 genotypes for both matrices instead of 24 for spreading codes to bytes.
+//   table bytes: index(sb, f, t, dm, lane, k) = ((((sb*4 + f)*NT + t)*2 + dm)*64 + lane)*16 + k
+//   row r = 128 sb + 64 h + 16 w + 4 b + f ; column c = multi_col(NT, s, digit) ; t = c / 32 ; lane = c % 32 + 32 h
+//
+// Columns.  One tile (S <= 4): column 8 s + d for digit d = 0..6, 8 s + 7 for the NaN flag.  Two tiles: tile 0
+// holds the four HIGH digits of every score (column 4 s + d - 3, d = 3..6), tile 1 the three low digits and the
+// flag (32 + 4 s + d, flag 32 + 4 s + 3).  So a caller who accepts 32-bit weights for the is-missing matrix
+// (nps_multi_set_missing_weight_bits) needs tile 1 of that matrix only where a NaN flag occurs: the weights
+// are rounded to a multiple of 256^3 and their low digits are zero.
+static __host__ __device__ __forceinline__ int multi_col(int NT, int s, int d /* 0..6, 7 = flag */) {
+    if (NT == 1) return 8 * s + d;
+    return d >= 3 && d < 7 ? 4 * s + d - 3 : 32 + 4 * s + (d == 7 ? 3 : d);
+}
+
 static __device__ __forceinline__ void put_digits(int8_t *__restrict__ table, int NT, uint64_t r, int s,
-                                                  int dm, long long V, int flag) {
+                                                  int dm, long long V, int flag, bool coarse) {
     const uint64_t sb = r >> 7;
-    const int h = (int)((r >> 6) & 1), w = (int)((r >> 4) & 3), j = (int)(r & 15);
+    const int h = (int)((r >> 6) & 1), w = (int)((r >> 4) & 3), b = (int)((r >> 2) & 3), f = (int)(r & 3);
+    V *= (dm == 1 || f == 3) ? 128 : (128 >> (2 * f));
+    if (coarse) V = ((V + (1ll << 23)) >> 24) << 24;  // nearest multiple of 256^3 (digits 0..2 become zero)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         int d;
         if (k < 7) {
-            d = (int)((V + 64) & 127) - 64;
-            V = (V - d) >> 7;
+            d = (int)((V + 128) & 255) - 128;
+            V = (V - d) >> 8;
         } else {
             d = flag;
         }
-        const int c = 8 * s + k, t = c >> 5, lane = (c & 31) + 32 * h;
-        table[((((sb * 4 + w) * NT + t) * 2 + dm) * 64 + lane) * 16 + j] = (int8_t)d;
+        const int c = multi_col(NT, s, k), t = c >> 5, lane = (c & 31) + 32 * h;
+        table[((((sb * 4 + f) * NT + t) * 2 + dm) * 64 + lane) * 16 + 4 * w + b] = (int8_t)d;
     }
 }
 
@@ -226,13 +251,15 @@ struct MultiState {          // per score, on the device
     long long const_lo, const_hi;  // whole-locus constants of this call in fixed point: (hi << 32) + lo
     unsigned long long const_nan;  // a whole-locus constant was NaN (imp-locus fail / NaN eaf)
     double const_sum;          // float64 sum over the calls so far
-    double pad[3];
+    unsigned long long m_low;  // (score 0 only) this call's is-missing weights need tile 1: a NaN flag occurred
+    double pad[2];
 };
 
 __global__ __launch_bounds__(256) void multi_params_kernel(
     const unsigned long long *__restrict__ tally /* first cohort row of this call */,
     const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int NT, uint64_t n_samples,
-    DevParams p, const int *__restrict__ F /* [S] */, int8_t *__restrict__ table, MultiState *__restrict__ state) {
+    DevParams p, const int *__restrict__ F /* [S] */, int8_t *__restrict__ table, MultiState *__restrict__ state,
+    int coarse_missing) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (j >= n_desc) return;
@@ -283,8 +310,9 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
     }  // else: the row is not part of this score
     const int f = F[s];
     const bool m_nan = wM != wM;
-    put_digits(table, NT, j, s, 0, llrint(ldexp(wD, f)), 0);
-    put_digits(table, NT, j, s, 1, m_nan ? 0ll : llrint(ldexp(wM, f)), m_nan ? 1 : 0);
+    put_digits(table, NT, j, s, 0, llrint(ldexp(wD, f)), 0, false);
+    put_digits(table, NT, j, s, 1, m_nan ? 0ll : llrint(ldexp(wM, f)), m_nan ? 1 : 0, coarse_missing && NT == 2);
+    if (m_nan) atomicOr(&state[0].m_low, 1ull);
     if (used) atomicAdd(&state[s].nloci, 1ull);
     if (has_const) {
         if (cst != cst) {
@@ -298,47 +326,70 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// The product.  Workgroup = 16 waves; wave v owns GW groups of 32 samples; the workgroup walks the
-// superblocks of its row chunk: per superblock one 16 B load per lane and group (1 KiB per wave
-// instruction, contiguous, prefetched one superblock ahead in registers) and the superblock's digit
-// tables (NT x 8 KiB) staged through LDS.  Per word: 16 2-bit codes -> 16 int8 codes (dosage matrix)
-// and 16 0/1 bytes (is-missing matrix), 6 VALU ops per four genotypes, then NT x 2 MFMAs per group.
+// The product.  Workgroup = WAVES waves; wave v owns GW groups of 32 samples; the workgroup walks the
+// superblocks of its row chunk.  Everything the loop reads comes in by LDS-DMA (global_load_lds_dwordx4:
+// 1 KiB per wave instruction, no VGPR destination), because the kernel sits at the 128-VGPR cap of a
+// 16-wave workgroup and a register prefetch had nowhere to live (the compiler sank the loads to the end of
+// the step and every wave then sat out a full HBM round trip per superblock: 10 ms of a 48 ms pass):
+//   * the superblock's digit tables (NT x 8 KiB, shared by the 16 waves): one 1 KiB piece per wave, staged
+//     kStage superblocks ahead into the other half of a double buffer, one workgroup barrier per stage;
+//   * the wave's own units (GW x 1 KiB per superblock): a private ring, kStage superblocks ahead.
+// The wave counts its DMAs itself (s_waitcnt vmcnt(N), in order): per step its table pieces, then GW units.
+// Per superblock and group: 60 VALU ops make the 8 operand register sets (4 fields x {dosage, is-missing};
+// see put_digits) for 4 x NT x 2 MFMAs.
 //
-// The vector work (expansion) of one wave overlaps the matrix work of the other three waves of its SIMD
-// only while the waves are out of step; a workgroup barrier puts them back in step.  With one barrier per
-// superblock (4 words) the two pipes took turns: 51.5 ms per pass = matrix time (29 ms) + vector time
-// (22 ms).  So the tables are staged kStage superblocks at a time (two LDS buffers of kStage x NT x 8 KiB)
-// and the workgroup meets once per stage.
-constexpr int kStage = 4;  // superblocks per barrier
+// The vector work of one wave overlaps the matrix work of the other three waves of its SIMD only while
+// the waves are out of step; a workgroup barrier puts them back in step, hence kStage > 1.
+constexpr int kStage = 2;  // superblocks per barrier = prefetch distance of the units
 
-template <int NT>
+template <int NT, int GW, int WAVES>
 struct __attribute__((aligned(16))) MultiLds {
     uint4 tab[2][kStage][4 * NT * 2 * 64];
+    uint4 unit[kStage][WAVES][GW][64];
 };
 
-static __device__ __forceinline__ void expand_word(uint32_t w, v4i &D, v4i &M) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t t = (w >> (8 * q)) & 0xFFu;
-        const uint32_t x1 = t | (t << 12);
-        const uint32_t sel = (x1 | (x1 << 6)) & 0x03030303u;  // byte b = code of row 4q + b
-        D[q] = (int)sel;
-        M[q] = (int)((sel >> 1) & sel & 0x01010101u);       // 1 where the code is 3 (missing)
-    }
+// one LDS-DMA: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (lds_dst wave-uniform).  M0 is
+// the destination base and compiler-reserved: written and restored inside the statement.
+static __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+static __device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+static __device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address of a __shared__ object
+    return (uint32_t)(uintptr_t)p;
 }
 
-template <int NT, int GW>
-__global__ __launch_bounds__(1024) void multi_mfma_kernel(const uint4 *__restrict__ units, uint64_t n_groups,
+#ifndef NPS_MULTI_GW
+#define NPS_MULTI_GW 2  // sample groups per wave; the workgroup has 32 / GW waves
+#endif
+#ifndef NPS_MULTI_DIAG
+#define NPS_MULTI_DIAG 0  // experiment builds: 1 no unit loads in the loop, 4 no table staging
+#endif
+template <int NT, int GW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__restrict__ units, uint64_t n_groups,
                                                           uint64_t sb_first, uint32_t n_sb, uint32_t sb_per_chunk,
                                                           const uint4 *__restrict__ table,
-                                                          int32_t *__restrict__ partial) {
-    constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock
-    constexpr int kTregs = (kTab + 1023) / 1024;
-    __shared__ MultiLds<NT> lds;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                          int32_t *__restrict__ partial,
+                                                          const MultiState *__restrict__ state, int m_low_always) {
+    constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock: 1024 (NT = 2) or 512
+    constexpr int kPieces = kTab / 64;     // 1 KiB pieces of a superblock's tables
+    constexpr int kPW = kPieces >= WAVES ? kPieces / WAVES : 1;  // table DMAs per wave and step
+    static_assert(kPieces % WAVES == 0 || WAVES % kPieces == 0, "table pieces per wave");
+    __shared__ MultiLds<NT, GW, WAVES> lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk = blockIdx.y;
     const uint32_t sb_a = chunk * sb_per_chunk, sb_b = min(n_sb, sb_a + sb_per_chunk);
-    const uint64_t g0 = ((uint64_t)blockIdx.x * 16 + wave) * GW;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * WAVES + wave) * GW;
+    if (sb_a >= sb_b) return;  // (whole workgroup)
+    // tile 1 of the is-missing matrix: always with full-width weights, else only if a NaN flag is set
+    const bool m_low = NT == 1 || m_low_always || __builtin_amdgcn_readfirstlane((int)state[0].m_low) != 0;
 
     v16i acc[GW][NT];
 #pragma unroll
@@ -348,73 +399,92 @@ __global__ __launch_bounds__(1024) void multi_mfma_kernel(const uint4 *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0;
 
-    auto load_units = [&](uint32_t sb, uint4 (&dst)[GW]) {
+    // Every wave issues the same DMAs in every step (the counted waits rely on it): addresses past the
+    // chunk / past the last group are clamped to valid ones, what they fetch is never used.
+    const int piece0 = (wave * kPW) % kPieces;  // (more waves than pieces: some pieces are fetched twice)
+    auto dma_table = [&](uint32_t sb, int buf, int slot) {
+        const uint32_t s = min(sb, sb_b - 1);
+#pragma unroll
+        for (int i = 0; i < kPW; ++i) {
+            const int e = (piece0 + i) * 64;
+            glds16(table + (uint64_t)s * kTab + e + lane, lds_addr(&lds.tab[buf][slot][e]));
+        }
+    };
+    auto dma_units = [&](uint32_t sb, int slot) {
+        const uint32_t s = min(sb, sb_b - 1);
 #pragma unroll
         for (int a = 0; a < GW; ++a) {
-            dst[a] = make_uint4(0, 0, 0, 0);
-            if (sb < sb_b && g0 + a < n_groups) dst[a] = units[((sb_first + sb) * n_groups + g0 + a) * 64 + lane];
-        }
-    };
-    auto load_table = [&](uint32_t sb, uint4 (&dst)[kTregs]) {
-#pragma unroll
-        for (int i = 0; i < kTregs; ++i) {
-            const int e = i * 1024 + tid;
-            dst[i] = make_uint4(0, 0, 0, 0);
-            if (sb < sb_b && e < kTab) dst[i] = table[(uint64_t)sb * kTab + e];
-        }
-    };
-    auto store_table = [&](int buf, int slot, const uint4 (&src)[kTregs]) {
-#pragma unroll
-        for (int i = 0; i < kTregs; ++i) {
-            const int e = i * 1024 + tid;
-            if (e < kTab) lds.tab[buf][slot][e] = src[i];
+            const uint64_t g = min(g0 + a, n_groups - 1);
+            glds16(units + ((sb_first + s) * n_groups + g) * 64 + lane, lds_addr(&lds.unit[slot][wave][a][0]));
         }
     };
 
-    uint4 cur[GW], nxt[GW];
-    uint4 treg[kTregs];
-    // first stage of tables
 #pragma unroll
     for (int k = 0; k < kStage; ++k) {
-        load_table(sb_a + k, treg);
-        store_table(0, k, treg);
+        dma_table(sb_a + k, 0, k);
+        dma_units(sb_a + k, k);
     }
-    load_units(sb_a, cur);
-    __syncthreads();
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
     int buf = 0;
     for (uint32_t s0 = sb_a; s0 < sb_b; s0 += kStage, buf ^= 1) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
             const uint32_t sb = s0 + k;
-            load_table(sb + kStage, treg);  // the same slot of the next stage; in flight during the MFMAs below
-            load_units(sb + 1, nxt);
+            // the units of this superblock were fetched one stage ago: younger DMAs = the later steps of that stage
+            wait_vm<(kPW + GW) * (kStage - 1)>();
+            uint32_t wd[GW][4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                v4i D[GW], M[GW];
+            for (int a = 0; a < GW; ++a) {
+                const uint4 u = lds.unit[k][wave][a][lane];
+                wd[a][0] = u.x, wd[a][1] = u.y, wd[a][2] = u.z, wd[a][3] = u.w;
+            }
+            // the ring slot is free again once the read has returned
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(NPS_MULTI_DIAG & 4)) dma_table(sb + kStage, buf ^ 1, k);
+            if (!(NPS_MULTI_DIAG & 1)) dma_units(sb + kStage, k);
+            if (sb < sb_b) {
+                uint32_t miss[GW][4];  // bit 2f of a byte: field f is code 3
 #pragma unroll
-                for (int a = 0; a < GW; ++a) {
-                    const uint32_t word = w == 0 ? cur[a].x : w == 1 ? cur[a].y : w == 2 ? cur[a].z : cur[a].w;
-                    expand_word(word, D[a], M[a]);
-                }
+                for (int a = 0; a < GW; ++a)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const uint4 bd = lds.tab[buf][k][((w * NT + t) * 2 + 0) * 64 + lane];
-                    const uint4 bm = lds.tab[buf][k][((w * NT + t) * 2 + 1) * 64 + lane];
-                    const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
-                    const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+                    for (int i = 0; i < 4; ++i) miss[a][i] = wd[a][i] & (wd[a][i] >> 1) & 0x55555555u;
 #pragma unroll
-                    for (int a = 0; a < GW; ++a) {
-                        acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
-                        acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) {
+                    v4i D[GW], M[GW];
+#pragma unroll
+                    for (int a = 0; a < GW; ++a)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            D[a][i] = f < 3 ? (int)(wd[a][i] & (0x03030303u << (2 * f)))
+                                            : (int)((wd[a][i] >> 6) & 0x03030303u);
+                            M[a][i] = (int)((miss[a][i] >> (2 * f)) & 0x01010101u);
+                        }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const uint4 bd = lds.tab[buf][k][((f * NT + t) * 2 + 0) * 64 + lane];
+                        const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
+#pragma unroll
+                        for (int a = 0; a < GW; ++a)
+                            acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
+                        if (t == 0 || m_low) {
+                            const uint4 bm = lds.tab[buf][k][((f * NT + t) * 2 + 1) * 64 + lane];
+                            const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+                            for (int a = 0; a < GW; ++a)
+                                acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+                        }
                     }
                 }
             }
-            store_table(buf ^ 1, k, treg);
-#pragma unroll
-            for (int a = 0; a < GW; ++a) cur[a] = nxt[a];
         }
-        __syncthreads();
+        // the next stage's tables have landed (only this step's unit DMAs may still be in flight); every wave
+        // has finished reading this stage's
+        wait_vm<GW>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
+    wait_vm<0>();  // (clamped prefetches of the last stage: nothing may land after the workgroup has ended)
     // C/D map of the 32x32 MFMA shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int a = 0; a < GW; ++a) {
@@ -435,30 +505,51 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restri
                                                          uint64_t n_groups, uint64_t n_samples, int S, int NT,
                                                          const int *__restrict__ F, double *__restrict__ part,
                                                          int overwrite, MultiState *__restrict__ state) {
+    // a thread folds the scores 2p and 2p + 1 of one sample: their columns are runs of 8 int32 (32-byte sectors)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const int s = blockIdx.y;
-    if (i == 0) {  // this call's whole-locus constants -> the float64 running constant of the score
+    const int s0 = 2 * blockIdx.y;
+    if (i < 2 && s0 + (int)i < S) {  // this call's whole-locus constants -> the float64 running constant of the score
+        const int s = s0 + (int)i;
         MultiState &st = state[s];
         const double c = ldexp((double)st.const_hi * 4294967296.0 + (double)st.const_lo, -F[s]);
         st.const_sum = (overwrite ? 0.0 : st.const_sum) + (st.const_nan ? __longlong_as_double(0x7ff8000000000000ll) : c);
         st.const_lo = st.const_hi = 0;
         st.const_nan = 0;
+        if (s == 0) st.m_low = 0;
     }
     if (i >= n_samples) return;
     const uint64_t g = i >> 5, si = i & 31;
-    long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long sum[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};  // [score][digit 0..6, flag]
     for (uint32_t c = 0; c < n_chunks; ++c) {
-        const int32_t *src = partial + (((uint64_t)c * n_groups + g) * 32 + si) * (NT * 32) + 8 * s;
+        const int4 *src = reinterpret_cast<const int4 *>(partial + (((uint64_t)c * n_groups + g) * 32 + si) * (NT * 32));
+        if (NT == 1) {  // columns 8 s + d
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sum[k] += src[k];
+            for (int j = 0; j < 2; ++j) {
+                const int4 lo = src[2 * (s0 + j)], hi = src[2 * (s0 + j) + 1];
+                sum[j][0] += lo.x, sum[j][1] += lo.y, sum[j][2] += lo.z, sum[j][3] += lo.w;
+                sum[j][4] += hi.x, sum[j][5] += hi.y, sum[j][6] += hi.z, sum[j][7] += hi.w;
+            }
+        } else {        // multi_col: digits 3..6 at 4 s, digits 0..2 and the flag at 32 + 4 s
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int4 hi = src[s0 + j], lo = src[8 + s0 + j];
+                sum[j][0] += lo.x, sum[j][1] += lo.y, sum[j][2] += lo.z, sum[j][7] += lo.w;
+                sum[j][3] += hi.x, sum[j][4] += hi.y, sum[j][5] += hi.z, sum[j][6] += hi.w;
+            }
+        }
     }
-    double v = (double)sum[6];
 #pragma unroll
-    for (int k = 5; k >= 0; --k) v = v * 128.0 + (double)sum[k];
-    v = ldexp(v, -F[s]);
-    if (sum[7] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
-    double *dst = part + (uint64_t)s * n_samples + i;
-    *dst = overwrite ? v : *dst + v;
+    for (int j = 0; j < 2; ++j) {
+        const int s = s0 + j;
+        if (s >= S) break;
+        double v = (double)sum[j][6];
+#pragma unroll
+        for (int k = 5; k >= 0; --k) v = v * 256.0 + (double)sum[j][k];
+        v = ldexp(v, -F[s] - 7);  // the digits are those of weight x 2^F x 128 (put_digits)
+        if (sum[j][7] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
+        double *dst = part + (uint64_t)s * n_samples + i;
+        *dst = overwrite ? v : *dst + v;
+    }
 }
 
 // nimpress.nim:643-649 per score: (sum + constants) / (2 nloci) + offset
@@ -479,44 +570,49 @@ __global__ __launch_bounds__(256) void multi_finish_kernel(const double *__restr
 // ---- host side ------------------------------------------------------------------------------
 hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
                                uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
-                               void *d_table, void *d_state) {
+                               void *d_table, void *d_state, int coarse_missing) {
     if (n_desc == 0 || S == 0) return hipSuccess;
     (void)hipGetLastError();
     hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)((n_desc + 255) / 256), (uint32_t)S), dim3(256), 0, st,
-                       d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (int8_t *)d_table, (MultiState *)d_state);
+                       d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (int8_t *)d_table, (MultiState *)d_state,
+                       coarse_missing);
     return hipGetLastError();
 }
 
 MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
     MultiPlan pl;
     pl.NT = (8 * S + 31) / 32;
-    pl.GW = 2;
+    pl.GW = NPS_MULTI_GW;
     pl.n_groups = (n_samples + 31) / 32;
     pl.n_sb = (uint32_t)((n_rows + 127) / 128);
-    pl.tiles = (uint32_t)((pl.n_groups + 16 * pl.GW - 1) / (16 * pl.GW));
+    pl.tiles = (uint32_t)((pl.n_groups + 31) / 32);  // 32 groups = 1 024 samples per workgroup
     // one workgroup per CU at a time: enough of them (~12 rounds) that the last, partly filled round costs
     // little, every chunk at least 16 superblocks long
     uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
     q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 16));
     q = std::min<uint32_t>(q, 64);
-    // int32 digit sums: |sum| <= rows x 3 x 64 per chunk, so at most 2^31 / 192 rows = 87 381 superblocks
-    q = std::max<uint32_t>(q, (pl.n_sb + 87380) / 87381);
+    // int32 digit sums: |operand byte x digit| <= 64 x 128 per row, so a chunk holds at most 2^31 / 8192 rows
+    // = 2 048 superblocks
+    q = std::max<uint32_t>(q, (pl.n_sb + 2039) / 2040);
     pl.sb_per_chunk = (pl.n_sb + q - 1) / q;
     pl.n_chunks = pl.sb_per_chunk ? (pl.n_sb + pl.sb_per_chunk - 1) / pl.sb_per_chunk : 0;
     return pl;
 }
 
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial) {
+                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing) {
     if (pl.n_sb == 0 || pl.n_groups == 0) return hipSuccess;
     (void)hipGetLastError();
-    const dim3 grid(pl.tiles, pl.n_chunks), block(1024);
+    constexpr int GW = NPS_MULTI_GW, WAVES = 32 / GW;
+    const dim3 grid(pl.tiles, pl.n_chunks), block(64 * WAVES);
     if (pl.NT == 1)
-        hipLaunchKernelGGL((multi_mfma_kernel<1, 2>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups, sb_first,
-                           pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial);
+        hipLaunchKernelGGL((multi_mfma_kernel<1, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
+                           sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
+                           (const MultiState *)d_state, coarse_missing ? 0 : 1);
     else if (pl.NT == 2)
-        hipLaunchKernelGGL((multi_mfma_kernel<2, 2>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups, sb_first,
-                           pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial);
+        hipLaunchKernelGGL((multi_mfma_kernel<2, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
+                           sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
+                           (const MultiState *)d_state, coarse_missing ? 0 : 1);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -525,7 +621,7 @@ hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_fold_kernel, dim3((uint32_t)std::max<uint64_t>(1, (n_samples + 255) / 256), (uint32_t)S),
+    hipLaunchKernelGGL(multi_fold_kernel, dim3((uint32_t)std::max<uint64_t>(1, (n_samples + 255) / 256), (uint32_t)((S + 1) / 2)),
                        dim3(256), 0, st, d_partial, pl.n_chunks, pl.n_groups, n_samples, S, pl.NT, d_F, d_part, overwrite,
                        (MultiState *)d_state);
     return hipGetLastError();

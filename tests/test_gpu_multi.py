@@ -72,12 +72,17 @@ def oracle_scores(codes, n, descs, params_kw, offsets):
     return np.stack(out), np.array(nl)
 
 
+@pytest.mark.parametrize("bits", [56, 32])
 @pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
 @pytest.mark.parametrize("shape", [(1, 1, 1), (6, 7, 3), (33, 129, 4), (257, 300, 5), (1000, 1025, 8), (4099, 64, 8)])
-def test_multi_vs_oracle_converted_cohort(shape, pk):
+def test_multi_vs_oracle_converted_cohort(shape, pk, bits):
     """a 2-bit cohort uploaded row-major, repacked on the device (nps_cohort_convert), S definitions with
-    their own beta / eaf / effect allele, rows a score does not list, absent / uncovered / FILTER rows"""
+    their own beta / eaf / effect allele, rows a score does not list, absent / uncovered / FILTER rows; with
+    full-width and with 32-bit weights for the imputed value of a missing genotype (the second changes the pass
+    only for more than 4 scores; the NaN cases of PARAM_GRID 3 and 4 must stay exact in both)"""
     n, m, S = shape
+    if bits == 32 and S <= 4:
+        pytest.skip("one column tile: the option changes nothing")
     kw = PARAM_GRID[pk]
     eaf_c, th, tm, tmi, descs = make_case(n, m, S, 1000 * pk + n + m)
     codes = refcpu.synth_rows(n, 0, m, 31, th, tm, tmi)
@@ -92,6 +97,7 @@ def test_multi_vs_oracle_converted_cohort(shape, pk):
     assert np.array_equal(nm, ms.astype(np.uint64)) and np.array_equal(ne, neff.astype(np.uint64))
     offsets = np.linspace(-0.5, 0.5, S)
     msc = capi.MultiScorer(n, capi.make_params(**kw), S)
+    msc.set_missing_weight_bits(bits)
     mdef = capi.MultiDef(descs)
     msc.score_cohort(co, mdef)
     got, nloci = msc.finish(offsets)
@@ -99,6 +105,16 @@ def test_multi_vs_oracle_converted_cohort(shape, pk):
     assert np.array_equal(nloci.astype(np.int64), ref_nloci)
     for s in range(S):
         keep = descs[s]["kind"] != capi.ROW_NOT_IN_SCORE
+        if bits == 32:
+            # the documented bound (include/nps.h): (missing genotypes of the sample) x 2^-30 x B, here with all
+            # rows of the score as the count, after the division by 2 nloci
+            d = descs[s][keep]
+            B = float(np.max(np.abs(d["beta"])) * (3.0 + max(2.0, 2.0 * float(np.max(np.abs(np.nan_to_num(d["eaf"])))))))
+            bound = keep.sum() * 2.0 ** -30 * B / max(2.0 * int(ref_nloci[s]), 1)
+            ok = ~np.isnan(ref[s])
+            assert np.array_equal(np.isnan(got[s]), np.isnan(ref[s]))
+            assert np.all(np.abs(got[s][ok] - ref[s][ok]) <= bound + REL_TOL * np.abs(ref[s][ok])), s
+            continue
         assert rel_err(got[s], ref[s], float(np.sum(np.abs(descs[s]["beta"][keep]))), int(ref_nloci[s])) <= REL_TOL, s
     # a second call on the same context after a reset gives the same bits
     msc.reset()
@@ -159,6 +175,12 @@ def test_multi_equals_single_score_path_medium():
     mdef = capi.MultiDef(descs)
     msc.score_cohort(co, mdef)
     got, nloci = msc.finish(np.zeros(S))
+    msc.reset()
+    msc.set_missing_weight_bits(32)
+    msc.score_cohort(co, mdef)
+    got32, nloci32 = msc.finish(np.zeros(S))
+    msc.set_missing_weight_bits(56)
+    assert np.array_equal(nloci, nloci32)
     for s in range(S):
         sc = capi.Scorer(n, capi.make_params())
         sc.score_cohort(gt, descs[s])
@@ -166,6 +188,8 @@ def test_multi_equals_single_score_path_medium():
         sc.close()
         assert nl == int(nloci[s])
         assert rel_err(got[s], one, float(np.sum(np.abs(descs[s]["beta"]))), nl) <= REL_TOL, s
+        # 32-bit weights for the ~4 % missing genotypes of this cohort: still far inside the 1e-6 bar
+        assert rel_err(got32[s], one, float(np.sum(np.abs(descs[s]["beta"]))), nl) <= 1e-6, s
     # converting the row-major cohort gives the same units as generating them directly
     co2 = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
     co2.convert_from(gt)

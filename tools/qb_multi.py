@@ -10,6 +10,7 @@ ap.add_argument("--variants", type=int, default=1_000_000)
 ap.add_argument("--scores", type=int, default=8)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--zero", action="store_true", help="all genotypes 0 (clock / power experiment)")
+ap.add_argument("--missing-bits", type=int, default=0, help="nps_multi_set_missing_weight_bits (32 or 56)")
 a = ap.parse_args()
 import torch
 from nimpress_amd import capi
@@ -31,6 +32,8 @@ for s in range(S):
     descs[s]["eaf"] = eaf
 mdef = capi.MultiDef(descs)
 msc = capi.MultiScorer(n, capi.make_params(), S)
+if a.missing_bits:
+    msc.set_missing_weight_bits(a.missing_bits)
 d_scores = torch.empty((S, n), dtype=torch.float64, device="cuda")
 off = np.zeros(S)
 for i in range(a.steps + 1):
