@@ -80,14 +80,12 @@ struct nps_ctx {
     // streaming batch
     uint32_t batch_cap = 0, batch_rows = 0;
     uint32_t *d_codes = nullptr;            // [batch_cap/4 groups][stride_words][4] (interleaved)
-    uint32_t *d_rowtmp = nullptr;           // one contiguous packed row (nps_push_packed staging)
     unsigned long long *d_tally = nullptr;  // [batch_cap]
     nps_row_desc *d_desc = nullptr;         // [batch_cap]
     nps_row_desc *h_desc = nullptr;         // pinned [batch_cap]
     double *d_lut = nullptr;                // [batch_cap][4]
     nps_locus_stat *d_stats = nullptr;      // [batch_cap]
     nps_locus_stat *h_stats = nullptr;      // pinned [batch_cap]
-    int32_t *d_raw = nullptr;               // raw FORMAT staging for one row (n*2 int32)
     static constexpr int kRawSlots = 8;  // rows in flight between the caller's buffer and the device
     int32_t *h_raw[kRawSlots] = {};  // pinned staging ring for caller buffers
     void *h_arena = nullptr;  // ONE pinned allocation holding h_desc, h_stats and h_raw[]
@@ -115,8 +113,7 @@ struct nps_ctx {
     double *d_rds_psum = nullptr;  // fused DS kernel: per (row, slice) partial dosage sums
     uint64_t psum_cap = 0;
 
-    // raw GT staging for ploidy > 2: device buffer + a ring of two pinned host buffers (grown on demand)
-    int32_t *d_poly = nullptr;
+    // raw GT staging for ploidy > 2: a ring of two pinned host buffers (grown on demand), read by the kernel
     size_t poly_cap = 0;
     void *h_poly[2] = {nullptr, nullptr};
     hipEvent_t ev_poly[2] = {nullptr, nullptr};
@@ -267,17 +264,14 @@ static void free_ctx(nps_ctx *c) {
         (void)hipEventDestroy(s.b);
     }
     (void)hipFree(c->d_codes);
-    (void)hipFree(c->d_rowtmp);
     (void)hipFree(c->d_tally);
     (void)hipFree(c->d_desc);
     (void)hipHostFree(c->h_arena);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_raw);
     for (int k = 0; k < nps_ctx::kRawSlots; ++k)
         if (c->ev_raw[k]) (void)hipEventDestroy(c->ev_raw[k]);
     (void)hipFree(c->d_ds);
-    (void)hipFree(c->d_poly);
     for (int k = 0; k < 2; ++k) {
         (void)hipHostFree(c->h_poly[k]);
         if (c->ev_poly[k]) (void)hipEventDestroy(c->ev_poly[k]);
@@ -375,7 +369,6 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CTX_TRY(hipMalloc(&c->d_codes, row_bytes * c->batch_cap));
     CTX_TRY(hipMemsetAsync(c->d_codes, 0, row_bytes * c->batch_cap, c->stream));
-    CTX_TRY(hipMalloc(&c->d_rowtmp, row_bytes));
     CTX_TRY(hipMalloc(&c->d_tally, sizeof(unsigned long long) * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_desc, sizeof(nps_row_desc) * c->batch_cap));
     {
@@ -402,7 +395,6 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
     }
     CTX_TRY(hipMalloc(&c->d_lut, sizeof(double) * 4 * c->batch_cap));
     CTX_TRY(hipMalloc(&c->d_stats, sizeof(nps_locus_stat) * c->batch_cap));
-    CTX_TRY(hipMalloc(&c->d_raw, sizeof(int32_t) * 2 * std::max<uint64_t>(c->n, 1)));
     for (int k = 0; k < nps_ctx::kRawSlots; ++k) {
         CTX_TRY(hipEventCreateWithFlags(&c->ev_raw[k], hipEventDisableTiming));
     }
@@ -596,30 +588,28 @@ static int push_gt_polyploid(nps_ctx *c, const void *gts, int elem_bytes, int pl
         const size_t bytes = (size_t)elem_bytes * (size_t)ploidy * c->n;
         if (bytes > c->poly_cap) {  // the staging grows to the widest record seen (rare: once per context)
             HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_poly);
-            c->d_poly = nullptr;
             c->poly_cap = 0;
             for (int k = 0; k < 2; ++k) {
                 (void)hipHostFree(c->h_poly[k]);
                 c->h_poly[k] = nullptr;
                 if (!c->ev_poly[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_poly[k], hipEventDisableTiming));
             }
-            HIP_TRY(hipMalloc(&c->d_poly, bytes));
             HIP_TRY(hipHostMalloc(&c->h_poly[0], bytes));
             HIP_TRY(hipHostMalloc(&c->h_poly[1], bytes));
             c->poly_cap = bytes;
         }
         // as for diploid rows: the caller may reuse `gts` on return, so it is copied into a pinned ring
-        // slot first; no stream synchronisation per row
+        // slot first (which the decode kernel reads where it lies); no stream synchronisation per row
         const int k = c->poly_next;
         c->poly_next ^= 1;
         HIP_TRY(hipEventSynchronize(c->ev_poly[k]));
         memcpy(c->h_poly[k], gts, bytes);
-        HIP_TRY(hipMemcpyAsync(c->d_poly, c->h_poly[k], bytes, hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, P_DECODE);
+            HIP_TRY(launch_decode_gt_to_ds(c->stream, c->h_poly[k], elem_bytes, c->n, ploidy, eaidx,
+                                           c->d_ds + (uint64_t)slot * c->ds_stride_f));
+        }
         HIP_TRY(hipEventRecord(c->ev_poly[k], c->stream));
-        ProfScope ps(c, P_DECODE);
-        HIP_TRY(launch_decode_gt_to_ds(c->stream, c->d_poly, elem_bytes, c->n, ploidy, eaidx,
-                                       c->d_ds + (uint64_t)slot * c->ds_stride_f));
     }
     PendingRow p;
     p.batch_idx = (int32_t)slot;
@@ -652,12 +642,15 @@ static int push_gt_typed(nps_ctx *c, const void *gts, int elem_bytes, int ploidy
         HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
         const size_t bytes = (size_t)elem_bytes * (size_t)ploidy * c->n;
         memcpy(c->h_raw[k], gts, bytes);
-        HIP_TRY(hipMemcpyAsync(c->d_raw, c->h_raw[k], bytes, hipMemcpyHostToDevice, c->stream));
+        // the decode kernel reads the pinned slot itself, over PCIe: one launch per row instead of a DMA
+        // copy and a launch that wait for each other (copy engine <-> compute queue, ~50 us per row)
+        {
+            ProfScope ps(c, P_DECODE);
+            HIP_TRY(launch_decode_gt(c->stream, c->h_raw[k], elem_bytes, c->n, ploidy, eaidx,
+                                     c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4, slot & 3,
+                                     c->d_tally + slot));
+        }
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
-        ProfScope ps(c, P_DECODE);
-        HIP_TRY(launch_decode_gt(c->stream, c->d_raw, elem_bytes, c->n, ploidy, eaidx,
-                                 c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4, slot & 3,
-                                 c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;
@@ -686,13 +679,13 @@ extern "C" int nps_push_packed(nps_ctx *c, const uint32_t *row, int ref_is_effec
         c->raw_next = (k + 1) % nps_ctx::kRawSlots;
         HIP_TRY(hipEventSynchronize(c->ev_raw[k]));
         memcpy(c->h_raw[k], row, sizeof(uint32_t) * c->n_words);
-        HIP_TRY(hipMemcpyAsync(c->d_rowtmp, c->h_raw[k], sizeof(uint32_t) * c->n_words,
-                               hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, P_TALLY);
+            HIP_TRY(launch_tally_scatter_row(c->stream, reinterpret_cast<const uint32_t *>(c->h_raw[k]), c->n, -1,
+                                             c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
+                                             slot & 3, c->d_tally + slot));
+        }
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
-        ProfScope ps(c, P_TALLY);
-        HIP_TRY(launch_tally_scatter_row(c->stream, c->d_rowtmp, c->n,
-                                         c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
-                                         slot & 3, c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;
@@ -713,13 +706,14 @@ extern "C" int nps_push_bed(nps_ctx *c, const uint8_t *bed_row, int effect_is_a1
         const size_t bytes = (size_t)((c->n + 3) / 4), padded = sizeof(uint32_t) * c->n_words;
         memcpy(c->h_raw[k], bed_row, bytes);
         memset((char *)c->h_raw[k] + bytes, 0, padded - bytes);
-        HIP_TRY(hipMemcpyAsync(c->d_rowtmp, c->h_raw[k], padded, hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, P_TALLY);
+            HIP_TRY(launch_tally_scatter_row(c->stream, reinterpret_cast<const uint32_t *>(c->h_raw[k]), c->n,
+                                             effect_is_a1 ? 1 : 0,
+                                             c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
+                                             slot & 3, c->d_tally + slot));
+        }
         HIP_TRY(hipEventRecord(c->ev_raw[k], c->stream));
-        ProfScope ps(c, P_TALLY);
-        HIP_TRY(launch_bed_recode_row(c->stream, c->d_rowtmp, c->n, effect_is_a1));
-        HIP_TRY(launch_tally_scatter_row(c->stream, c->d_rowtmp, c->n,
-                                         c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
-                                         slot & 3, c->d_tally + slot));
     }
     commit_data_row(c, slot);
     return NPS_OK;

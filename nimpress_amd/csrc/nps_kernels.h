@@ -69,8 +69,9 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
                                uint64_t n_samples, uint64_t n_rows, unsigned long long *d_tally,
                                int parity = 0);
 
-// a plain (contiguous) packed row: tally it and scatter it into row `row_in_group` of a group
-hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
+// a plain (contiguous) packed row, device or pinned host memory: tally it and scatter it into row
+// `row_in_group` of a group; bed_mode -1 = native codes, 0 / 1 = PLINK .bed row, effect allele A2 / A1
+hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *row, uint64_t n_samples, int bed_mode,
                                     uint32_t *d_group, int row_in_group,
                                     unsigned long long *d_tally);
 
@@ -79,7 +80,6 @@ hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint6
 hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
                                   uint64_t k, uint64_t n_samples, const uint8_t *d_mode, uint32_t *d_dst,
                                   uint64_t stride_words);
-hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1);
 
 // nps_cohort_optimize (nps_kernels.hip): the "parity layout".  The table index of the accumulation kernels
 // puts the four LOW code bits and index bit 4 into the five LDS bank-select bits; the other three bits

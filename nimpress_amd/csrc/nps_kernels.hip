@@ -80,6 +80,14 @@ __global__ __launch_bounds__(256) void decode_gt_kernel(const T *__restrict__ gt
             const int2 v = reinterpret_cast<const int2 *>(gts)[s];
             a[0] = v.x;
             a[PLOIDY - 1] = v.y;
+        } else if (PLOIDY == 2 && sizeof(T) == 2) {  // one load per sample (the buffer may be host memory)
+            const uint32_t v = reinterpret_cast<const uint32_t *>(gts)[s];
+            a[0] = (int32_t)(int16_t)(v & 0xFFFFu);
+            a[PLOIDY - 1] = (int32_t)(int16_t)(v >> 16);
+        } else if (PLOIDY == 2 && sizeof(T) == 1) {
+            const uint32_t v = reinterpret_cast<const uint16_t *>(gts)[s];
+            a[0] = (int32_t)(int8_t)(v & 0xFFu);
+            a[PLOIDY - 1] = (int32_t)(int8_t)(v >> 8);
         } else {
 #pragma unroll
             for (int k = 0; k < PLOIDY; ++k) a[k] = (int32_t)gts[s * PLOIDY + k];
@@ -197,11 +205,17 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
     return hipGetLastError();
 }
 
-// one contiguous packed row (nps_push_packed staging): tally + scatter into the interleaved batch.
-// grid = chunks of 2048 words; every block adds its part with one 64-bit atomic (`tally` is zero before
-// the first row of a batch slot is pushed, as for the decode kernel)
+// one contiguous packed row (nps_push_packed / nps_push_bed staging, read where it lies: the pinned host
+// slot): tally + scatter into the interleaved batch.  bed_mode: -1 = native codes, 0 / 1 = a PLINK .bed row
+// whose effect allele is A2 / A1 (bed_recode below).  grid = chunks of 2048 words; every block adds its part
+// with one 64-bit atomic (`tally` is zero before the first row of a batch slot is pushed, as for the decode
+// kernel)
+static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, bool effect_a1, uint32_t c,
+                                                       uint32_t n_words, uint32_t tail_mask);
+
 __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *__restrict__ row,
-                                                                uint32_t n_words,
+                                                                uint32_t n_words, int bed_mode,
+                                                                uint32_t tail_mask,
                                                                 uint32_t *__restrict__ out_group,
                                                                 int row_in_group,
                                                                 unsigned long long *__restrict__ tally) {
@@ -212,7 +226,9 @@ __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *
     for (int u = 0; u < 8; ++u) {
         const uint32_t c = c0 + u * 256 + threadIdx.x;
         if (c < n_words) {
-            const uint32_t w = word_to_planes(row[c]);  // the staging row is in the C-ABI's bit order
+            uint32_t x = row[c];  // the staging row is in the C-ABI's bit order
+            if (bed_mode >= 0) x = bed_recode(x, bed_mode != 0, c, n_words, tail_mask);
+            const uint32_t w = word_to_planes(x);
             tally_word(w, cw, cm);
             out_group[(uint64_t)c * 4 + row_in_group] = w;
         }
@@ -222,14 +238,16 @@ __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *
         atomicAdd(tally, ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm));
 }
 
-hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *d_row, uint64_t n_samples,
+hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *row, uint64_t n_samples, int bed_mode,
                                     uint32_t *d_group, int row_in_group,
                                     unsigned long long *d_tally) {
     const uint64_t n_words = words_for(n_samples);
     if (n_words == 0) return hipSuccess;
+    const uint32_t rem = (uint32_t)(n_samples & 15);
+    const uint32_t tail_mask = rem ? ((1u << (2 * rem)) - 1u) : 0xffffffffu;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(tally_scatter_row_kernel, dim3((uint32_t)((n_words + 2047) / 2048)), dim3(256), 0, st, d_row,
-                       (uint32_t)n_words, d_group, row_in_group, d_tally);
+    hipLaunchKernelGGL(tally_scatter_row_kernel, dim3((uint32_t)((n_words + 2047) / 2048)), dim3(256), 0, st, row,
+                       (uint32_t)n_words, bed_mode, tail_mask, d_group, row_in_group, d_tally);
     return hipGetLastError();
 }
 
@@ -285,24 +303,6 @@ hipError_t launch_interleave_rows(hipStream_t st, const uint32_t *d_src, uint64_
     (void)hipGetLastError();
     hipLaunchKernelGGL(interleave_rows_kernel, dim3((n_words + 255) / 256, (uint32_t)groups), dim3(256), 0,
                        st, d_src, src_stride_words, k, n_words, tail_mask, d_mode, d_dst, stride_words);
-    return hipGetLastError();
-}
-
-// one .bed row in place -> native codes (nps_push_bed staging)
-__global__ __launch_bounds__(256) void bed_recode_row_kernel(uint32_t *__restrict__ row, uint32_t n_words,
-                                                             uint32_t tail_mask, int effect_a1) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c < n_words) row[c] = bed_recode(row[c], effect_a1 != 0, c, n_words, tail_mask);
-}
-
-hipError_t launch_bed_recode_row(hipStream_t st, uint32_t *d_row, uint64_t n_samples, int effect_a1) {
-    if (n_samples == 0) return hipSuccess;
-    const uint32_t n_words = (uint32_t)words_for(n_samples);
-    const uint32_t rem = (uint32_t)(n_samples & 15);
-    const uint32_t tail_mask = rem ? ((1u << (2 * rem)) - 1u) : 0xffffffffu;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(bed_recode_row_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, d_row, n_words,
-                       tail_mask, effect_a1);
     return hipGetLastError();
 }
 
