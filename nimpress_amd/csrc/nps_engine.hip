@@ -1796,13 +1796,13 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
     if (def->n_desc == 0) return NPS_OK;
     HIP_TRY(hipSetDevice(m->device));
     const MultiPlan pl = multi_plan(m->n, def->n_desc, m->S, m->cus);
-    if (pl.table_bytes() > m->table_cap) {
+    if (pl.table_bytes() + pl.flag_bytes() > m->table_cap) {
         HIP_TRY(hipStreamSynchronize(m->stream));
         (void)hipFree(m->d_table);
         m->d_table = nullptr;
         m->table_cap = 0;
-        HIP_TRY(hipMalloc(&m->d_table, pl.table_bytes()));
-        m->table_cap = pl.table_bytes();
+        HIP_TRY(hipMalloc(&m->d_table, pl.table_bytes() + pl.flag_bytes()));
+        m->table_cap = pl.table_bytes() + pl.flag_bytes();
     }
     if (pl.partial_elems() > m->partial_cap) {
         HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1821,7 +1821,8 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
     HIP_TRY(hipEventRecord(m->ev[1], m->stream));
     if (m->n)
         HIP_TRY(launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial, m->d_state,
-                                  m->coarse_missing ? 1 : 0));
+                                  m->coarse_missing ? 1 : 0, co->d_row_tally + cohort_row0, def->n_desc,
+                                  reinterpret_cast<uint32_t *>(static_cast<char *>(m->d_table) + pl.table_bytes())));
     HIP_TRY(hipEventRecord(m->ev[2], m->stream));
     HIP_TRY(launch_multi_fold(m->stream, pl, m->d_partial, m->n, m->S, def->d_F, m->d_part, m->have_sums ? 0 : 1,
                               m->d_state));

@@ -220,6 +220,7 @@ struct MultiPlan {
     uint64_t n_groups = 0;
     uint32_t n_sb = 0, tiles = 0, sb_per_chunk = 0, n_chunks = 0;
     uint64_t table_bytes() const { return (uint64_t)n_sb * 4 * NT * 2 * 64 * 16; }
+    uint64_t flag_bytes() const { return (uint64_t)n_sb * 4; }  // one word per superblock, behind the tables
     uint64_t partial_elems() const { return (uint64_t)n_chunks * n_groups * 32 * NT * 32; }
 };
 MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus);
@@ -228,7 +229,8 @@ hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally
                                uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
                                void *d_table, void *d_state, int coarse_missing);
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing);
+                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing,
+                             const unsigned long long *d_tally, uint64_t n_rows, uint32_t *d_sbflag);
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state);
 hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,

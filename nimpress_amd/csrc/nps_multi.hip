@@ -325,6 +325,24 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
     }
 }
 
+// one flag per superblock of the call: does any of its 128 rows have a missing genotype at all (the packer's
+// whole-row tallies know)?  Where none has, the is-missing matrix of the superblock is zero and the product
+// kernel skips its MFMAs -- cohorts of imputed hard calls have no missing genotypes anywhere.
+__global__ __launch_bounds__(256) void multi_sbflag_kernel(const unsigned long long *__restrict__ tally, uint64_t n_rows,
+                                                           uint32_t n_sb, uint32_t *__restrict__ flag) {
+    const uint32_t sb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sb >= n_sb) return;
+    const int lane = threadIdx.x & 63;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint64_t r = (uint64_t)sb * 128 + k * 64 + lane;
+        any |= r < n_rows && (tally[r] >> 32) != 0;
+    }
+    const bool w = __any(any);
+    if (lane == 0) flag[sb] = w ? 1u : 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // The product.  Workgroup = WAVES waves; wave v owns GW groups of 32 samples; the workgroup walks the
 // superblocks of its row chunk.  Everything the loop reads comes in by LDS-DMA (global_load_lds_dwordx4:
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
                                                           uint64_t sb_first, uint32_t n_sb, uint32_t sb_per_chunk,
                                                           const uint4 *__restrict__ table,
                                                           int32_t *__restrict__ partial,
-                                                          const MultiState *__restrict__ state, int m_low_always) {
+                                                          const MultiState *__restrict__ state, int m_low_always,
+                                                          const uint32_t *__restrict__ sb_has_missing) {
     constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock: 1024 (NT = 2) or 512
     constexpr int kPieces = kTab / 64;     // 1 KiB pieces of a superblock's tables
     constexpr int kPW = kPieces >= WAVES ? kPieces / WAVES : 1;  // table DMAs per wave and step
@@ -444,6 +463,7 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
             if (!(NPS_MULTI_DIAG & 4)) dma_table(sb + kStage, buf ^ 1, k);
             if (!(NPS_MULTI_DIAG & 1)) dma_units(sb + kStage, k);
             if (sb < sb_b) {
+                const bool has_m = sb_has_missing[sb] != 0;  // (uniform: a scalar load)
                 uint32_t miss[GW][4];  // bit 2f of a byte: field f is code 3
 #pragma unroll
                 for (int a = 0; a < GW; ++a)
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
 #pragma unroll
                         for (int a = 0; a < GW; ++a)
                             acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
-                        if (t == 0 || m_low) {
+                        if (has_m && (t == 0 || m_low)) {
                             const uint4 bm = lds.tab[buf][k][((f * NT + t) * 2 + 1) * 64 + lane];
                             const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
 #pragma unroll
@@ -600,19 +620,21 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
 }
 
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing) {
+                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing,
+                             const unsigned long long *d_tally, uint64_t n_rows, uint32_t *d_sbflag) {
     if (pl.n_sb == 0 || pl.n_groups == 0) return hipSuccess;
     (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_sbflag_kernel, dim3((pl.n_sb + 3) / 4), dim3(256), 0, st, d_tally, n_rows, pl.n_sb, d_sbflag);
     constexpr int GW = NPS_MULTI_GW, WAVES = 32 / GW;
     const dim3 grid(pl.tiles, pl.n_chunks), block(64 * WAVES);
     if (pl.NT == 1)
         hipLaunchKernelGGL((multi_mfma_kernel<1, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
                            sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
-                           (const MultiState *)d_state, coarse_missing ? 0 : 1);
+                           (const MultiState *)d_state, coarse_missing ? 0 : 1, d_sbflag);
     else if (pl.NT == 2)
         hipLaunchKernelGGL((multi_mfma_kernel<2, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
                            sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
-                           (const MultiState *)d_state, coarse_missing ? 0 : 1);
+                           (const MultiState *)d_state, coarse_missing ? 0 : 1, d_sbflag);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -162,6 +162,40 @@ def test_multi_synth_cohort_and_row_chunks():
     co.close()
 
 
+@pytest.mark.parametrize("where", ["none", "first_half", "one_row"])
+def test_multi_superblocks_without_missing(where):
+    """superblocks (128 rows) in which no sample is missing skip the is-missing matrix: a cohort with no missing
+    genotype at all, one whose first two superblocks have none, one with a single missing-bearing row"""
+    n, m, S = 700, 512, 8
+    rng = np.random.default_rng(41)
+    eaf_c = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = np.zeros(m)
+    if where == "first_half":
+        miss[256:] = rng.uniform(0.0, 0.08, 256)
+    elif where == "one_row":
+        miss[300] = 0.3
+    th, tm, tmi = refcpu.hwe_thresholds(eaf_c, miss)
+    _, _, _, _, descs = make_case(n, m, S, 3)
+    codes = refcpu.synth_rows(n, 0, m, 5, th, tm, tmi)
+    co = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
+    co.synth(0, 5, th, tm, tmi)
+    nm, _ = co.row_tallies()
+    assert (nm[:256] == 0).all() and ((nm > 0).any() == (where != "none"))
+    for kw in (PARAM_GRID[0], PARAM_GRID[4]):
+        msc = capi.MultiScorer(n, capi.make_params(**kw), S)
+        mdef = capi.MultiDef(descs)
+        msc.score_cohort(co, mdef)
+        got, nloci = msc.finish(np.zeros(S))
+        ref, ref_nloci = oracle_scores(codes, n, descs, kw, np.zeros(S))
+        assert np.array_equal(nloci.astype(np.int64), ref_nloci)
+        for s in range(S):
+            keep = descs[s]["kind"] != capi.ROW_NOT_IN_SCORE
+            assert rel_err(got[s], ref[s], float(np.sum(np.abs(descs[s]["beta"][keep]))), int(ref_nloci[s])) <= REL_TOL, s
+        msc.close()
+        mdef.close()
+    co.close()
+
+
 def test_multi_equals_single_score_path_medium():
     """8 definitions in one pass == the single-score fused kernel run 8 times, 60 000 samples x 8 192 rows"""
     n, m, S, seed = 60_000, 8192, 8, 20250104

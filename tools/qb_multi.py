@@ -10,6 +10,7 @@ ap.add_argument("--variants", type=int, default=1_000_000)
 ap.add_argument("--scores", type=int, default=8)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--zero", action="store_true", help="all genotypes 0 (clock / power experiment)")
+ap.add_argument("--no-missing", action="store_true", help="a cohort without missing genotypes")
 ap.add_argument("--missing-bits", type=int, default=0, help="nps_multi_set_missing_weight_bits (32 or 56)")
 a = ap.parse_args()
 import torch
@@ -20,6 +21,8 @@ _, eaf, miss = bench.synth_score(m, seed)
 th, tm, tmi = bench.hwe_thresholds(eaf, miss)
 if a.zero:
     th[:] = 0; tm[:] = 0; tmi[:] = 0
+if a.no_missing:
+    tmi[:] = 0
 t0 = time.perf_counter()
 co = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
 for x in range(0, m, 1 << 15):
