@@ -1813,8 +1813,7 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
         m->partial_cap = pl.partial_elems();
     }
     multi_drain_timing(m);  // (the events are about to be re-recorded)
-    // unused columns of the last tile and the rows that pad the last superblock stay zero
-    HIP_TRY(hipMemsetAsync(m->d_table, 0, pl.table_bytes(), m->stream));
+    // (multi_params_kernel writes every fragment of the table, zeros for unused columns and padding rows)
     HIP_TRY(hipEventRecord(m->ev[0], m->stream));
     HIP_TRY(launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
                                 dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0));

@@ -226,24 +226,16 @@ static __host__ __device__ __forceinline__ int multi_col(int NT, int s, int d /*
     return d >= 3 && d < 7 ? 4 * s + d - 3 : 32 + 4 * s + (d == 7 ? 3 : d);
 }
 
-static __device__ __forceinline__ void put_digits(int8_t *__restrict__ table, int NT, uint64_t r, int s,
-                                                  int dm, long long V, int flag, bool coarse) {
-    const uint64_t sb = r >> 7;
-    const int h = (int)((r >> 6) & 1), w = (int)((r >> 4) & 3), b = (int)((r >> 2) & 3), f = (int)(r & 3);
+// the eight digit bytes of one weight (seven signed base-256 digits of V x 128 / 4^f, then the flag)
+static __device__ __forceinline__ void weight_digits(long long V, int dm, int f, int flag, bool coarse, int (&d)[8]) {
     V *= (dm == 1 || f == 3) ? 128 : (128 >> (2 * f));
     if (coarse) V = ((V + (1ll << 23)) >> 24) << 24;  // nearest multiple of 256^3 (digits 0..2 become zero)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int d;
-        if (k < 7) {
-            d = (int)((V + 128) & 255) - 128;
-            V = (V - d) >> 8;
-        } else {
-            d = flag;
-        }
-        const int c = multi_col(NT, s, k), t = c >> 5, lane = (c & 31) + 32 * h;
-        table[((((sb * 4 + f) * NT + t) * 2 + dm) * 64 + lane) * 16 + 4 * w + b] = (int8_t)d;
+    for (int k = 0; k < 7; ++k) {
+        d[k] = (int)((V + 128) & 255) - 128;
+        V = (V - d[k]) >> 8;
     }
+    d[7] = flag;
 }
 
 struct MultiState {          // per score, on the device
@@ -255,73 +247,115 @@ struct MultiState {          // per score, on the device
     double pad[2];
 };
 
+// One thread per (superblock, row half h, field f, score slot s): the 16 rows 128 sb + 64 h + 16 w + 4 b + f
+// (k = 4 w + b) whose digits make ONE 16-byte MFMA fragment per digit column and matrix -- 16 whole-fragment stores
+// instead of 256 scattered bytes.  Score slots S .. 4 NT - 1 (unused columns) and rows past n_desc get zeros, so
+// the table needs no memset.
 __global__ __launch_bounds__(256) void multi_params_kernel(
     const unsigned long long *__restrict__ tally /* first cohort row of this call */,
     const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int NT, uint64_t n_samples,
-    DevParams p, const int *__restrict__ F /* [S] */, int8_t *__restrict__ table, MultiState *__restrict__ state,
-    int coarse_missing) {
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    DevParams p, const int *__restrict__ F /* [S] */, uint4 *__restrict__ table, MultiState *__restrict__ state,
+    int coarse_missing, uint32_t n_sb) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // (sb, h, f): f fastest, so 4 threads read 4 adjacent rows
     const int s = blockIdx.y;
-    if (j >= n_desc) return;
-    const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
+    if (u >= (uint64_t)n_sb * 8) return;
+    const uint64_t sb = u >> 3;
+    const int h = (int)((u >> 2) & 1), f = (int)(u & 3);
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
-    int used = 0, has_const = 0;
-    const bool rie = d.ref_is_effect != 0;
-    auto locus = [&]() {  // imputeLocusDosages nimpress.nim:417-447
-        if (p.imp_locus == NPS_LOCUS_IGNORE) return;
-        used = 1;
-        has_const = 1;
-        cst = (p.imp_locus == NPS_LOCUS_PS ? d.eaf * 2.0 : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0) : nan) *
-              d.beta;
-    };
-    if (d.kind == NPS_ROW_PRESENT) {
-        const unsigned long long t = tally[j];
-        const uint64_t nmiss = t >> 32, neff = t & 0xffffffffull, ngen = n_samples - nmiss;
-        const double missingrate = (double)nmiss / (double)n_samples;
-        if (missingrate > p.max_missing_rate) {  // :565-571
-            locus();
-        } else {  // :582-585 -> imputeSampleDosages :450-481
-            used = 1;
-            double imp;
-            switch (p.imp_sample) {
-            case NPS_SAMPLE_PS: imp = d.eaf * 2.0; break;
-            case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
-            case NPS_SAMPLE_FAIL: imp = nan; break;
-            default:
-                if ((double)ngen >= p.min_cs)
-                    imp = (double)neff / (double)ngen;
-                else
-                    imp = p.imp_sample == NPS_SAMPLE_INT_PS ? d.eaf * 2.0 : nan;
-                break;
-            }
-            wD = d.beta;
-            // a missing genotype has code 3: it already got 3 x beta from the dosage matrix
-            wM = imp * d.beta - 3.0 * d.beta;
-        }
-    } else if (d.kind == NPS_ROW_ABSENT) {  // :536-551
-        if (p.imp_missing == NPS_MISSING_HOMREF) {
+    const int fx = s < S ? F[s] : 0;
+    uint32_t frag[2][8][4];  // [matrix][digit][word w]: byte b of word w = row k = 4 w + b
+#pragma unroll
+    for (int dm = 0; dm < 2; ++dm)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) frag[dm][k][w] = 0;
+    unsigned long long n_used = 0, c_lo = 0, c_hi = 0;
+    bool c_nan = false, any_m_nan = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t j = sb * 128 + 64 * h + 16 * (k >> 2) + 4 * (k & 3) + f;
+        if (s >= S || j >= n_desc) continue;
+        const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
+        double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
+        int used = 0, has_const = 0;
+        const bool rie = d.ref_is_effect != 0;
+        auto locus = [&]() {  // imputeLocusDosages nimpress.nim:417-447
+            if (p.imp_locus == NPS_LOCUS_IGNORE) return;
             used = 1;
             has_const = 1;
-            cst = (rie ? 2.0 : 0.0) * d.beta;
+            cst = (p.imp_locus == NPS_LOCUS_PS ? d.eaf * 2.0 : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0) : nan) *
+                  d.beta;
+        };
+        if (d.kind == NPS_ROW_PRESENT) {
+            const unsigned long long t = tally[j];
+            const uint64_t nmiss = t >> 32, neff = t & 0xffffffffull, ngen = n_samples - nmiss;
+            const double missingrate = (double)nmiss / (double)n_samples;
+            if (missingrate > p.max_missing_rate) {  // :565-571
+                locus();
+            } else {  // :582-585 -> imputeSampleDosages :450-481
+                used = 1;
+                double imp;
+                switch (p.imp_sample) {
+                case NPS_SAMPLE_PS: imp = d.eaf * 2.0; break;
+                case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
+                case NPS_SAMPLE_FAIL: imp = nan; break;
+                default:
+                    if ((double)ngen >= p.min_cs)
+                        imp = (double)neff / (double)ngen;
+                    else
+                        imp = p.imp_sample == NPS_SAMPLE_INT_PS ? d.eaf * 2.0 : nan;
+                    break;
+                }
+                wD = d.beta;
+                // a missing genotype has code 3: it already got 3 x beta from the dosage matrix
+                wM = imp * d.beta - 3.0 * d.beta;
+            }
+        } else if (d.kind == NPS_ROW_ABSENT) {  // :536-551
+            if (p.imp_missing == NPS_MISSING_HOMREF) {
+                used = 1;
+                has_const = 1;
+                cst = (rie ? 2.0 : 0.0) * d.beta;
+            }
+        } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
+            locus();
+        }  // else: the row is not part of this score
+        const bool m_nan = wM != wM;
+        int dd[8], dmm[8];
+        weight_digits(llrint(ldexp(wD, fx)), 0, f, 0, false, dd);
+        weight_digits(m_nan ? 0ll : llrint(ldexp(wM, fx)), 1, f, m_nan ? 1 : 0, coarse_missing && NT == 2, dmm);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            frag[0][q][k >> 2] |= (uint32_t)(dd[q] & 255) << (8 * (k & 3));
+            frag[1][q][k >> 2] |= (uint32_t)(dmm[q] & 255) << (8 * (k & 3));
         }
-    } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
-        locus();
-    }  // else: the row is not part of this score
-    const int f = F[s];
-    const bool m_nan = wM != wM;
-    put_digits(table, NT, j, s, 0, llrint(ldexp(wD, f)), 0, false);
-    put_digits(table, NT, j, s, 1, m_nan ? 0ll : llrint(ldexp(wM, f)), m_nan ? 1 : 0, coarse_missing && NT == 2);
-    if (m_nan) atomicOr(&state[0].m_low, 1ull);
-    if (used) atomicAdd(&state[s].nloci, 1ull);
-    if (has_const) {
-        if (cst != cst) {
-            atomicOr(&state[s].const_nan, 1ull);
-        } else {
-            const long long V = llrint(ldexp(cst, f));  // exact, order-independent sums of both halves
-            atomicAdd((unsigned long long *)&state[s].const_lo, (unsigned long long)(V & 0xffffffffll));
-            atomicAdd((unsigned long long *)&state[s].const_hi, (unsigned long long)(V >> 32));
+        any_m_nan |= m_nan;
+        n_used += used;
+        if (has_const) {
+            if (cst != cst) {
+                c_nan = true;
+            } else {
+                const long long V = llrint(ldexp(cst, fx));  // exact, order-independent sums of both halves
+                c_lo += (unsigned long long)(V & 0xffffffffll);
+                c_hi += (unsigned long long)(V >> 32);
+            }
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = multi_col(NT, s, q), t = c >> 5, lane = (c & 31) + 32 * h;
+#pragma unroll
+        for (int dm = 0; dm < 2; ++dm)
+            table[(((sb * 4 + f) * NT + t) * 2 + dm) * 64 + lane] =
+                make_uint4(frag[dm][q][0], frag[dm][q][1], frag[dm][q][2], frag[dm][q][3]);
+    }
+    if (s >= S) return;
+    if (any_m_nan) atomicOr(&state[0].m_low, 1ull);
+    if (n_used) atomicAdd(&state[s].nloci, n_used);
+    if (c_nan) atomicOr(&state[s].const_nan, 1ull);
+    if (c_lo | c_hi) {
+        atomicAdd((unsigned long long *)&state[s].const_lo, c_lo);
+        atomicAdd((unsigned long long *)&state[s].const_hi, c_hi);
     }
 }
 
@@ -592,10 +626,11 @@ hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally
                                uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
                                void *d_table, void *d_state, int coarse_missing) {
     if (n_desc == 0 || S == 0) return hipSuccess;
+    const uint32_t n_sb = (uint32_t)((n_desc + 127) / 128);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)((n_desc + 255) / 256), (uint32_t)S), dim3(256), 0, st,
-                       d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (int8_t *)d_table, (MultiState *)d_state,
-                       coarse_missing);
+    hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)(((uint64_t)n_sb * 8 + 255) / 256), (uint32_t)(4 * NT)),
+                       dim3(256), 0, st, d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (uint4 *)d_table,
+                       (MultiState *)d_state, coarse_missing, n_sb);
     return hipGetLastError();
 }
 
