@@ -302,7 +302,9 @@ int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_
  * fewer matrix instructions.  NaN imputation values
  * (imp-sample fail / int_fail below --mincs) are exact in both modes.  Applies to the following calls. */
 int nps_multi_set_missing_weight_bits(nps_multi *m, int bits);
-/* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset */
+/* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset.
+ * Errors as for nps_score_cohort_def: refused calls leave the context unchanged; a HIP failure during the pass
+ * makes every later call return NPS_E_STATE until nps_multi_reset. */
 int nps_score_cohort_multi(nps_multi *m, const nps_cohort *c, uint64_t cohort_row0, const nps_multidef *def);
 /* scores_out: [n_scores][n_samples]; nloci_out: [n_scores]; offsets: [n_scores]  (nimpress.nim:643-649) */
 int nps_multi_finish(nps_multi *m, const double *offsets, double *scores_out, uint64_t *nloci_out);

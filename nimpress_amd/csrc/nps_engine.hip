@@ -1687,6 +1687,7 @@ struct nps_multi {
     double ms[3] = {0.0, 0.0, 0.0};  // params, product, fold of all calls since the last reset
     bool timed = false;
     bool coarse_missing = false;     // nps_multi_set_missing_weight_bits(32)
+    bool broken = false;             // a HIP call failed between the first and the last launch of a pass
 };
 
 // add the device time of the last call (if its events have not been read yet) to the running totals
@@ -1775,6 +1776,7 @@ extern "C" int nps_multi_reset(nps_multi *m, const nps_params *params) {
     HIP_TRY(hipSetDevice(m->device));
     multi_drain_timing(m);
     HIP_TRY(hipMemsetAsync(m->d_state, 0, multi_state_bytes() * NPS_MULTI_MAX_SCORES, m->stream));
+    m->broken = false;
     m->have_sums = false;
     m->ms[0] = m->ms[1] = m->ms[2] = 0.0;
     return NPS_OK;
@@ -1783,6 +1785,7 @@ extern "C" int nps_multi_reset(nps_multi *m, const nps_params *params) {
 extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64_t cohort_row0,
                                       const nps_multidef *def) {
     if (!m || !co || !def) return fail(NPS_E_INVAL, "ctx, cohort or definitions is NULL");
+    if (m->broken) return fail(NPS_E_STATE, "an earlier pass failed on the device: nps_multi_reset first");
     if (co->format != NPS_FMT_GT2M) return fail(NPS_E_INVAL, "nps_score_cohort_multi needs a NPS_FMT_GT2M cohort");
     if (co->device != m->device || def->device != m->device)
         return fail(NPS_E_INVAL, "cohort / definitions / context on different devices");
@@ -1813,19 +1816,35 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
         m->partial_cap = pl.partial_elems();
     }
     multi_drain_timing(m);  // (the events are about to be re-recorded)
+    // Everything that can be refused has been checked and allocated.  From here a HIP failure leaves the running
+    // sums and counts of the context undefined: it is marked broken (NPS_E_STATE until nps_multi_reset).
     // (multi_params_kernel writes every fragment of the table, zeros for unused columns and padding rows)
-    HIP_TRY(hipEventRecord(m->ev[0], m->stream));
-    HIP_TRY(launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
-                                dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0));
-    HIP_TRY(hipEventRecord(m->ev[1], m->stream));
-    if (m->n)
-        HIP_TRY(launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial, m->d_state,
+    auto run = [&]() -> hipError_t {
+        hipError_t e = hipEventRecord(m->ev[0], m->stream);
+        if (e != hipSuccess) return e;
+        e = launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
+                                dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(m->ev[1], m->stream);
+        if (e != hipSuccess) return e;
+        if (m->n) {
+            e = launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial, m->d_state,
                                   m->coarse_missing ? 1 : 0, co->d_row_tally + cohort_row0, def->n_desc,
-                                  reinterpret_cast<uint32_t *>(static_cast<char *>(m->d_table) + pl.table_bytes())));
-    HIP_TRY(hipEventRecord(m->ev[2], m->stream));
-    HIP_TRY(launch_multi_fold(m->stream, pl, m->d_partial, m->n, m->S, def->d_F, m->d_part, m->have_sums ? 0 : 1,
-                              m->d_state));
-    HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+                                  reinterpret_cast<uint32_t *>(static_cast<char *>(m->d_table) + pl.table_bytes()));
+            if (e != hipSuccess) return e;
+        }
+        e = hipEventRecord(m->ev[2], m->stream);
+        if (e != hipSuccess) return e;
+        e = launch_multi_fold(m->stream, pl, m->d_partial, m->n, m->S, def->d_F, m->d_part, m->have_sums ? 0 : 1,
+                              m->d_state);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(m->ev[3], m->stream);
+    };
+    const hipError_t e = run();
+    if (e != hipSuccess) {
+        m->broken = true;
+        return fail(NPS_E_HIP, "nps_score_cohort_multi: %s (context needs nps_multi_reset)", hipGetErrorString(e));
+    }
     m->have_sums = true;
     m->timed = true;
     return NPS_OK;
@@ -1834,6 +1853,7 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
 static int multi_finish_common(nps_multi *m, const double *offsets, double *d_dst, double *h_scores_out,
                                uint64_t *nloci_out) {
     if (!offsets) return fail(NPS_E_INVAL, "offsets is NULL");
+    if (m->broken) return fail(NPS_E_STATE, "an earlier pass failed on the device: nps_multi_reset first");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemcpyAsync(m->d_offsets, offsets, sizeof(double) * m->S, hipMemcpyHostToDevice, m->stream));
     HIP_TRY(launch_multi_finish(m->stream, m->d_part, m->n, m->S, m->d_state, m->d_offsets, m->have_sums ? 1 : 0,
