@@ -418,10 +418,7 @@ static __device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byt
 }
 
 #ifndef NPS_MULTI_GW
-#define NPS_MULTI_GW 2  // sample groups per wave; the workgroup has 32 / GW waves
-#endif
-#ifndef NPS_MULTI_DIAG
-#define NPS_MULTI_DIAG 0  // experiment builds: 1 no unit loads in the loop, 4 no table staging
+#define NPS_MULTI_GW 2  // sample groups per wave; the workgroup has 32 / GW waves (-DNPS_MULTI_GW=4: measured equal)
 #endif
 template <int NT, int GW, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__restrict__ units, uint64_t n_groups,
@@ -494,8 +491,8 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
             }
             // the ring slot is free again once the read has returned
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(NPS_MULTI_DIAG & 4)) dma_table(sb + kStage, buf ^ 1, k);
-            if (!(NPS_MULTI_DIAG & 1)) dma_units(sb + kStage, k);
+            dma_table(sb + kStage, buf ^ 1, k);
+            dma_units(sb + kStage, k);
             if (sb < sb_b) {
                 const bool has_m = sb_has_missing[sb] != 0;  // (uniform: a scalar load)
                 uint32_t miss[GW][4];  // bit 2f of a byte: field f is code 3
