@@ -1575,11 +1575,9 @@ extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     HIP_TRY(hipSetDevice(dst->device));
     HIP_TRY(hipDeviceSynchronize());
     if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;
+    // units and, from the same tiles, the whole-row tallies (tallyAlleles nimpress.nim:32-47)
     HIP_TRY(launch_convert_gt2m(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
-                                src->n_rows, dst->d_data));
-    // whole-row tallies, computed while packing (tallyAlleles nimpress.nim:32-47; same kernel as the two-pass path)
-    HIP_TRY(launch_tally_packed(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
-                                src->n_rows, dst->d_row_tally));
+                                src->n_rows, dst->d_data, dst->d_row_tally));
     HIP_TRY(hipDeviceSynchronize());
     return NPS_OK;
 }

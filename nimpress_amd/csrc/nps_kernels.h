@@ -212,9 +212,9 @@ static inline uint64_t gt2m_bytes(uint64_t n_samples, uint64_t n_rows) {
 hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t row0, uint64_t gen_row0,
                              uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het, const uint32_t *d_t_hom,
                              const uint32_t *d_t_miss, unsigned long long *d_tally);
-// a whole 2-bit row-major cohort (plain order) -> units
+// a whole 2-bit row-major cohort (plain order) -> units and whole-row tallies (nmissing << 32 | neffect)
 hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
-                               uint64_t n_samples, uint64_t n_rows, void *d_units);
+                               uint64_t n_samples, uint64_t n_rows, void *d_units, unsigned long long *d_tally);
 struct MultiPlan {
     int NT = 0, GW = 0;          // column tiles of 32 (4 scores each); sample groups per wave
     uint64_t n_groups = 0;

@@ -128,36 +128,57 @@ __global__ __launch_bounds__(256) void synth_tally_kernel(unsigned long long *__
 }
 
 // rows [0, n_rows) of a 2-bit row-major cohort (group-interleaved device layout of nps_kernels.h) ->
-// units of superblocks [0, ceil(n_rows/128)).  One thread per output lane; a one-time repack.
-__global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint32_t *__restrict__ src,
-                                                           uint64_t src_stride_words, uint64_t n_samples,
-                                                           uint64_t n_rows, uint4 *__restrict__ units,
-                                                           uint64_t n_groups) {
-    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t sb = blockIdx.y;
-    if (u >= n_groups * 64) return;
-    const uint64_t g = u >> 6;
-    const uint32_t lane = (uint32_t)(u & 63);
-    const uint64_t s = g * 32 + (lane & 31);
-    const uint32_t h = lane >> 5;
-    uint32_t out[4] = {0, 0, 0, 0};
-    if (s < n_samples) {
-        const int pb = plane_bit((int)(s & 15));
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t word = 0;
-            for (int j = 0; j < 16; ++j) {
-                const uint64_t r = sb * 128 + 64 * h + 16 * w + j;
-                if (r < n_rows) {
-                    const uint32_t x = src[g4_word_index(r, s >> 4, src_stride_words)];
-                    const uint32_t c = ((x >> pb) & 1u) | (((x >> (pb + 4)) & 1u) << 1);
-                    word |= m_code(c) << (2 * j);
-                }
-            }
-            out[w] = word;
-        }
+// units of superblocks [0, ceil(n_rows/128)).  A one-time repack.  Workgroup = one superblock x 8 word columns
+// (128 samples = 4 groups): the 128 x 8 word tile comes in as 32 row groups x 128 contiguous bytes, goes through
+// LDS, and every thread assembles one output lane (64 rows of one sample) from it.
+__global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint4 *__restrict__ src /* first row group */,
+                                                           uint64_t src_stride_words, uint64_t n_row_groups,
+                                                           uint64_t n_words, uint4 *__restrict__ units,
+                                                           uint64_t n_groups,
+                                                           unsigned long long *__restrict__ tally /* zeroed */) {
+    __shared__ uint32_t tile[128][9];  // [row][word column], padded
+    const int t = threadIdx.x;
+    const uint64_t sb = blockIdx.y, c0 = (uint64_t)blockIdx.x * 8;
+    {
+        const uint64_t rg = sb * 32 + (t >> 3), c = c0 + (t & 7);
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (rg < n_row_groups && c < n_words) q = src[rg * src_stride_words + c];
+        const int r = 4 * (t >> 3);
+        tile[r][t & 7] = q.x, tile[r + 1][t & 7] = q.y, tile[r + 2][t & 7] = q.z, tile[r + 3][t & 7] = q.w;
     }
-    units[sb * n_groups * 64 + u] = make_uint4(out[0], out[1], out[2], out[3]);
+    __syncthreads();
+    {   // whole-row tallies (tallyAlleles, nimpress.nim:32-47) while the tile is here: two threads per row
+        const int r = t >> 1;
+        uint32_t cw = 0, cm = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t w = tile[r][4 * (t & 1) + c];
+            cw += __popc(w);
+            cm += __popc((w >> 4) & ~w & 0x0F0F0F0Fu);  // (nps_kernels.hip tally_word)
+        }
+        cw += __shfl_xor(cw, 1, 64);
+        cm += __shfl_xor(cm, 1, 64);
+        if ((t & 1) == 0 && (cw | cm))
+            atomicAdd(&tally[sb * 128 + r], ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm));
+    }
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (t >> 6);
+    if (g >= n_groups) return;
+    const int lane = t & 63, h = lane >> 5;
+    const int sl = 32 * (t >> 6) + (lane & 31);  // sample of the tile
+    const int cc = sl >> 4, pb = plane_bit(sl & 15);
+    uint32_t out[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t x = tile[64 * h + 16 * w + j][cc] >> pb;  // low code bit in bit 0, high in bit 4
+            const uint32_t c = (x & 1u) | ((x >> 3) & 2u);
+            word |= m_code(c) << (2 * j);
+        }
+        out[w] = word;
+    }
+    units[(sb * n_groups + g) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t row0, uint64_t gen_row0,
@@ -185,16 +206,20 @@ hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, 
 }
 
 hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
-                               uint64_t n_samples, uint64_t n_rows, void *d_units) {
+                               uint64_t n_samples, uint64_t n_rows, void *d_units, unsigned long long *d_tally) {
     if (n_rows == 0 || n_samples == 0) return hipSuccess;
     const uint64_t n_groups = (n_samples + 31) / 32, n_sb = (n_rows + 127) / 128;
+    const uint64_t n_words = (n_samples + 15) / 16, n_row_groups = (n_rows + 3) / 4;
+    // (the tally array of a GT2M cohort is padded to whole superblocks: rows past n_rows read as zeros and add nothing)
+    hipError_t e = hipMemsetAsync(d_tally, 0, sizeof(unsigned long long) * n_rows, st);
+    if (e != hipSuccess) return e;
     (void)hipGetLastError();
     for (uint64_t sb = 0; sb < n_sb; sb += 65535) {
         const uint64_t k = std::min<uint64_t>(65535, n_sb - sb);
-        const uint64_t rows_left = n_rows - sb * 128;
-        hipLaunchKernelGGL(convert_gt2m_kernel, dim3((uint32_t)((n_groups * 64 + 255) / 256), (uint32_t)k), dim3(256),
-                           0, st, d_src + (sb * 32) * src_stride_words * 4, src_stride_words, n_samples, rows_left,
-                           (uint4 *)d_units + sb * n_groups * 64, n_groups);
+        hipLaunchKernelGGL(convert_gt2m_kernel, dim3((uint32_t)((n_words + 7) / 8), (uint32_t)k), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(d_src) + sb * 32 * src_stride_words, src_stride_words,
+                           n_row_groups - sb * 32, n_words, (uint4 *)d_units + sb * n_groups * 64, n_groups,
+                           d_tally + sb * 128);
     }
     return hipGetLastError();
 }
