@@ -10,7 +10,7 @@
 // MFMA runs at the vector rate and would need every genotype converted to a double.  Instead:
 //
 //   * the per-row weights are turned into FIXED-POINT integers (49 bits, times a power of two <= 128 that
-//     belongs to the operand extraction, see put_digits) and split into seven signed base-256 digits:
+//     belongs to the operand extraction, see weight_digits) and split into seven signed base-256 digits:
 //     w = sum_k d_k 256^k / 2^(F+7).  code (int8) x digit (int8) accumulated in int32 by
 //     v_mfma_i32_32x32x32_i8 is EXACT integer arithmetic, independent of the summation order; the seven
 //     digit sums of a sample are recombined in float64 at the very end.  The only error is the
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void multi_sbflag_kernel(const unsigned long l
 //   * the wave's own units (GW x 1 KiB per superblock): a private ring, kStage superblocks ahead.
 // The wave counts its DMAs itself (s_waitcnt vmcnt(N), in order): per step its table pieces, then GW units.
 // Per superblock and group: 60 VALU ops make the 8 operand register sets (4 fields x {dosage, is-missing};
-// see put_digits) for 4 x NT x 2 MFMAs.
+// see weight_digits) for 4 x NT x 2 MFMAs.
 //
 // The vector work of one wave overlaps the matrix work of the other three waves of its SIMD only while
 // the waves are out of step; a workgroup barrier puts them back in step, hence kStage > 1.
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restri
         double v = (double)sum[j][6];
 #pragma unroll
         for (int k = 5; k >= 0; --k) v = v * 256.0 + (double)sum[j][k];
-        v = ldexp(v, -F[s] - 7);  // the digits are those of weight x 2^F x 128 (put_digits)
+        v = ldexp(v, -F[s] - 7);  // the digits are those of weight x 2^F x 128 (weight_digits)
         if (sum[j][7] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
         double *dst = part + (uint64_t)s * n_samples + i;
         *dst = overwrite ? v : *dst + v;
