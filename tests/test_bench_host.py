@@ -30,3 +30,43 @@ def test_bench_spawns_its_ranks_without_a_launcher():
     assert r.returncode != 0
     assert r.stderr.count("needs an MI355X") == 2 or "NPS_E_NODEVICE" in r.stderr, r.stderr[-2000:]
     assert "must be launched" not in r.stderr
+
+
+def _rehearse(world, extra):
+    """N ranks of tests/rehearse_bench.py (a fake libnps, CPU tensors, gloo): bench.main() of every rank, unchanged"""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rehearse_bench.py"), "--gpus",
+                                       str(world), "--steps", "2", "--warmup", "1", "--samples", "4000", "--variants",
+                                       "640", "--no-extras", "--no-cpu-baseline"] + extra,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for so, _ in outs[1:] for ln in so.splitlines())
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_weak_scaling_rehearsal():
+    d = _rehearse(2, [])
+    assert d["rehearsal"] and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["parallelism"].startswith("score-sharded x2") and d["config"]["nloci"] == 640
+    assert "cpu_baseline" not in d and "secondary" not in d and d["vs_baseline"] is None
+
+
+def test_bench_three_ranks_strong_scaling_rehearsal():
+    d = _rehearse(3, ["--scaling", "strong"])
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["nloci"] == 640                      # the shards' nloci, all-reduced
+    # every rank contributed partial sums of 1.0: 3.0 / (2 x 640) after the all-reduce and the normalisation
+    assert abs(d["rehearsal_normalised"][0] - 3.0 / 1280.0) < 1e-15 and d["rehearsal_normalised"][1] == 640
+    assert d["config"]["parallelism"].startswith("one score, rows sharded x3")
