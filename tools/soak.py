@@ -5,7 +5,9 @@ previous pass -- is a different number, not the same bits again); every pass mus
 scores and nloci for its definition (no float atomics, fixed combine order), no bounded wait may expire,
 and the fused result is compared with the two-pass kernels at the start.  Build with -DNPS_DIAGNOSTICS
 (tools/mkexp.sh) to have the DS kernel's partial sums poisoned with NaNs before every launch as well.
-    python tools/soak.py [--format ds] [--samples N] [--variants M] [--passes K]"""
+    python tools/soak.py [--format ds|multi] [--samples N] [--variants M] [--passes K]
+--format multi: the multi-score product kernel (LDS-DMA staging with hand-counted waits): two sets of 8
+definitions alternate, every pass bit-identical per set, set 0 checked against the single-score fused kernel."""
 import argparse
 import os
 import sys
@@ -27,6 +29,50 @@ a = ap.parse_args()
 n, m = a.samples, a.variants
 _, eaf, miss = bench.synth_score(m, 7)
 th, tm, tmi = bench.hwe_thresholds(eaf, miss)
+if a.format == "multi":
+    S = 8
+    co = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
+    gt = capi.Cohort(n, m)
+    for r0 in range(0, m, 1 << 15):
+        r1 = min(m, r0 + (1 << 15))
+        co.synth_at(r0, r0, 7, th[r0:r1], tm[r0:r1], tmi[r0:r1])
+        gt.synth_at(r0, r0, 7, th[r0:r1], tm[r0:r1], tmi[r0:r1])
+    sets = []
+    for j in range(2):
+        d = np.zeros((S, m), dtype=capi.ROW_DESC_DTYPE)
+        for s_ in range(S):
+            d[s_]["beta"] = np.round(np.random.default_rng(100 * j + s_).normal(0, 0.02 * (1 + j), m), 4)
+            d[s_]["eaf"] = eaf
+        sets.append((d, capi.MultiDef(d)))
+    msc = capi.MultiScorer(n, capi.make_params(), S)
+    out = torch.empty((S, n), dtype=torch.float64, device="cuda")
+    first = [None, None]
+    t0 = time.time()
+    for k in range(a.passes):
+        j = k & 1
+        msc.reset()
+        msc.score_cohort(co, sets[j][1])
+        nl = msc.finish_device(np.zeros(S), out.data_ptr())
+        cur = out.clone()
+        if first[j] is None:
+            first[j] = (cur, nl.copy())
+            if j == 0:
+                sc = capi.Scorer(n, capi.make_params())
+                d1 = torch.empty(n, dtype=torch.float64, device="cuda")
+                for s_ in (0, S - 1):
+                    sc.reset()
+                    sc.score_cohort(gt, sets[0][0][s_])
+                    sc.finish_device(0.0, d1.data_ptr())
+                    scale = float(d1.abs().max().item()) + 1e-300
+                    assert float((cur[s_] - d1).abs().max().item()) <= 1e-9 * scale, "multi != single-score path"
+        else:
+            assert np.array_equal(nl, first[j][1]), (k, nl)
+            assert bool(torch.equal(cur.view(torch.int64), first[j][0].view(torch.int64))), "pass %d differs" % k
+        if k % 100 == 0:
+            print("pass %d ok (%.1f s)" % (k, time.time() - t0), flush=True)
+    print("soak ok: %d multi-score passes of 8 scores x %d x %d, two definition sets alternating, bit-identical per "
+          "set and equal to the single-score kernel, %.1f s" % (a.passes, n, m, time.time() - t0))
+    sys.exit(0)
 is_ds = a.format == "ds"
 co = capi.Cohort(n, m, fmt=capi.FMT_DS32 if is_ds else capi.FMT_GT2)
 for r0 in range(0, m, 1 << 15):
