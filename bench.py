@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--samples", type=int, default=500_000, help="cohort size N (default: config 3)")
     ap.add_argument("--variants", type=int, default=1_000_000, help="score rows M (default: config 3)")
