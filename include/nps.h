@@ -218,6 +218,16 @@ void nps_destroy(nps_ctx *ctx);
  * samples, 16 ROWS of one sample per 32-bit word; carries its whole-row tallies.  Filled by
  * nps_cohort_convert (from a NPS_FMT_GT2 cohort) or nps_cohort_synth[_rows]; scored by nps_score_cohort_multi. */
 #define NPS_FMT_GT2M 2
+/* 2-bit codes in the strip layout of the matrix-core single-score kernel: strips of 2048 samples x
+ * superblocks of 128 rows x 1 KiB units (128 rows x 32 samples, row-major).  Same C-ABI as NPS_FMT_GT2 towards the
+ * caller (nps_cohort_upload / _download speak plain rows of NPS_CODE_* codes; row0 of an upload or a synthetic fill
+ * must be a multiple of 128, and rows after its end inside the last superblock written become zero); filled also by
+ * nps_cohort_convert from a NPS_FMT_GT2 cohort.  Scored by nps_score_cohort[_def] (cohort_row0 a multiple of 128,
+ * NPS_MODE_AUTO or NPS_MODE_FUSED) with results identical in meaning to the NPS_FMT_GT2 kernels: tallies, nloci
+ * and decisions bit-exact, scores equal up to the quantisation of the row weights (2^-56 of the largest one: the size
+ * of float64 rounding of the terms themselves).  The kernel's time does
+ * not depend on the genotypes.  Needs ceil(n_samples / 2048) <= compute units of the device. */
+#define NPS_FMT_GT2X 3
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
                       int format);
@@ -313,7 +323,7 @@ int nps_multi_reset(nps_multi *m, const nps_params *params /* NULL = keep */);
 void nps_multi_destroy(nps_multi *m);
 /* device time (HIP events) of the calls since the last reset: weight digits, the product, the fold */
 int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold);
-/* NPS_FMT_GT2 cohort (plain order) -> NPS_FMT_GT2M cohort of the same shape, with its row tallies */
+/* NPS_FMT_GT2 cohort (plain order) -> NPS_FMT_GT2M (with its row tallies) or NPS_FMT_GT2X cohort of the same shape */
 int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src);
 /* the whole-row tallies a NPS_FMT_GT2M cohort carries (tallyAlleles, nimpress.nim:32-47), for warnings */
 int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t *nmissing_out,

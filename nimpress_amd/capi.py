@@ -20,7 +20,7 @@ MISSING = {"homref": 0, "ignore": 1}
 SAMPLE = {"ps": 0, "homref": 1, "fail": 2, "int_ps": 3, "int_fail": 4}
 ROW_PRESENT, ROW_UNCOVERED, ROW_ABSENT, ROW_FILTERED = 0, 1, 2, 3
 REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMIS = range(5)
-FMT_GT2, FMT_DS32, FMT_GT2M = 0, 1, 2
+FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X = 0, 1, 2, 3
 ROW_NOT_IN_SCORE = 4
 MULTI_MAX_SCORES = 8
 MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2

@@ -141,6 +141,12 @@ struct nps_ctx {
     double *d_part_fused = nullptr;         // [Q][team stride] partial scores of the fused kernel
     uint64_t part_fused_cap = 0;            // doubles
     unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernels (cleared by fold_kernel)
+    float *d_mx_cpart = nullptr;            // NPS_FMT_GT2X runs: digit sums handed from fused_mx_kernel to mx_fold_kernel
+    uint64_t mx_cpart_cap = 0;              // floats
+    double *d_mx_const = nullptr;           // ... and the locus constants of rows over --maxmis (zero between passes)
+    bool mx_plan_valid = false;
+    uint64_t mx_plan_m = 0;
+    MxPlan mx_plan_cache{};
     bool rtally_clean = false;              // d_rtally is all zero (allocation, or the last fused epilogue)
     // shape -> persistent-grid plan of the last resident run (occupancy queries are slow)
     bool plan_valid = false;
@@ -288,6 +294,8 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_rds_psum);
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
+    (void)hipFree(c->d_mx_cpart);
+    (void)hipFree(c->d_mx_const);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -905,7 +913,7 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
                                  int format) {
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
-    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M)
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M && format != NPS_FMT_GT2X)
         return fail(NPS_E_INVAL, "unknown cohort format %d", format);
     if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
     int rc = select_device(device);
@@ -930,8 +938,13 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
             return fail(NPS_E_NOMEM, "hipMalloc of the row tallies failed");
         }
     }
+    if (format == NPS_FMT_GT2X) {
+        c->stride_bytes = 0;  // not row-major: strips x superblocks x 1 KiB units
+        bytes = std::max<uint64_t>(gt2x_bytes(n_samples, n_rows), 256);
+    }
     hipError_t e = hipMalloc(&c->d_data, bytes);
     if (e != hipSuccess) {
+        (void)hipFree(c->d_row_tally);
         delete c;
         return fail(NPS_E_NOMEM, "hipMalloc(%llu bytes) for the cohort failed: %s",
                     (unsigned long long)bytes, hipGetErrorString(e));
@@ -939,6 +952,7 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     e = hipMemset(c->d_data, 0, bytes);
     if (e != hipSuccess) {
         (void)hipFree(c->d_data);
+        (void)hipFree(c->d_row_tally);
         delete c;
         return fail(NPS_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
     }
@@ -1058,6 +1072,36 @@ static int gt2_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *
     return NPS_OK;
 }
 
+// NPS_FMT_GT2X: plain rows (C-ABI order and codes) <-> units, through a device staging buffer of whole superblocks
+static int gt2x_transfer(const nps_cohort *c, uint64_t row0, uint64_t nrows, void *host_rows, size_t host_stride,
+                         bool to_device) {
+    if (to_device && (row0 & 127))
+        return fail(NPS_E_INVAL, "row0 must be a multiple of 128 for NPS_FMT_GT2X cohorts");
+    const uint64_t n_words = words_for(c->n_samples), sw = (n_words + 1) / 2 * 2;
+    const uint64_t chunk = std::max<uint64_t>(128, (256ull << 20) / (sw * 4) / 128 * 128);
+    uint32_t *d_stage = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, std::min(chunk, (nrows + 127) / 128 * 128) * sw * 4));
+    hipError_t e = hipSuccess;
+    for (uint64_t r = 0; e == hipSuccess && r < nrows; r += chunk) {
+        const uint64_t k = std::min(chunk, nrows - r);
+        if (to_device) {
+            e = hipMemcpy2D(d_stage, sw * 4, (const char *)host_rows + r * host_stride, host_stride, n_words * 4, k,
+                            hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = launch_rows_to_gt2x(nullptr, d_stage, sw, c->n_samples, c->n_rows, row0 + r, k, c->d_data);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        } else {
+            e = launch_gt2x_to_rows(nullptr, c->d_data, c->n_samples, c->n_rows, row0 + r, k, d_stage, sw);
+            if (e == hipSuccess)
+                e = hipMemcpy2D((char *)host_rows + r * host_stride, host_stride, d_stage, sw * 4, n_words * 4, k,
+                                hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_stage);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "cohort transfer failed: %s", hipGetErrorString(e));
+    return NPS_OK;
+}
+
 extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const uint8_t *bed_rows,
                                      size_t row_stride_bytes, const uint8_t *effect_is_a1) {
     int rc = check_range(c, row0, nrows);
@@ -1091,6 +1135,7 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
         if (rc) return rc;
         return gt2_upload(c, row0, nrows, host_rows, host_stride, width, nullptr);
     }
+    if (c->format == NPS_FMT_GT2X) return gt2x_transfer(c, row0, nrows, const_cast<void *>(host_rows), host_stride, true);
     HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
                         host_stride, width, nrows, hipMemcpyHostToDevice));
     return NPS_OK;
@@ -1106,6 +1151,7 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
     if (c->format == NPS_FMT_GT2) return gt2_transfer(c, row0, nrows, host_rows, host_stride, false);
+    if (c->format == NPS_FMT_GT2X) return gt2x_transfer(c, row0, nrows, host_rows, host_stride, false);
     HIP_TRY(hipMemcpy2D(host_rows, host_stride, (const char *)c->d_data + row0 * c->stride_bytes,
                         c->stride_bytes, width, nrows, hipMemcpyDeviceToHost));
     return NPS_OK;
@@ -1120,8 +1166,8 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (!t_het || !t_hom || !t_miss) return fail(NPS_E_INVAL, "threshold arrays are NULL");
     if (c->format == NPS_FMT_GT2 && (row0 & 3))
         return fail(NPS_E_INVAL, "row0 must be a multiple of 4 for 2-bit cohorts");
-    if (c->format == NPS_FMT_GT2M && (row0 & 127))
-        return fail(NPS_E_INVAL, "row0 must be a multiple of 128 for NPS_FMT_GT2M cohorts");
+    if ((c->format == NPS_FMT_GT2M || c->format == NPS_FMT_GT2X) && (row0 & 127))
+        return fail(NPS_E_INVAL, "row0 must be a multiple of 128 for NPS_FMT_GT2M / NPS_FMT_GT2X cohorts");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     rc = cohort_unoptimize(c);
@@ -1137,6 +1183,9 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
         if (c->format == NPS_FMT_GT2M)
             e = launch_synth_gt2m(nullptr, c->d_data, c->n_samples, row0 + r, gen_row0 + r, k, seed, d_t + r,
                                   d_t + nrows + r, d_t + 2 * nrows + r, c->d_row_tally);
+        else if (c->format == NPS_FMT_GT2X)
+            e = launch_synth_gt2x(nullptr, c->d_data, c->n_samples, c->n_rows, row0 + r, gen_row0 + r, k, seed, d_t + r,
+                                  d_t + nrows + r, d_t + 2 * nrows + r);
         else if (c->format == NPS_FMT_DS32)
             e = launch_synth_ds(nullptr, (float *)c->d_data, c->stride_bytes / 4, c->n_samples,
                                 row0 + r, gen_row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
@@ -1164,6 +1213,9 @@ struct nps_scoredef {
     std::vector<nps_row_desc> host_rows;  // rows without genotype data, in order
     std::vector<int64_t> data_index;      // per desc: >= 0 index among PRESENT rows, -1 host row
     nps_row_desc *d_desc = nullptr;       // [m] PRESENT rows, compact
+    // NPS_FMT_GT2X runs: the largest |beta| (4 + max(2, 2 |eaf|)) over the PRESENT rows with finite numbers: the
+    // fixed-point scale 2^F of fused_mx_kernel keeps every weight below 2^56
+    double mx_bound = 0.0;
 };
 
 extern "C" int nps_scoredef_create(nps_scoredef **out, int device, const nps_row_desc *rows,
@@ -1185,6 +1237,10 @@ extern "C" int nps_scoredef_create(nps_scoredef **out, int device, const nps_row
         if (r.kind == NPS_ROW_PRESENT) {
             d->data_index[j] = (int64_t)data.size();
             data.push_back(r);
+            if (std::isfinite(r.beta)) {
+                const double ie = std::isfinite(r.eaf) ? std::max(2.0, 2.0 * std::fabs(r.eaf)) : 2.0;
+                d->mx_bound = std::max(d->mx_bound, std::fabs(r.beta) * (4.0 + ie));
+            }
         } else if (r.kind == NPS_ROW_UNCOVERED || r.kind == NPS_ROW_ABSENT ||
                    r.kind == NPS_ROW_FILTERED) {
             d->data_index[j] = -1;
@@ -1315,11 +1371,31 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (co->format == NPS_FMT_GT2M)
         return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are scored with nps_score_cohort_multi");
     const bool is_ds = co->format == NPS_FMT_DS32;
+    const bool is_mx = co->format == NPS_FMT_GT2X;
+    if (is_mx && (cohort_row0 & 127))
+        return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 128 for NPS_FMT_GT2X cohorts");
+    if (is_mx && mode == NPS_MODE_TWOPASS)
+        return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2X cohorts are scored by the single-read kernel only");
     if (!is_ds && (cohort_row0 & 3))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
+    MxPlan mxp;
+    if (is_mx && m && c->n) {
+        if (c->mx_plan_valid && c->mx_plan_m == m) {
+            mxp = c->mx_plan_cache;
+        } else {
+            HIP_TRY(mx_plan(c->device, c->n, m, &mxp));
+            c->mx_plan_cache = mxp;
+            c->mx_plan_m = m;
+            c->mx_plan_valid = true;
+        }
+        if (!mxp.ok)
+            return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the persistent grid of the "
+                        "NPS_FMT_GT2X kernel (one 2048-sample strip per compute unit)", (unsigned long long)c->n,
+                        (unsigned long long)m);
+    }
     FusedPlan plan;
-    if (mode != NPS_MODE_TWOPASS && m && c->n) {
+    if (!is_mx && mode != NPS_MODE_TWOPASS && m && c->n) {
         if (c->plan_valid && c->plan_fmt == co->format && c->plan_m == m) {
             plan = c->plan_cache;
         } else {
@@ -1363,10 +1439,18 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     }
 
     // buffers (a failed allocation leaves the context usable: nothing has been queued yet)
-    const uint64_t m_pad = (m + 15) / 16 * 16;
+    const uint64_t m_pad = is_mx ? (m + 127) / 128 * 128 : (m + 15) / 16 * 16;
     rc = ensure_resident_buffers(c, m_pad);
     if (rc) return rc;
     const bool fused = plan.ok && c->n;
+    if (is_mx && c->n) {
+        rc = grow(c, (void **)&c->d_mx_cpart, &c->mx_cpart_cap, mxp.cpart_floats, sizeof(float));
+        if (rc) return rc;
+        if (!c->d_mx_const) {
+            HIP_TRY(hipMalloc(&c->d_mx_const, 256));
+            HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, 256, c->stream));
+        }
+    }
     if (fused) {
         rc = grow(c, (void **)&c->d_part_fused, &c->part_fused_cap,
                   (uint64_t)plan.Q * plan.part_team_stride, sizeof(double));
@@ -1413,6 +1497,56 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         c->rtally_clean = true;  // all words were zero before the run, [0, m_pad) are zero again
         return NPS_OK;
     };
+
+    if (is_mx) {
+        if (c->n == 0) return done();
+        // fixed-point scale: every weight of the definition below 2^56 (fourteen hexadecimal digits)
+        int F = 56;
+        if (def->mx_bound > 0.0) {
+            int e2 = 0;
+            (void)std::frexp(def->mx_bound, &e2);  // bound < 2^e2
+            F = std::min(1000, std::max(-1000, 56 - e2));
+        }
+        // the reference's test `nmissing / N > --maxmis` (double division, nimpress.nim:565) is monotone in
+        // nmissing: the largest count that is NOT over the rate, found with that very expression
+        const double rate = c->params.max_missing_rate;
+        int64_t t_maxmis = -1;
+        if (!((double)0 / (double)c->n > rate)) {
+            uint64_t lo = 0, hi = c->n;  // pred(lo) holds
+            while (lo < hi) {
+                const uint64_t mid = lo + (hi - lo + 1) / 2;
+                if (!((double)mid / (double)c->n > rate))
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            t_maxmis = (int64_t)lo;
+        }
+        rc = tally_ready();
+        if (rc) return rc;
+        hipError_t fe;
+        {
+            ProfScope ps(c, P_FUSED);
+            fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                 def->d_desc, dev_params(c->params), t_maxmis, F, c->d_rtally, c->d_rstats, c->d_nloci,
+                                 c->d_mx_const, c->d_mx_cpart, c->d_timeout);
+        }
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
+            c->rtally_clean = true;
+            return fail(NPS_E_HIP, "NPS_FMT_GT2X kernel launch failed: %s", hipGetErrorString(fe));
+        }
+        guard.armed = true;
+        {
+            ProfScope ps(c, P_REDUCE);
+            HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, c->d_mx_const, c->d_part,
+                                   c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_timeout, c->d_nloci + 1));
+            HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double), c->stream));
+        }
+        c->chunks_used = std::max(c->chunks_used, 1u);
+        c->rtally_clean = true;
+        return done();
+    }
 
     if (is_ds) {
         const uint64_t stride_f = co->stride_bytes / 4;
@@ -1566,8 +1700,8 @@ extern "C" int nps_score_cohort(nps_ctx *c, const nps_cohort *co, uint64_t cohor
 // several score definitions in one pass over a NPS_FMT_GT2M cohort (nps_multi.hip)
 extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     if (!dst || !src) return fail(NPS_E_INVAL, "cohort is NULL");
-    if (dst->format != NPS_FMT_GT2M || src->format != NPS_FMT_GT2)
-        return fail(NPS_E_INVAL, "nps_cohort_convert goes from a NPS_FMT_GT2 to a NPS_FMT_GT2M cohort");
+    if ((dst->format != NPS_FMT_GT2M && dst->format != NPS_FMT_GT2X) || src->format != NPS_FMT_GT2)
+        return fail(NPS_E_INVAL, "nps_cohort_convert goes from a NPS_FMT_GT2 to a NPS_FMT_GT2M or NPS_FMT_GT2X cohort");
     if (dst->device != src->device || dst->n_samples != src->n_samples || dst->n_rows != src->n_rows)
         return fail(NPS_E_INVAL, "source and destination differ in device, samples or rows");
     if (src->optimized)
@@ -1575,6 +1709,12 @@ extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     HIP_TRY(hipSetDevice(dst->device));
     HIP_TRY(hipDeviceSynchronize());
     if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;
+    if (dst->format == NPS_FMT_GT2X) {
+        HIP_TRY(launch_gt2_to_gt2x(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
+                                   src->n_rows, dst->d_data));
+        HIP_TRY(hipDeviceSynchronize());
+        return NPS_OK;
+    }
     // units and, from the same tiles, the whole-row tallies (tallyAlleles nimpress.nim:32-47)
     HIP_TRY(launch_convert_gt2m(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
                                 src->n_rows, dst->d_data, dst->d_row_tally));
@@ -1912,8 +2052,17 @@ extern "C" void *nps_stream(nps_ctx *c) { return c ? (void *)c->stream : nullptr
 extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint32_t *slices,
                                   uint32_t *teams, uint32_t *samples_per_slice) {
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
-    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32) return fail(NPS_E_INVAL, "unknown format %d", format);
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2X)
+        return fail(NPS_E_INVAL, "unknown format %d", format);
     HIP_TRY(hipSetDevice(c->device));
+    if (format == NPS_FMT_GT2X) {
+        MxPlan mp;
+        HIP_TRY(mx_plan(c->device, c->n, n_rows, &mp));
+        if (slices) *slices = mp.ok ? mp.P : 0;
+        if (teams) *teams = mp.ok ? 1 : 0;
+        if (samples_per_slice) *samples_per_slice = mp.ok ? 2048 : 0;
+        return NPS_OK;
+    }
     FusedPlan plan;
     if (format == NPS_FMT_DS32)
         HIP_TRY(ds_fused_plan(c->device, c->n, n_rows, 0, 0, &plan));

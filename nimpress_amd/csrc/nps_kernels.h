@@ -236,4 +236,59 @@ hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t 
 hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,
                                const double *d_offsets, int have_sums, double *d_scores);
 
+// ---- single-read kernel on the matrix cores for the strip layout NPS_FMT_GT2X (nps_mx.hip) -----------------
+// cohort = [strip of 2048 samples][superblock of 128 rows][unit of 32 samples][row][8 bytes]; codes 0, 1, 2 =
+// dosage, 3 = missing; sample s of a unit in bits 2s, 2s+1 of the row's 8 bytes.  Every strip but the last has
+// 64 units; the last has what is left.
+struct MxGeom {
+    uint64_t n_units = 0, n_sb = 0;
+    uint32_t P = 0, nu_last = 0;
+};
+static inline MxGeom mx_geom(uint64_t n_samples, uint64_t n_rows) {
+    MxGeom g;
+    g.n_units = (n_samples + 31) / 32;
+    g.n_sb = (n_rows + 127) / 128;
+    g.P = (uint32_t)((g.n_units + 63) / 64);
+    g.nu_last = g.P ? (uint32_t)(g.n_units - 64ull * (g.P - 1)) : 0u;
+    return g;
+}
+static inline uint64_t gt2x_superblocks(uint64_t n_rows) { return (n_rows + 127) / 128; }
+static inline uint64_t gt2x_bytes(uint64_t n_samples, uint64_t n_rows) {
+    const MxGeom g = mx_geom(n_samples, n_rows);
+    return g.n_units * g.n_sb * 1024;
+}
+// KiB index of unit `unit` (= sample / 32) of superblock sb
+static __host__ __device__ inline uint64_t gt2x_unit_index(uint64_t unit, uint64_t sb, uint64_t n_units, uint64_t n_sb) {
+    const uint64_t p = unit >> 6, P = (n_units + 63) >> 6;
+    const uint64_t nu = p == P - 1 ? n_units - 64 * (P - 1) : 64;
+    return p * 64 * n_sb + sb * nu + (unit & 63);
+}
+struct MxPlan {
+    bool ok = false;
+    uint32_t P = 0, nu_last = 0, n_sb = 0, n_flush = 0;
+    uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
+};
+hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan);
+// d_tally: [n_sb*128] zeroed; d_cpart: [plan.cpart_floats]; d_const_sum: one double, zero on entry;
+// t_maxmis: largest nmissing with !((double)nmissing / (double)N > --maxmis); F: fixed-point scale 2^F with
+// |beta| (4 + max(2, 2 |eaf|)) 2^F < 2^56 for every row
+hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
+                           int64_t t_maxmis, int F, unsigned long long *d_tally, nps_locus_stat *d_stats,
+                           unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout);
+hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
+                          const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
+                          uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status);
+// rows [row0, row0+n_rows) (row0 a multiple of 128) of a cohort of n_rows_cohort rows; rows past the end inside
+// the last superblock written become zero
+hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,
+                             uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                             const uint32_t *d_t_hom, const uint32_t *d_t_miss);
+hipError_t launch_rows_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words, uint64_t n_samples,
+                               uint64_t n_rows_cohort, uint64_t row0, uint64_t n_rows, void *d_units);
+hipError_t launch_gt2x_to_rows(hipStream_t st, const void *d_units, uint64_t n_samples, uint64_t n_rows_cohort,
+                               uint64_t row0, uint64_t n_rows, uint32_t *d_dst, uint64_t dst_stride_words);
+hipError_t launch_gt2_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t stride_words, uint64_t n_samples,
+                              uint64_t n_rows, void *d_units);
+
 }  // namespace nps

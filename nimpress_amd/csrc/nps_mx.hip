@@ -1,0 +1,716 @@
+// nps_mx.hip -- the single-read kernel for a resident 2-bit cohort in the strip layout (NPS_FMT_GT2X), with the
+// accumulation on the matrix cores (gfx950, wave64).  Same loop as nps_fused.hip -- tallyAlleles
+// (nimpress.nim:32-47), the maxmis decision (:565-571), imputeLocus/SampleDosages (:417-481) and
+// `scores[i] += dosage*beta` (:639-641) in ONE read of the matrix -- but nothing in it depends on the genotype
+// distribution: no table lookups, no float64 adds per genotype.
+//
+//   * A row's contribution to a sample is  code * Wc + is_missing * Wm  with code = dosage (3 for a missing
+//     genotype), Wc = beta, Wm = (imputed dosage - 3) * beta: a matrix product over the rows.  The weights are
+//     56-bit fixed-point integers (scale 2^F per score definition) in sign-magnitude, split into fourteen hexadecimal
+//     digits: an FP6 (e2m3) operand byte 00dddd IS the digit d/8, so a digit needs no encoding at all.  The
+//     2-bit codes are FP4 (e2m1) operands as they lie: a nibble 00hl is 0, 0.5, 1, 1.5 -- linear in the code -- and
+//     the second genotype of a nibble, moved one bit down, sits in the exponent field: 0, 1, 2, 4.  Five vector
+//     instructions per 16 genotypes make the four operand registers (two code operands, two is-missing
+//     operands); v_mfma_scale_f32_16x16x128_f8f6f4 with unit-making block scales accumulates exact integers
+//     in float32 (flushed long before 2^24), sixteen columns = fourteen digits, a spare and one NaN flag.
+//   * Layout: strips of 2048 samples x superblocks of 128 rows; a unit = 128 rows x 32 samples = 1 KiB,
+//     row-major [row][8 bytes], two samples per nibble.  One workgroup (8 waves) owns a strip and streams all
+//     its superblocks; a lane's 16-byte load is two whole rows of a unit, so the tally is popcounts on the
+//     registers as they arrive.  The same registers, parked in LDS and read back with ds_read_b64_tr_b4 (a
+//     16 x 16 transpose of nibbles per 16 lanes), are the MFMA A operand: 32 rows of one sample pair per lane.
+//   * Hand-over as in nps_fused.hip: per row one 64-bit agent-scope atomic add per strip
+//     (arrivals<<56 | nmissing<<28 | neffect), polled by the strip's control wave a step and a half later; the
+//     control wave turns the complete tallies into the superblock's weight digits (16 bytes per row and
+//     operand) in LDS, and every wave fetches its B fragments from there with ds_read_b96_tr_b6.
+//     Every wait is bounded (NPS_E_TIMEOUT instead of a hang); the grid is launched cooperatively.
+//
+// Pipeline of a workgroup, step k (one barrier per step):
+//     loads of superblock k+3 -> registers | tally k+2 (registers) | park k+1 (registers -> LDS) | barrier |
+//     accumulate k (LDS -> MFMA)            control wave: tables of k before the barrier, publish k+2 after it
+#include <algorithm>
+#include <cmath>
+
+#include "nps_kernels.h"
+
+namespace nps {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v3i __attribute__((ext_vector_type(3)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
+#define NPS_LDS __attribute__((address_space(3)))
+
+constexpr int kUD = 9;                   // units per data wave (waves 0..6); wave 7: the 64th unit + the control work
+constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
+constexpr uint32_t kLdsTables = 131072;  // [2][3 operands][128 rows][16 bytes]
+constexpr uint32_t kLdsTally = kLdsTables + 12288;  // [2][128] uint32: nmissing << 16 | neffect of the strip
+constexpr uint32_t kLdsBytes = kLdsTally + 1024;
+constexpr uint32_t kMxSpinLimit = 1u << 20;
+
+struct MxArgs {
+    const v4u *units;        // the cohort
+    uint64_t n_sb_cohort;    // its superblocks (a strip is n_sb_cohort * units-of-the-strip KiB)
+    uint32_t sb0, n_sb;      // this run: first superblock, superblocks
+    uint64_t n_rows;         // rows of this run
+    uint64_t n_samples;
+    uint32_t P, nu_last;     // strips, units of the last one
+    const nps_row_desc *desc;
+    DevParams prm;
+    int64_t t_maxmis;        // the largest nmissing for which nmissing / N > --maxmis is false (-1: none)
+    double scale;            // 2^F
+    unsigned long long *tally;  // [n_sb * 128], zero on entry
+    nps_locus_stat *stats;
+    unsigned long long *nloci;
+    double *const_sum;       // += the locus constants of rows over --maxmis (added to every sample by mx_fold_kernel)
+    float *cpart;            // [n_flush][P][64][2][256]
+    unsigned int *timeout;
+};
+
+static __device__ __forceinline__ v2i tr4(const char *p) {
+    return __builtin_amdgcn_ds_read_tr4_b64_v2i32((NPS_LDS v2i *)p);
+}
+static __device__ __forceinline__ v3i tr6(const char *p) {
+    return __builtin_amdgcn_ds_read_tr6_b96_v3i32((NPS_LDS v3i *)p);
+}
+static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {  // popcount(x) + acc, one instruction
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+// where row r of a unit lives in its 1 KiB LDS image: a lane's two rows stay together (one ds_write_b128), and
+// the 32 lanes of a half wave read 256 different bytes in both transposed reads
+static __host__ __device__ inline int mx_rowoff(int r) {
+    return 8 * (r & 15) + 128 * ((r >> 5) & 1) + 256 * ((r >> 4) & 1) + 512 * (r >> 6);
+}
+
+// four 4-bit fields -> four 6-bit fields
+static __device__ __forceinline__ uint32_t spread4(uint32_t x) {
+    x = (x & 0x00FFu) | ((x & 0xFF00u) << 4);
+    x = (x & 0x00F00Fu) | ((x & 0x0F00F0u) << 2);
+    return x;
+}
+// an integer weight, |w| < 2^56, as sixteen FP6 operand bytes packed 6 bits apart: fourteen hexadecimal digits of
+// |w| (an e2m3 byte 00dddd is d/8: the subnormals and the first binade are one linear run), the sign bit in every
+// digit, a spare column and the flag column
+static __device__ __forceinline__ void mx_codes(long long w, uint32_t flag, uint32_t (&c)[3]) {
+    const unsigned long long aw = (unsigned long long)(w < 0 ? -w : w);
+    const uint32_t lo = (uint32_t)aw, hi = (uint32_t)(aw >> 32);
+    const uint32_t c0 = spread4(lo & 0xFFFFu), c1 = spread4(lo >> 16), c2 = spread4(hi & 0xFFFFu), c3 = spread4((hi >> 16) & 0xFFu);
+    c[0] = c0 | (c1 << 24);
+    c[1] = (c1 >> 8) | (c2 << 16);
+    c[2] = (c2 >> 16) | (c3 << 8) | (flag << 26);
+    if (w < 0) {
+        c[0] |= 0x20820820u;
+        c[1] |= 0x08208208u;
+        c[2] |= 0x02082082u;
+    }
+}
+
+// One row, from its complete tally word: the decisions of getImputedDosages (nimpress.nim:565-571), the locus
+// constant (:417-447) or the sample imputation value (:450-481), as the three weight operands of the row.
+static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long long x, bool live, uint64_t row,
+                                              double beta, double eaf, bool rie, bool write_stats,
+                                              uint32_t (&wc)[3], uint32_t (&wme)[3], uint32_t (&wmo)[3], int &used,
+                                              double &cst) {
+    wc[0] = wc[1] = wc[2] = wme[0] = wme[1] = wme[2] = wmo[0] = wmo[1] = wmo[2] = 0u;
+    used = 0;
+    cst = 0.0;
+    if (!live) return;
+    const uint64_t nmiss = (x >> 28) & 0xFFFFFFFull, neff = x & 0xFFFFFFFull;
+    const uint64_t ngen = a.n_samples - nmiss;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    int reason;
+    if ((int64_t)nmiss > a.t_maxmis) {  // == (double)nmiss / (double)N > --maxmis, t_maxmis found with that very division
+        reason = NPS_REASON_MAXMIS;
+        if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
+            const double c = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                             : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                                   : nan;
+            used = 1;
+            cst = c * beta;
+        }
+    } else {
+        reason = NPS_REASON_GENOTYPED;
+        used = 1;
+        double imp;
+        switch (a.prm.imp_sample) {
+        case NPS_SAMPLE_PS: imp = eaf * 2.0; break;
+        case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
+        case NPS_SAMPLE_FAIL: imp = nan; break;
+        default:
+            if ((double)ngen >= a.prm.min_cs)
+                imp = (double)neff / (double)ngen;
+            else
+                imp = a.prm.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
+            break;
+        }
+        if (!(fabs(beta) < __builtin_huge_val())) {
+            cst = nan;  // a non-finite beta makes every sample's sum NaN (0 * NaN, NaN + x), as in the reference
+        } else {
+            const long long w1 = __double2ll_rn(beta * a.scale);
+            const double t = imp * beta;  // the product the reference adds for a missing sample (nimpress.nim:639)
+            const bool bad = !(fabs(t) < __builtin_huge_val());  // NaN (or overflow): the sample's score is NaN
+            const long long wi = bad ? 3 * w1 : __double2ll_rn(t * a.scale);
+            mx_codes(w1, 0u, wc);
+            mx_codes(wi - 3 * w1, bad ? 1u : 0u, wme);  // a missing genotype has code 3 (4 in the odd operand)
+            mx_codes(wi - 4 * w1, bad ? 1u : 0u, wmo);
+        }
+    }
+    if (write_stats) {
+        nps_locus_stat s;
+        s.ngenotyped = ngen;
+        s.nmissing = nmiss;
+        s.neffect = (double)neff;
+        s.used = used;
+        s.reason = reason;
+        a.stats[row] = s;
+    }
+}
+
+// NU: units the wave can own (register arrays); GUARD: it may own fewer (ragged last strip) -- without guards the
+// compiler pipelines across units; CTL: the control wave (its own code path, so that the data waves' registers
+// hold nothing of it)
+template <int NU, bool GUARD, bool CTL>
+static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const uint32_t strip = blockIdx.x;
+    constexpr bool is_ctl = CTL;
+    const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
+    const int u0 = wave * kUD;
+    const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
+    constexpr bool full = !GUARD;
+
+    char *const slot0 = smem + (size_t)u0 * 1024, *const slot1 = smem + 65536 + (size_t)u0 * 1024;
+    const int woff = mx_rowoff(2 * lane);
+    const int r1off = mx_rowoff(32 * g + q), r2off = mx_rowoff(32 * g + 16 + q);
+    const int fr0 = (32 * g + q) * 16, fr1 = (32 * g + 16 + q) * 16;
+    const v4u *const base = a.units + ((uint64_t)strip * 64 * a.n_sb_cohort + (uint64_t)a.sb0 * nu + u0) * 64 + lane;
+    const uint64_t sb_stride = (uint64_t)nu * 64;
+
+    v4f C[NU][2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) C[u][0] = C[u][1] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4u bank[2][NU];  // two superblocks of the wave's units in registers: one being tallied, one waiting to be parked
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) bank[s][u] = v4u{0u, 0u, 0u, 0u};
+
+    auto load_unit = [&](uint32_t k, int u) -> v4u {
+        return __builtin_nontemporal_load(base + (uint64_t)k * sb_stride + u * 64);
+    };
+    auto load_sb = [&](uint32_t k, v4u(&dst)[NU]) {
+        if (k >= a.n_sb) return;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (full || u < n_my) dst[u] = load_unit(k, u);
+    };
+
+    // tallyAlleles over the wave's units of a superblock: a lane holds rows 2*lane, 2*lane+1 (32 samples each) of
+    // every unit.  Codes 01 / 10 / 11 = dosage 1 / dosage 2 / missing: with X = set bits, Y = set high bits,
+    // Z = missing,  effect alleles = X + Y - 3 Z.
+    struct Tal {
+        uint32_t xa = 0, ya = 0, za = 0, xb = 0, yb = 0, zb = 0;
+    };
+    auto tally_unit = [&](Tal &t, const v4u w) {
+        const uint32_t sx = w.x >> 1, sy = w.y >> 1, sz = w.z >> 1, sw = w.w >> 1;
+        t.xa = bcnt_acc(w.y, bcnt_acc(w.x, t.xa));
+        t.ya = bcnt_acc((w.x & 0xAAAAAAAAu) | (sy & 0x55555555u), t.ya);
+        t.za = bcnt_acc((w.x & sx & 0x55555555u) | ((w.y & sy & 0x55555555u) << 1), t.za);
+        t.xb = bcnt_acc(w.w, bcnt_acc(w.z, t.xb));
+        t.yb = bcnt_acc((w.z & 0xAAAAAAAAu) | (sw & 0x55555555u), t.yb);
+        t.zb = bcnt_acc((w.z & sz & 0x55555555u) | ((w.w & sw & 0x55555555u) << 1), t.zb);
+    };
+    auto tally_add = [&](uint32_t kt, const Tal &t) {
+        const unsigned long long pa = (t.xa + t.ya - 3u * t.za) | (t.za << 16), pb = (t.xb + t.yb - 3u * t.zb) | (t.zb << 16);
+        unsigned long long *T = reinterpret_cast<unsigned long long *>(smem + kLdsTally) + (kt & 1) * 64 + lane;
+        atomicAdd(T, pa | (pb << 32));  // the 16-bit fields of a word never carry: a strip has 2048 samples
+    };
+    // first half of step k, unit after unit: tally superblock k+2 (bank b_tal), park superblock k+1 (bank b_park ->
+    // LDS slot) and refill that register with the unit's rows of superblock k+3
+    auto front = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park) {
+        if (n_my == 0) return;
+        Tal t;
+        if (k + 3 < a.n_sb) {  // steady state: no per-unit conditions
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (full || u < n_my) {
+                    tally_unit(t, b_tal[u]);
+                    *reinterpret_cast<v4u *>(s_park + u * 1024 + woff) = b_park[u];
+                    b_park[u] = load_unit(k + 3, u);
+                }
+            tally_add(k + 2, t);
+        } else {
+            const bool do_t = k + 2 < a.n_sb, do_p = k + 1 < a.n_sb;
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (full || u < n_my) {
+                    if (do_t) tally_unit(t, b_tal[u]);
+                    if (do_p) *reinterpret_cast<v4u *>(s_park + u * 1024 + woff) = b_park[u];
+                }
+            if (do_t) tally_add(k + 2, t);
+        }
+    };
+
+    // scores += code * Wc + is_missing * Wm for the wave's units of superblock k (parked in `slot`)
+    auto accumulate = [&](uint32_t k, const char *slot) {
+        if (k >= a.n_sb || n_my == 0) return;
+        const char *tab = smem + kLdsTables + (k & 1) * 6144;
+        v8i Bc, Bme, Bmo;
+        {
+            const v3i c0 = tr6(tab + fr0), c1 = tr6(tab + fr1);
+            const v3i e0 = tr6(tab + 2048 + fr0), e1 = tr6(tab + 2048 + fr1);
+            const v3i o0 = tr6(tab + 4096 + fr0), o1 = tr6(tab + 4096 + fr1);
+            Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
+            Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
+            Bmo = v8i{o0[0], o0[1], o0[2], o1[0], o1[1], o1[2], 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (full || u < n_my) {
+                const v2i t01 = tr4(slot + u * 1024 + r1off), t23 = tr4(slot + u * 1024 + r2off);
+                const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
+                v8i ce = {0, 0, 0, 0, 0, 0, 0, 0}, co = ce, me = ce, mo = ce;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t s1 = w[r] >> 1;
+                    ce[r] = (int)(w[r] & 0x33333333u);       // even sample: 00hl = code / 2
+                    co[r] = (int)(s1 & 0x66666666u);         // odd sample: 0hl0 = 0, 1, 2, 4
+                    me[r] = (int)(w[r] & s1 & 0x11111111u);  // even sample missing: 0001 = 1/2
+                    mo[r] = (int)(w[r] & s1 & 0x44444444u);  // odd sample missing: 0100 = 2
+                }
+                // block scales (E8M0): codes 0,1,2,3 | 0,1,2,4; missing bit 1; digits d/8 -> d
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ce, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(co, Bc, C[u][1], 4, 2, 0, 127, 0, 130);
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(me, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bmo, C[u][1], 4, 2, 0, 126, 0, 130);
+            }
+        }
+    };
+
+    auto store_c = [&](uint32_t f, bool zero) {
+        float *dst = a.cpart + ((((uint64_t)f * a.P + strip) * 64 + u0) * 2) * 256 + lane * 4;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (full || u < n_my) {
+                *reinterpret_cast<v4f *>(dst + (u * 2 + 0) * 256) = C[u][0];
+                *reinterpret_cast<v4f *>(dst + (u * 2 + 1) * 256) = C[u][1];
+                if (zero) C[u][0] = C[u][1] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- control state (wave 7)
+    uint32_t nloci_local = 0;
+    double cst_local = 0.0;
+    bool timed_out = false;
+    double nbeta[2] = {0.0, 0.0}, neaf[2] = {0.0, 0.0};
+    bool nrie[2] = {false, false};
+    auto ctl_fetch_desc = [&](uint32_t k) {  // score rows of superblock k, a step before they are needed
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
+            if (k < a.n_sb && row < a.n_rows) {
+                nbeta[rr] = a.desc[row].beta;
+                neaf[rr] = a.desc[row].eaf;
+                nrie[rr] = a.desc[row].ref_is_effect != 0;
+            }
+        }
+    };
+    // the tally words of superblock k were published by every strip more than a step ago: normally one poll
+    auto ctl_tables = [&](uint32_t k) {
+        if (k >= a.n_sb) return;
+        unsigned long long x[2];
+        bool valid[2], ok[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
+            valid[rr] = row < a.n_rows;
+            x[rr] = valid[rr] ? __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            ok[rr] = !valid[rr] || (uint32_t)(x[rr] >> 56) == a.P;
+        }
+        uint32_t spins = 0;
+        while (!__all(ok[0] && ok[1]) && !timed_out) {
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+                if (!ok[rr]) {
+                    const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
+                    x[rr] = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok[rr] = (uint32_t)(x[rr] >> 56) == a.P;
+                }
+            if ((++spins & 255u) == 0) {
+                const unsigned int t = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t != 0 || spins >= kMxSpinLimit) {
+                    if (lane == 0) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    timed_out = true;
+                }
+            }
+        }
+        char *tab = smem + kLdsTables + (k & 1) * 6144;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
+            uint32_t wc[3], wme[3], wmo[3];
+            int used;
+            double cst;
+            mx_row(a, x[rr], valid[rr] && ok[rr], row, nbeta[rr], neaf[rr], nrie[rr], strip == 0 && a.stats != nullptr,
+                   wc, wme, wmo, used, cst);
+            char *p = tab + (lane + 64 * rr) * 16;
+            *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
+            *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
+            *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
+            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+            cst_local += cst;
+        }
+    };
+    // the strip's tallies of superblock kp are complete in LDS (barrier passed): one atomic per row
+    auto ctl_publish = [&](uint32_t kp) {
+        uint32_t *T = reinterpret_cast<uint32_t *>(smem + kLdsTally) + (kp & 1) * 128;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = lane + 64 * rr;
+            const uint32_t v = T[r];
+            T[r] = 0u;
+            const uint64_t row = (uint64_t)kp * 128 + r;
+            if (kp < a.n_sb && row < a.n_rows) {
+                const unsigned long long add = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
+                __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+
+    // ---- prologue: superblocks 0 and 1 tallied and published, 0 parked, 2 on its way
+    if (tid < 256) reinterpret_cast<uint32_t *>(smem + kLdsTally)[tid] = 0u;
+    load_sb(0, bank[0]);
+    load_sb(1, bank[1]);
+    if (is_ctl) ctl_fetch_desc(0);
+    __syncthreads();
+    if (n_my != 0 && a.n_sb > 0) {
+        Tal t;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (full || u < n_my) tally_unit(t, bank[0][u]);
+        tally_add(0, t);
+    }
+    __syncthreads();
+    if (is_ctl) ctl_publish(0);
+    if (n_my != 0 && a.n_sb > 1) {
+        Tal t;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (full || u < n_my) tally_unit(t, bank[1][u]);
+        tally_add(1, t);
+    }
+    if (a.n_sb > 0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (full || u < n_my) *reinterpret_cast<v4u *>(slot0 + u * 1024 + woff) = bank[0][u];
+    }
+    load_sb(2, bank[0]);
+    __syncthreads();
+    if (is_ctl) ctl_publish(1);
+
+    // ---- steps
+    auto step = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park, const char *s_acc) {
+        if (is_ctl) ctl_tables(k);
+        front(k, b_tal, b_park, s_park);
+        __syncthreads();
+        accumulate(k, s_acc);
+        if (is_ctl) {
+            ctl_publish(k + 2);
+            ctl_fetch_desc(k + 1);
+        }
+        if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < a.n_sb) store_c(k / kFlushSb, true);
+    };
+    const uint32_t n_steps = (a.n_sb + 1) / 2 * 2;
+    for (uint32_t k = 0; k < n_steps; k += 2) {
+        step(k + 0, bank[0], bank[1], slot1, slot0);
+        step(k + 1, bank[1], bank[0], slot0, slot1);
+    }
+    store_c((a.n_sb - 1) / kFlushSb, false);
+    if (is_ctl && strip == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
+        if (lane == 0) {
+            if (nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
+            if (cst_local != 0.0) atomicAdd(a.const_sum, cst_local);  // (NaN != 0 is true)
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
+    extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
+    const int wave = threadIdx.x >> 6;
+    const int nu = blockIdx.x == a.P - 1 ? (int)a.nu_last : 64;
+    // both bodies pass the same barriers; which one a wave runs is wave-uniform
+    if (wave == 7)
+        mx_body<64 - 7 * kUD, true, true>(a, smem);
+    else if (nu - wave * kUD >= kUD)
+        mx_body<kUD, false, false>(a, smem);
+    else
+        mx_body<kUD, true, false>(a, smem);
+}
+
+// Epilogue of a pass: the sixteen digit sums of a sample -> float64, plus the pass's locus constants, into chunk 0
+// of the context's partial scores; the tally words go back to zero; a raised bounded-wait word is recorded.
+__global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_flush, uint32_t P,
+                                                      uint64_t n, double inv_scale, const double *__restrict__ const_sum,
+                                                      double *__restrict__ part0, int overwrite,
+                                                      unsigned long long *__restrict__ tally, uint64_t n_tally,
+                                                      unsigned int *__restrict__ timeout,
+                                                      unsigned long long *__restrict__ status) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    for (uint64_t j = i; j < n_tally; j += nthreads) tally[j] = 0ull;
+    if (i == 0 && timeout) {
+        if (*timeout) atomicOr(status, 1ull);
+        *timeout = 0u;
+    }
+    if (i >= n) return;
+    const uint64_t strip = i >> 11;
+    const uint32_t unit = (uint32_t)(i >> 5) & 63u, s = (uint32_t)i & 31u;
+    const uint32_t e = s & 1u, ii = s >> 1;
+    double total = 0.0;
+    bool isnan_ = false;
+    for (uint32_t f = 0; f < n_flush; ++f) {
+        const float *t = cpart + ((((uint64_t)f * P + strip) * 64 + unit) * 2 + e) * 256 + ((ii >> 2) * 16) * 4 + (ii & 3);
+        double v = (double)t[13 * 4];
+#pragma unroll
+        for (int d = 12; d >= 0; --d) v = v * 16.0 + (double)t[d * 4];
+        total += v;
+        isnan_ = isnan_ || t[15 * 4] != 0.f;
+    }
+    double r = total * inv_scale + *const_sum;
+    if (isnan_) r = __longlong_as_double(0x7ff8000000000000ll);
+    part0[i] = overwrite ? r : part0[i] + r;
+}
+
+// ---- packing: generator, plain rows <-> units -------------------------------------------------------------
+static __device__ __forceinline__ uint64_t xmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one thread = one row of one unit (32 samples); block = 128 rows x 2 units; grid = (unit pairs, superblocks)
+__global__ __launch_bounds__(256) void synth_gt2x_kernel(unsigned long long *__restrict__ units, uint64_t n_units,
+                                                         uint64_t n_sb, uint64_t n_samples, uint64_t sb0,
+                                                         uint64_t gen_row0, uint64_t n_rows, uint64_t seed,
+                                                         const uint32_t *__restrict__ t_het,
+                                                         const uint32_t *__restrict__ t_hom,
+                                                         const uint32_t *__restrict__ t_miss) {
+    const uint64_t unit = (uint64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+    const uint32_t rho = threadIdx.x & 127;
+    const uint64_t sb = blockIdx.y;  // relative to sb0
+    if (unit >= n_units) return;
+    const uint64_t r = sb * 128 + rho;  // row relative to the first row written = index into the thresholds
+    unsigned long long out = 0;
+    if (r < n_rows) {
+        const uint64_t key = xmix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull));
+        const uint32_t th = t_het[r], tm = t_hom[r], tmi = t_miss[r];
+        for (int k = 0; k < 32; ++k) {
+            const uint64_t s = unit * 32 + k;
+            if (s < n_samples) {
+                const uint64_t h = xmix64(key + s);
+                const uint32_t gq = (uint32_t)h, ms = (uint32_t)(h >> 32);
+                const unsigned long long c = ms < tmi ? 3ull : (gq < tm ? 2ull : (gq < th ? 1ull : 0ull));
+                out |= c << (2 * k);
+            }
+        }
+    }
+    units[gt2x_unit_index(unit, sb0 + sb, n_units, n_sb) * 128 + rho] = out;
+}
+
+// plain rows (C-ABI order and codes, row stride src_stride_words) -> units; rows past n_rows of the last
+// superblock become zero.  One thread = one row of one unit.
+__global__ __launch_bounds__(256) void rows_to_gt2x_kernel(const uint32_t *__restrict__ src, uint64_t src_stride_words,
+                                                           uint64_t n_words, uint64_t n_rows,
+                                                           unsigned long long *__restrict__ units, uint64_t n_units,
+                                                           uint64_t n_sb, uint64_t sb0) {
+    const uint64_t unit = (uint64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+    const uint32_t rho = threadIdx.x & 127;
+    const uint64_t sb = blockIdx.y;
+    if (unit >= n_units) return;
+    const uint64_t r = sb * 128 + rho;
+    unsigned long long out = 0;
+    if (r < n_rows) {
+        const uint32_t *p = src + r * src_stride_words + unit * 2;
+        const unsigned long long lo = unit * 2 < n_words ? p[0] : 0u, hi = unit * 2 + 1 < n_words ? p[1] : 0u;
+        const unsigned long long x = lo | (hi << 32);
+        out = x ^ ((x >> 1) & 0x5555555555555555ull);  // NPS_CODE_* (2 = missing, 3 = dosage 2) -> 2 = dosage 2, 3 = missing
+    }
+    units[gt2x_unit_index(unit, sb0 + sb, n_units, n_sb) * 128 + rho] = out;
+}
+
+__global__ __launch_bounds__(256) void gt2x_to_rows_kernel(const unsigned long long *__restrict__ units, uint64_t n_units,
+                                                           uint64_t n_sb, uint64_t row0, uint64_t n_rows,
+                                                           uint32_t *__restrict__ dst, uint64_t dst_stride_words,
+                                                           uint64_t n_words) {
+    const uint64_t unit = (uint64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+    const uint64_t r = (uint64_t)blockIdx.y * 128 + (threadIdx.x & 127);  // relative to row0
+    if (unit >= n_units || r >= n_rows) return;
+    const uint64_t row = row0 + r;
+    unsigned long long x = units[gt2x_unit_index(unit, row >> 7, n_units, n_sb) * 128 + (row & 127)];
+    x ^= (x >> 1) & 0x5555555555555555ull;  // the recoding is its own inverse
+    uint32_t *p = dst + r * dst_stride_words + unit * 2;
+    if (unit * 2 < n_words) p[0] = (uint32_t)x;
+    if (unit * 2 + 1 < n_words) p[1] = (uint32_t)(x >> 32);
+}
+
+// a NPS_FMT_GT2 cohort (group-interleaved, plane-separated words, plain layout) -> units
+__global__ __launch_bounds__(256) void gt2_to_gt2x_kernel(const uint32_t *__restrict__ src, uint64_t stride_words,
+                                                          uint64_t n_words, uint64_t n_rows,
+                                                          unsigned long long *__restrict__ units, uint64_t n_units,
+                                                          uint64_t n_sb, uint64_t sb_off) {
+    const uint64_t unit = (uint64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+    const uint32_t rho = threadIdx.x & 127;
+    const uint64_t sb = sb_off + blockIdx.y;
+    if (unit >= n_units) return;
+    const uint64_t r = sb * 128 + rho;
+    unsigned long long out = 0;
+    if (r < n_rows) {
+        const unsigned long long lo = unit * 2 < n_words ? word_from_planes(src[g4_word_index(r, unit * 2, stride_words)]) : 0u;
+        const unsigned long long hi =
+            unit * 2 + 1 < n_words ? word_from_planes(src[g4_word_index(r, unit * 2 + 1, stride_words)]) : 0u;
+        const unsigned long long x = lo | (hi << 32);
+        out = x ^ ((x >> 1) & 0x5555555555555555ull);
+    }
+    units[gt2x_unit_index(unit, sb, n_units, n_sb) * 128 + rho] = out;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+static hipError_t grid_2d(uint64_t n_units, uint64_t n_sb, dim3 *grid) {
+    if (n_sb > 65535) return hipErrorInvalidValue;  // callers split the superblock range
+    *grid = dim3((uint32_t)((n_units + 1) / 2), (uint32_t)n_sb);
+    return hipSuccess;
+}
+
+hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,
+                             uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
+                             const uint32_t *d_t_hom, const uint32_t *d_t_miss) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    if (row0 & 127) return hipErrorInvalidValue;
+    const MxGeom gm = mx_geom(n_samples, n_rows_cohort);
+    dim3 grid;
+    hipError_t e = grid_2d(gm.n_units, (n_rows + 127) / 128, &grid);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_gt2x_kernel, grid, dim3(256), 0, st, (unsigned long long *)d_units, gm.n_units, gm.n_sb,
+                       n_samples, row0 >> 7, gen_row0, n_rows, seed, d_t_het, d_t_hom, d_t_miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words, uint64_t n_samples,
+                               uint64_t n_rows_cohort, uint64_t row0, uint64_t n_rows, void *d_units) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    if (row0 & 127) return hipErrorInvalidValue;
+    const MxGeom gm = mx_geom(n_samples, n_rows_cohort);
+    dim3 grid;
+    hipError_t e = grid_2d(gm.n_units, (n_rows + 127) / 128, &grid);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_to_gt2x_kernel, grid, dim3(256), 0, st, d_src, src_stride_words, words_for(n_samples), n_rows,
+                       (unsigned long long *)d_units, gm.n_units, gm.n_sb, row0 >> 7);
+    return hipGetLastError();
+}
+
+hipError_t launch_gt2x_to_rows(hipStream_t st, const void *d_units, uint64_t n_samples, uint64_t n_rows_cohort,
+                               uint64_t row0, uint64_t n_rows, uint32_t *d_dst, uint64_t dst_stride_words) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    const MxGeom gm = mx_geom(n_samples, n_rows_cohort);
+    dim3 grid;
+    hipError_t e = grid_2d(gm.n_units, (n_rows + 127) / 128, &grid);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(gt2x_to_rows_kernel, grid, dim3(256), 0, st, (const unsigned long long *)d_units, gm.n_units,
+                       gm.n_sb, row0, n_rows, d_dst, dst_stride_words, words_for(n_samples));
+    return hipGetLastError();
+}
+
+hipError_t launch_gt2_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t stride_words, uint64_t n_samples,
+                              uint64_t n_rows, void *d_units) {
+    if (n_rows == 0 || n_samples == 0) return hipSuccess;
+    const MxGeom gm = mx_geom(n_samples, n_rows);
+    (void)hipGetLastError();
+    for (uint64_t sb = 0; sb < gm.n_sb; sb += 32768) {
+        const uint64_t k = std::min<uint64_t>(32768, gm.n_sb - sb);
+        hipLaunchKernelGGL(gt2_to_gt2x_kernel, dim3((uint32_t)((gm.n_units + 1) / 2), (uint32_t)k), dim3(256), 0, st,
+                           d_src, stride_words, words_for(n_samples), n_rows, (unsigned long long *)d_units, gm.n_units,
+                           gm.n_sb, sb);
+    }
+    return hipGetLastError();
+}
+
+hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan) {
+    *plan = MxPlan{};
+    if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;
+    static int cus_cached[64] = {0};
+    int cus = device >= 0 && device < 64 ? cus_cached[device] : 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return e;
+        cus = prop.multiProcessorCount;
+        if (device >= 0 && device < 64) cus_cached[device] = cus;
+    }
+    const MxGeom gm = mx_geom(n_samples, n_rows);
+    if (gm.P > (uint32_t)cus || gm.P > 255 || gm.n_sb > 0x1fffffffull) return hipSuccess;  // 8-bit arrival count
+    plan->P = gm.P;
+    plan->nu_last = gm.nu_last;
+    plan->n_sb = (uint32_t)gm.n_sb;
+    plan->n_flush = (uint32_t)((gm.n_sb + kFlushSb - 1) / kFlushSb);
+    plan->cpart_floats = (uint64_t)plan->n_flush * gm.P * 64 * 2 * 256;
+    plan->ok = true;
+    return hipSuccess;
+}
+
+hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
+                           int64_t t_maxmis, int F, unsigned long long *d_tally, nps_locus_stat *d_stats,
+                           unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)fused_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    MxArgs a;
+    a.units = (const v4u *)d_units;
+    a.n_sb_cohort = n_sb_cohort;
+    a.sb0 = (uint32_t)sb0;
+    a.n_sb = plan.n_sb;
+    a.n_rows = n_rows;
+    a.n_samples = n_samples;
+    a.P = plan.P;
+    a.nu_last = plan.nu_last;
+    a.desc = d_desc;
+    a.prm = prm;
+    a.t_maxmis = t_maxmis;
+    a.scale = std::ldexp(1.0, F);
+    a.tally = d_tally;
+    a.stats = d_stats;
+    a.nloci = d_nloci;
+    a.const_sum = d_const_sum;
+    a.cpart = d_cpart;
+    a.timeout = d_timeout;
+    void *args[] = {&a};
+    return hipLaunchCooperativeKernel((const void *)fused_mx_kernel, dim3(plan.P), dim3(512), args, kLdsBytes, st);
+}
+
+hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
+                          const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
+                          uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status) {
+    (void)hipGetLastError();
+    const uint64_t blocks = std::max<uint64_t>(1, (n_samples + 255) / 256);
+    hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_flush, plan.P, n_samples,
+                       std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_timeout, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace nps

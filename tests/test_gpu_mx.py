@@ -1,0 +1,210 @@
+"""GPU parity tests of the matrix-core single-read kernel (NPS_FMT_GT2X cohorts, nps_mx.hip) vs the CPU oracle.
+
+Same bars as tests/test_gpu_parity.py: tallies / decisions / nloci bit-exact, scores within 1e-6 relative
+(in practice ~1e-13: the row weights are 45-bit fixed point).  Everything goes through the C-ABI.
+"""
+import numpy as np
+import pytest
+
+from nimpress_amd import capi
+from oracle import refcpu
+from tests.test_gpu_parity import PARAM_GRID, assert_stats_equal, make_cohort, oracle_scores, rel_err
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+
+
+def check_scores(scores, ref_scores, beta, nloci):
+    """the north star's bar -- 1e-6 relative, floored as in tests/test_gpu_parity.py -- or, for samples whose own
+    terms cancel to (almost) nothing, an absolute difference below 2^-50 of the mean absolute weight: the row
+    weights are 56-bit fixed point, i.e. as fine as the float64 rounding of the reference's own terms.  (Scores
+    of beta values with four decimals cancel to exactly zero for a few samples in 10^4; the reference's result for
+    those is its own rounding noise, ~1e-20, and no other summation reproduces that to six digits.)"""
+    got, ref = np.asarray(scores), np.asarray(ref_scores)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN positions differ"
+    ok = ~np.isnan(ref)
+    if not ok.any():
+        return
+    sb = float(np.sum(np.abs(beta))) / max(2.0 * nloci, 1.0)
+    d = np.abs(got[ok] - ref[ok])
+    tol = np.maximum(REL_TOL * np.maximum(np.abs(ref[ok]), 1e-12 * sb), 2.0 ** -50 * sb)
+    bad = np.nonzero(d > tol)[0]
+    if bad.size:  # say where: strip / unit / parity of the samples that differ
+        idx = np.nonzero(ok)[0][bad]
+        raise AssertionError("%d samples differ (max |d| %.3g, max relative %.3g): strips %s units %s parity %s first %s" % (
+            bad.size, d.max(), rel_err(got, ref, beta, max(nloci, 1)), np.unique(idx >> 11)[:20],
+            np.unique((idx >> 5) & 63)[:64], np.unique(idx & 1), idx[:12]))
+
+
+def score_gt2x(dev, n, kw, descs, offset, row0=0, mode=capi.MODE_AUTO):
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, descs, row0, mode)
+    stats = sc.flush()
+    scores, nloci = sc.finish(offset)
+    sc.close()
+    return scores, nloci, stats
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (31, 3), (32, 128), (33, 129), (1000, 300), (2048, 5), (2049, 257),
+                                   (4100, 40)])
+def test_gt2x_fill_paths_agree(shape):
+    """generator, upload of plain rows, conversion from a NPS_FMT_GT2 cohort: the same rows come back"""
+    n, m = shape
+    rng = np.random.default_rng(n * 7 + m)
+    co = make_cohort(n, m, 99 + n, rng)
+    words = (n + 15) // 16
+    want = co["codes"][:, :words]
+    a = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    a.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    assert np.array_equal(a.download(0, m), want)
+    a.close()
+    b = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    b.upload(0, co["codes"])
+    assert np.array_equal(b.download(0, m), want)
+    if m > 130:  # a sub-range that starts inside a superblock
+        assert np.array_equal(b.download(129, m - 130), want[129:m - 1])
+    b.close()
+    src = capi.Cohort(n, m)
+    src.upload(0, co["codes"])
+    c = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    c.convert_from(src)
+    assert np.array_equal(c.download(0, m), want)
+    c.close()
+    src.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (33, 1), (100, 3), (1000, 64), (2047, 127), (2048, 128), (2049, 129),
+                                   (4096, 257), (20000, 1001), (16385, 47), (40000, 385), (70000, 33), (5, 900)])
+def test_gt2x_resident_vs_oracle(shape):
+    """1 .. 35 strips (ragged last strip: 1 unit, 1 sample), 1 .. 8 superblocks (ragged last one), all decisions"""
+    n, m = shape
+    rng = np.random.default_rng(n + m)
+    co = make_cohort(n, m, 4242, rng)
+    kw = PARAM_GRID[(n + m) % len(PARAM_GRID)]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    scores, nloci, stats = score_gt2x(dev, n, kw, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0.0)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+
+
+@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
+def test_gt2x_all_imputation_modes(pk):
+    n, m = 3000, 200
+    rng = np.random.default_rng(900 + pk)
+    co = make_cohort(n, m, 31 + pk, rng)
+    kw = PARAM_GRID[pk]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.upload(0, co["codes"])
+    scores, nloci, stats = score_gt2x(dev, n, kw, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0.125,
+                                      mode=capi.MODE_FUSED)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.125)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+
+
+def test_gt2x_row_ranges_mixed_kinds_and_accumulation():
+    """two calls over sub-ranges of one cohort (cohort_row0 = 0 and 256), rows without genotype data in between,
+    NaN eaf, a large and a tiny beta in one definition"""
+    n, m_present = 5000, 600
+    rng = np.random.default_rng(77)
+    # score rows: every 25th one has no genotype data; the cohort holds the PRESENT rows only
+    kind_all = []
+    for j in range(m_present):
+        if j % 25 == 10:
+            kind_all.append([capi.ROW_UNCOVERED, capi.ROW_ABSENT, capi.ROW_FILTERED][j % 3])
+        kind_all.append(capi.ROW_PRESENT)
+    kind_all = np.array(kind_all, np.int32)
+    m = kind_all.size
+    co = make_cohort(n, m, 555, rng)
+    co["eaf"][5] = np.nan
+    co["beta"][7] = 3.5
+    co["beta"][9] = 1e-7
+    kw = PARAM_GRID[0]
+    dev = capi.Cohort(n, m_present, fmt=capi.FMT_GT2X)
+    dev.upload(0, co["codes"][:m_present])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    present_seen = 0
+    # first call: the score rows that consume cohort rows 0..255, second call: the rest
+    cut = int(np.nonzero(np.cumsum(kind_all == capi.ROW_PRESENT) == 256)[0][0]) + 1
+    for lo, hi in ((0, cut), (cut, m)):
+        sc.score_cohort(dev, capi.row_descs(co["beta"][lo:hi], co["eaf"][lo:hi], kind_all[lo:hi], co["rie"][lo:hi]),
+                        present_seen)
+        present_seen += int((kind_all[lo:hi] == capi.ROW_PRESENT).sum())
+    assert present_seen == m_present
+    stats = sc.flush()
+    scores, nloci = sc.finish(1.5)
+    sc.close()
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 1.5, kind_all)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+
+
+def test_gt2x_more_rows_than_one_flush():
+    """300 000 rows x 70 samples: the float32 digit sums are flushed after 262 144 rows"""
+    n, m = 70, 300_000
+    rng = np.random.default_rng(3)
+    co = make_cohort(n, m, 8, rng, force_missing_rows=False)
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=10)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    scores, nloci, stats = score_gt2x(dev, n, kw, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0.0)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert np.array_equal(stats["nmissing"], np.array([s[1] for s in ref_stats], dtype=np.uint64))
+    check_scores(scores, ref_scores, co["beta"], nloci)
+
+
+def test_gt2x_equals_table_kernel_large():
+    """500 000 samples x 4096 rows (245 strips, the bench geometry): the matrix-core kernel on the strip layout and
+    the table-lookup kernel on the row layout agree -- tallies and decisions bit for bit, scores to the weights'
+    quantisation -- at a size the oracle cannot reach"""
+    n, m = 500_000, 4096
+    rng = np.random.default_rng(123)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0, 0.02, m)
+    miss[::100] = 0.1
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    res = []
+    for fmt in (capi.FMT_GT2, capi.FMT_GT2X):
+        dev = capi.Cohort(n, m, fmt=fmt)
+        dev.synth(0, 5, th, tm, tmi)
+        sc = capi.Scorer(n, capi.make_params())
+        sc.score_cohort(dev, capi.row_descs(beta, eaf), 0, capi.MODE_FUSED)
+        stats = sc.flush()
+        scores, nloci = sc.finish(0.0)
+        res.append((stats, scores, nloci))
+        sc.close()
+        dev.close()
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0])
+    assert int((res[0][0]["reason"] == capi.REASON_MAXMIS).sum()) >= 30
+    scale = np.sum(np.abs(beta)) / (2 * res[0][2])
+    assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-10 * scale
+
+
+def test_gt2x_refusals():
+    dev = capi.Cohort(100, 300, fmt=capi.FMT_GT2X)
+    sc = capi.Scorer(100, capi.make_params())
+    d = capi.row_descs(np.zeros(10), np.full(10, 0.1))
+    with pytest.raises(capi.NpsError):
+        sc.score_cohort(dev, d, 5)                       # cohort_row0 not a multiple of 128
+    with pytest.raises(capi.NpsError):
+        sc.score_cohort(dev, d, 0, capi.MODE_TWOPASS)    # no two-pass kernels for this layout
+    with pytest.raises(capi.NpsError):
+        dev.upload(64, np.zeros((10, 7), np.uint32))     # row0 of an upload: whole superblocks
+    sc.score_cohort(dev, d, 128)                         # refused calls left the context usable
+    scores, nloci = sc.finish(0.0)
+    assert nloci == 10 and np.all(scores == 0.0)
+    sc.close()
+    dev.close()
