@@ -144,6 +144,8 @@ struct nps_ctx {
     float *d_mx_cpart = nullptr;            // NPS_FMT_GT2X runs: digit sums handed from fused_mx_kernel to mx_fold_kernel
     uint64_t mx_cpart_cap = 0;              // floats
     double *d_mx_const = nullptr;           // ... and the locus constants of rows over --maxmis (zero between passes)
+    unsigned long long *d_mx_tally1 = nullptr;  // first-stage tally words (groups of 16 strips), zero between passes
+    uint64_t mx_tally1_cap = 0;
     bool mx_plan_valid = false;
     uint64_t mx_plan_m = 0;
     MxPlan mx_plan_cache{};
@@ -296,6 +298,7 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_mx_cpart);
     (void)hipFree(c->d_mx_const);
+    (void)hipFree(c->d_mx_tally1);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -1450,6 +1453,12 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             HIP_TRY(hipMalloc(&c->d_mx_const, 256));
             HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, 256, c->stream));
         }
+        const uint64_t need1 = (uint64_t)((mxp.P + 15) / 16) * m_pad;
+        if (need1 > c->mx_tally1_cap) {
+            rc = grow(c, (void **)&c->d_mx_tally1, &c->mx_tally1_cap, need1, sizeof(unsigned long long));
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_mx_tally1, 0, sizeof(unsigned long long) * c->mx_tally1_cap, c->stream));
+        }
     }
     if (fused) {
         rc = grow(c, (void **)&c->d_part_fused, &c->part_fused_cap,
@@ -1528,7 +1537,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         {
             ProfScope ps(c, P_FUSED);
             fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                 def->d_desc, dev_params(c->params), t_maxmis, F, c->d_rtally, c->d_rstats, c->d_nloci,
+                                 def->d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally, c->d_mx_tally1, c->d_rstats,
+                                 c->d_nloci,
                                  c->d_mx_const, c->d_mx_cpart, c->d_timeout);
         }
         if (fe != hipSuccess) {
@@ -1540,7 +1550,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         {
             ProfScope ps(c, P_REDUCE);
             HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, c->d_mx_const, c->d_part,
-                                   c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_timeout, c->d_nloci + 1));
+                                   c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
+                                   (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1));
             HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double), c->stream));
         }
         c->chunks_used = std::max(c->chunks_used, 1u);

@@ -269,16 +269,19 @@ struct MxPlan {
     uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
 };
 hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan);
-// d_tally: [n_sb*128] zeroed; d_cpart: [plan.cpart_floats]; d_const_sum: one double, zero on entry;
+// d_tally: [n_sb*128] zeroed; d_tally1: [ceil(P/16)][n_sb*128] zeroed (both are zero again after launch_mx_fold); d_cpart: [plan.cpart_floats]; d_const_sum: one double, zero on entry; d_pre: 32 bytes
+// per row (scratch, written by the pass's first launch);
 // t_maxmis: largest nmissing with !((double)nmissing / (double)N > --maxmis); F: fixed-point scale 2^F with
 // |beta| (4 + max(2, 2 |eaf|)) 2^F < 2^56 for every row
 hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
-                           int64_t t_maxmis, int F, unsigned long long *d_tally, nps_locus_stat *d_stats,
+                           int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
+                           unsigned long long *d_tally1, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout);
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
-                          uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status);
+                          uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
+                          unsigned long long *d_status);
 // rows [row0, row0+n_rows) (row0 a multiple of 128) of a cohort of n_rows_cohort rows; rows past the end inside
 // the last superblock written become zero
 hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,

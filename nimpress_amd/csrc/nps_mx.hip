@@ -29,6 +29,7 @@
 //     accumulate k (LDS -> MFMA)            control wave: tables of k before the barrier, publish k+2 after it
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "nps_kernels.h"
 
@@ -42,13 +43,15 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 #define NPS_LDS __attribute__((address_space(3)))
 
-constexpr int kUD = 9;                   // units per data wave (waves 0..6); wave 7: the 64th unit + the control work
+constexpr int kUD = 9;                   // units per data wave (waves 0..5)
+constexpr int kUC = 5;                   // units of the two control waves (6, 7), which also do the per-row work of 64 rows each
 constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
 constexpr uint32_t kLdsTables = 131072;  // [2][3 operands][128 rows][16 bytes]
 constexpr uint32_t kLdsTally = kLdsTables + 12288;  // [2][128] uint32: nmissing << 16 | neffect of the strip
 constexpr uint32_t kLdsBytes = kLdsTally + 1024;
 constexpr uint32_t kMxSpinLimit = 1u << 20;
 
+struct MxPre;
 struct MxArgs {
     const v4u *units;        // the cohort
     uint64_t n_sb_cohort;    // its superblocks (a strip is n_sb_cohort * units-of-the-strip KiB)
@@ -57,10 +60,12 @@ struct MxArgs {
     uint64_t n_samples;
     uint32_t P, nu_last;     // strips, units of the last one
     const nps_row_desc *desc;
+    const MxPre *pre;        // per score row, from mx_prep_kernel: what does not depend on the tallies
     DevParams prm;
     int64_t t_maxmis;        // the largest nmissing for which nmissing / N > --maxmis is false (-1: none)
     double scale;            // 2^F
     unsigned long long *tally;  // [n_sb * 128], zero on entry
+    unsigned long long *tally1;  // [groups of 16 strips][n_sb * 128], zero on entry: first stage of the hand-over
     nps_locus_stat *stats;
     unsigned long long *nloci;
     double *const_sum;       // += the locus constants of rows over --maxmis (added to every sample by mx_fold_kernel)
@@ -108,12 +113,62 @@ static __device__ __forceinline__ void mx_codes(long long w, uint32_t flag, uint
     }
 }
 
+// Per score row, everything that does not depend on the row's tally (one launch per pass, before the fused kernel):
+// the weight of a unit of dosage w1 = round(beta 2^F) with its operand bytes, and the weight wfb of a missing
+// genotype whenever the imputed dosage is known beforehand (ps / homref / fail, and the fall-back of int_ps /
+// int_fail below --mincs).
+struct MxPre {
+    uint32_t c[3];
+    uint32_t flags;  // 1: beta is not finite (every sample's sum becomes NaN); 2: wfb stands for NaN
+    long long w1, wfb;
+};
+static_assert(sizeof(MxPre) == 32, "MxPre layout");
+static_assert(6 * kUD + 2 * kUC == 64, "units of a strip");
+
+__global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows,
+                                                      DevParams prm, double scale, MxPre *__restrict__ pre) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_rows) return;
+    const double beta = desc[j].beta, eaf = desc[j].eaf;
+    const bool rie = desc[j].ref_is_effect != 0;
+    const double inf = __builtin_huge_val(), nan = __longlong_as_double(0x7ff8000000000000ll);
+    MxPre o;
+    o.c[0] = o.c[1] = o.c[2] = 0u;
+    o.flags = 0u;
+    o.w1 = o.wfb = 0;
+    if (!(fabs(beta) < inf)) {
+        o.flags = 1u;
+    } else {
+        o.w1 = __double2ll_rn(beta * scale);
+        mx_codes(o.w1, 0u, o.c);
+        const double imp = prm.imp_sample == NPS_SAMPLE_HOMREF ? (rie ? 2.0 : 0.0)
+                           : (prm.imp_sample == NPS_SAMPLE_FAIL || prm.imp_sample == NPS_SAMPLE_INT_FAIL) ? nan
+                                                                                                          : eaf * 2.0;
+        const double t = imp * beta;  // the product the reference adds for a missing sample (nimpress.nim:639)
+        if (!(fabs(t) < inf)) {
+            o.flags = 2u;
+            o.wfb = 3 * o.w1;
+        } else {
+            o.wfb = __double2ll_rn(t * scale);
+        }
+    }
+    pre[j] = o;
+}
+
+// n / d for 0 <= n <= d < 2^27 (0 / 0 = NaN), within an ulp: the weights it feeds are rounded to 2^-56 anyway
+static __device__ __forceinline__ double fast_ratio(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
 // One row, from its complete tally word: the decisions of getImputedDosages (nimpress.nim:565-571), the locus
 // constant (:417-447) or the sample imputation value (:450-481), as the three weight operands of the row.
 static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long long x, bool live, uint64_t row,
-                                              double beta, double eaf, bool rie, bool write_stats,
-                                              uint32_t (&wc)[3], uint32_t (&wme)[3], uint32_t (&wmo)[3], int &used,
-                                              double &cst) {
+                                              const MxPre &pre, bool write_stats, uint32_t (&wc)[3], uint32_t (&wme)[3],
+                                              uint32_t (&wmo)[3], int &used, double &cst) {
     wc[0] = wc[1] = wc[2] = wme[0] = wme[1] = wme[2] = wmo[0] = wmo[1] = wmo[2] = 0u;
     used = 0;
     cst = 0.0;
@@ -124,7 +179,9 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
     int reason;
     if ((int64_t)nmiss > a.t_maxmis) {  // == (double)nmiss / (double)N > --maxmis, t_maxmis found with that very division
         reason = NPS_REASON_MAXMIS;
-        if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
+        if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {  // (rare: the row's score entry is fetched here)
+            const double beta = a.desc[row].beta, eaf = a.desc[row].eaf;
+            const bool rie = a.desc[row].ref_is_effect != 0;
             const double c = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
                              : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
                                                                    : nan;
@@ -134,28 +191,22 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
     } else {
         reason = NPS_REASON_GENOTYPED;
         used = 1;
-        double imp;
-        switch (a.prm.imp_sample) {
-        case NPS_SAMPLE_PS: imp = eaf * 2.0; break;
-        case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
-        case NPS_SAMPLE_FAIL: imp = nan; break;
-        default:
-            if ((double)ngen >= a.prm.min_cs)
-                imp = (double)neff / (double)ngen;
-            else
-                imp = a.prm.imp_sample == NPS_SAMPLE_INT_PS ? eaf * 2.0 : nan;
-            break;
-        }
-        if (!(fabs(beta) < __builtin_huge_val())) {
+        if (pre.flags & 1u) {
             cst = nan;  // a non-finite beta makes every sample's sum NaN (0 * NaN, NaN + x), as in the reference
         } else {
-            const long long w1 = __double2ll_rn(beta * a.scale);
-            const double t = imp * beta;  // the product the reference adds for a missing sample (nimpress.nim:639)
-            const bool bad = !(fabs(t) < __builtin_huge_val());  // NaN (or overflow): the sample's score is NaN
-            const long long wi = bad ? 3 * w1 : __double2ll_rn(t * a.scale);
-            mx_codes(w1, 0u, wc);
-            mx_codes(wi - 3 * w1, bad ? 1u : 0u, wme);  // a missing genotype has code 3 (4 in the odd operand)
-            mx_codes(wi - 4 * w1, bad ? 1u : 0u, wmo);
+            long long wi = pre.wfb;
+            bool bad = (pre.flags & 2u) != 0;
+            const bool internal = a.prm.imp_sample == NPS_SAMPLE_INT_PS || a.prm.imp_sample == NPS_SAMPLE_INT_FAIL;
+            if (internal && (double)ngen >= a.prm.min_cs) {
+                const double imp = fast_ratio((double)neff, (double)ngen);
+                bad = imp != imp;
+                wi = bad ? 3 * pre.w1 : __double2ll_rn(imp * (double)pre.w1);
+            }
+            wc[0] = pre.c[0];
+            wc[1] = pre.c[1];
+            wc[2] = pre.c[2];
+            mx_codes(wi - 3 * pre.w1, bad ? 1u : 0u, wme);  // a missing genotype has code 3 (4 in the odd operand)
+            mx_codes(wi - 4 * pre.w1, bad ? 1u : 0u, wmo);
         }
     }
     if (write_stats) {
@@ -172,14 +223,17 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // NU: units the wave can own (register arrays); GUARD: it may own fewer (ragged last strip) -- without guards the
 // compiler pipelines across units; CTL: the control wave (its own code path, so that the data waves' registers
 // hold nothing of it)
-template <int NU, bool GUARD, bool CTL>
+// DBG (diagnostics builds only): 1 no tally popcounts, 2 no accumulation, 4 no hand-over (no atomics, no wait),
+// 8 no weight digits (zero tables), 16 no parking
+template <int NU, bool GUARD, bool CTL, int DBG>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
     const uint32_t strip = blockIdx.x;
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave * kUD;
+    const int u0 = wave < 6 ? wave * kUD : 6 * kUD + (wave - 6) * kUC;
+    const int crow = lane + 64 * (wave - 6);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
 
@@ -216,6 +270,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         uint32_t xa = 0, ya = 0, za = 0, xb = 0, yb = 0, zb = 0;
     };
     auto tally_unit = [&](Tal &t, const v4u w) {
+        if (DBG & 1) return;
         const uint32_t sx = w.x >> 1, sy = w.y >> 1, sz = w.z >> 1, sw = w.w >> 1;
         t.xa = bcnt_acc(w.y, bcnt_acc(w.x, t.xa));
         t.ya = bcnt_acc((w.x & 0xAAAAAAAAu) | (sy & 0x55555555u), t.ya);
@@ -239,7 +294,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             for (int u = 0; u < NU; ++u)
                 if (full || u < n_my) {
                     tally_unit(t, b_tal[u]);
-                    *reinterpret_cast<v4u *>(s_park + u * 1024 + woff) = b_park[u];
+                    if (!(DBG & 16)) *reinterpret_cast<v4u *>(s_park + u * 1024 + woff) = b_park[u];
                     b_park[u] = load_unit(k + 3, u);
                 }
             tally_add(k + 2, t);
@@ -257,7 +312,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 
     // scores += code * Wc + is_missing * Wm for the wave's units of superblock k (parked in `slot`)
     auto accumulate = [&](uint32_t k, const char *slot) {
-        if (k >= a.n_sb || n_my == 0) return;
+        if (k >= a.n_sb || n_my == 0 || (DBG & 2)) return;
         const char *tab = smem + kLdsTables + (k & 1) * 6144;
         v8i Bc, Bme, Bmo;
         {
@@ -303,45 +358,40 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         }
     };
 
-    // ---- control state (wave 7)
+    // ---- control state (waves 6 and 7: 64 rows of every superblock each)
     uint32_t nloci_local = 0;
     double cst_local = 0.0;
     bool timed_out = false;
-    double nbeta[2] = {0.0, 0.0}, neaf[2] = {0.0, 0.0};
-    bool nrie[2] = {false, false};
-    auto ctl_fetch_desc = [&](uint32_t k) {  // score rows of superblock k, a step before they are needed
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
-            if (k < a.n_sb && row < a.n_rows) {
-                nbeta[rr] = a.desc[row].beta;
-                neaf[rr] = a.desc[row].eaf;
-                nrie[rr] = a.desc[row].ref_is_effect != 0;
-            }
+    MxPre npre;
+    npre.c[0] = npre.c[1] = npre.c[2] = npre.flags = 0u;
+    npre.w1 = npre.wfb = 0;
+    auto ctl_fetch_pre = [&](uint32_t k) {  // the row's precomputed part, a step before it is needed
+        const uint64_t row = (uint64_t)k * 128 + crow;
+        if (k < a.n_sb && row < a.n_rows) {
+            const v4u *p = reinterpret_cast<const v4u *>(a.pre + row);
+            const v4u p0 = p[0], p1 = p[1];
+            npre.c[0] = p0.x;
+            npre.c[1] = p0.y;
+            npre.c[2] = p0.z;
+            npre.flags = p0.w;
+            npre.w1 = (long long)((unsigned long long)p1.x | ((unsigned long long)p1.y << 32));
+            npre.wfb = (long long)((unsigned long long)p1.z | ((unsigned long long)p1.w << 32));
         }
     };
     // the tally words of superblock k were published by every strip more than a step ago: normally one poll
     auto ctl_tables = [&](uint32_t k) {
         if (k >= a.n_sb) return;
-        unsigned long long x[2];
-        bool valid[2], ok[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
-            valid[rr] = row < a.n_rows;
-            x[rr] = valid[rr] ? __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            ok[rr] = !valid[rr] || (uint32_t)(x[rr] >> 56) == a.P;
-        }
+        const uint64_t row = (uint64_t)k * 128 + crow;
+        const bool valid = row < a.n_rows;
+        unsigned long long x = valid ? __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bool ok = !valid || (uint32_t)(x >> 56) == a.P || (DBG & 4);
         uint32_t spins = 0;
-        while (!__all(ok[0] && ok[1]) && !timed_out) {
+        while (!__all(ok) && !timed_out) {
             __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-                if (!ok[rr]) {
-                    const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
-                    x[rr] = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok[rr] = (uint32_t)(x[rr] >> 56) == a.P;
-                }
+            if (!ok) {
+                x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t)(x >> 56) == a.P;
+            }
             if ((++spins & 255u) == 0) {
                 const unsigned int t = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (t != 0 || spins >= kMxSpinLimit) {
@@ -350,36 +400,42 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 }
             }
         }
-        char *tab = smem + kLdsTables + (k & 1) * 6144;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint64_t row = (uint64_t)k * 128 + lane + 64 * rr;
-            uint32_t wc[3], wme[3], wmo[3];
-            int used;
-            double cst;
-            mx_row(a, x[rr], valid[rr] && ok[rr], row, nbeta[rr], neaf[rr], nrie[rr], strip == 0 && a.stats != nullptr,
-                   wc, wme, wmo, used, cst);
-            char *p = tab + (lane + 64 * rr) * 16;
-            *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
-            *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
-            *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
-            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
-            cst_local += cst;
+        uint32_t wc[3], wme[3], wmo[3];
+        int used;
+        double cst;
+        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);
+        char *p = smem + kLdsTables + (k & 1) * 6144 + crow * 16;
+        *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
+        *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
+        *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
+        nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+        cst_local += cst;
+    };
+    // The strip's tallies of superblock kp are complete in LDS (barrier passed).  Same-line atomics are served one
+    // after the other at the memory side (~25 ns each), so 245 strips adding to one row's word would take longer
+    // than the step and a half the pipeline allows: the strips arrive in groups of 16 on a word of their group,
+    // and the strip whose add completes a group (told by the value its add returned) adds the group's sum to the
+    // row's word: at most 16 adds in a row on either word.
+    const uint32_t grp = strip >> 4, grp_size = min(16u, a.P - (grp << 4));
+    unsigned long long pub_old = 0ull, pub_add = 0ull;
+    bool pub_live = false;
+    auto ctl_publish_begin = [&](uint32_t kp) {
+        uint32_t *T = reinterpret_cast<uint32_t *>(smem + kLdsTally) + (kp & 1) * 128;
+        const uint32_t v = T[crow];
+        T[crow] = 0u;
+        const uint64_t row = (uint64_t)kp * 128 + crow;
+        pub_live = kp < a.n_sb && row < a.n_rows && !(DBG & 4);
+        if (pub_live) {
+            pub_add = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
+            pub_old = __hip_atomic_fetch_add(&a.tally1[(uint64_t)grp * a.n_sb * 128 + row], pub_add, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // the strip's tallies of superblock kp are complete in LDS (barrier passed): one atomic per row
-    auto ctl_publish = [&](uint32_t kp) {
-        uint32_t *T = reinterpret_cast<uint32_t *>(smem + kLdsTally) + (kp & 1) * 128;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = lane + 64 * rr;
-            const uint32_t v = T[r];
-            T[r] = 0u;
-            const uint64_t row = (uint64_t)kp * 128 + r;
-            if (kp < a.n_sb && row < a.n_rows) {
-                const unsigned long long add = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
-                __hip_atomic_fetch_add(&a.tally[row], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+    auto ctl_publish_end = [&](uint32_t kp) {
+        if (pub_live) {
+            const unsigned long long tot = pub_old + pub_add;
+            if ((uint32_t)(tot >> 56) == grp_size)
+                __hip_atomic_fetch_add(&a.tally[(uint64_t)kp * 128 + crow], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
@@ -387,7 +443,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     if (tid < 256) reinterpret_cast<uint32_t *>(smem + kLdsTally)[tid] = 0u;
     load_sb(0, bank[0]);
     load_sb(1, bank[1]);
-    if (is_ctl) ctl_fetch_desc(0);
+    if (is_ctl) ctl_fetch_pre(0);
     __syncthreads();
     if (n_my != 0 && a.n_sb > 0) {
         Tal t;
@@ -397,7 +453,10 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         tally_add(0, t);
     }
     __syncthreads();
-    if (is_ctl) ctl_publish(0);
+    if (is_ctl) {
+        ctl_publish_begin(0);
+        ctl_publish_end(0);
+    }
     if (n_my != 0 && a.n_sb > 1) {
         Tal t;
 #pragma unroll
@@ -412,18 +471,22 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
     load_sb(2, bank[0]);
     __syncthreads();
-    if (is_ctl) ctl_publish(1);
+    if (is_ctl) {
+        ctl_publish_begin(1);
+        ctl_publish_end(1);
+    }
 
     // ---- steps
     auto step = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park, const char *s_acc) {
         if (is_ctl) ctl_tables(k);
         front(k, b_tal, b_park, s_park);
         __syncthreads();
-        accumulate(k, s_acc);
-        if (is_ctl) {
-            ctl_publish(k + 2);
-            ctl_fetch_desc(k + 1);
+        if (is_ctl) {  // the returning add and the loads are in flight during the wave's own accumulation
+            ctl_publish_begin(k + 2);
+            ctl_fetch_pre(k + 1);
         }
+        accumulate(k, s_acc);
+        if (is_ctl) ctl_publish_end(k + 2);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < a.n_sb) store_c(k / kFlushSb, true);
     };
     const uint32_t n_steps = (a.n_sb + 1) / 2 * 2;
@@ -442,17 +505,18 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
-    if (wave == 7)
-        mx_body<64 - 7 * kUD, true, true>(a, smem);
+    if (wave >= 6)
+        mx_body<kUC, true, true, DBG>(a, smem);
     else if (nu - wave * kUD >= kUD)
-        mx_body<kUD, false, false>(a, smem);
+        mx_body<kUD, false, false, DBG>(a, smem);
     else
-        mx_body<kUD, true, false>(a, smem);
+        mx_body<kUD, true, false, DBG>(a, smem);
 }
 
 // Epilogue of a pass: the sixteen digit sums of a sample -> float64, plus the pass's locus constants, into chunk 0
@@ -461,11 +525,13 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
                                                       uint64_t n, double inv_scale, const double *__restrict__ const_sum,
                                                       double *__restrict__ part0, int overwrite,
                                                       unsigned long long *__restrict__ tally, uint64_t n_tally,
+                                                      unsigned long long *__restrict__ tally1, uint64_t n_tally1,
                                                       unsigned int *__restrict__ timeout,
                                                       unsigned long long *__restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
     for (uint64_t j = i; j < n_tally; j += nthreads) tally[j] = 0ull;
+    for (uint64_t j = i; j < n_tally1; j += nthreads) tally1[j] = 0ull;
     if (i == 0 && timeout) {
         if (*timeout) atomicOr(status, 1ull);
         *timeout = 0u;
@@ -671,14 +737,36 @@ hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan
 
 hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
-                           int64_t t_maxmis, int F, unsigned long long *d_tally, nps_locus_stat *d_stats,
+                           int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
+                           unsigned long long *d_tally1, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)fused_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kLdsBytes);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(mx_prep_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, d_desc, n_rows, prm,
+                       std::ldexp(1.0, F), (MxPre *)d_pre);
+    {
+        hipError_t pe = hipGetLastError();
+        if (pe != hipSuccess) return pe;
+    }
+    const void *fn = (const void *)fused_mx_kernel<0>;
+#ifdef NPS_DIAGNOSTICS
+    // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
+    static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
+    switch (dbg) {
+    case 1: fn = (const void *)fused_mx_kernel<1>; break;
+    case 2: fn = (const void *)fused_mx_kernel<2>; break;
+    case 3: fn = (const void *)fused_mx_kernel<3>; break;
+    case 4: fn = (const void *)fused_mx_kernel<4>; break;
+    case 12: fn = (const void *)fused_mx_kernel<12>; break;
+    case 15: fn = (const void *)fused_mx_kernel<15>; break;
+    case 31: fn = (const void *)fused_mx_kernel<31>; break;
+    default: break;
+    }
+#endif
+    static const void *attr_set = nullptr;
+    if (attr_set != fn) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = fn;
     }
     MxArgs a;
     a.units = (const v4u *)d_units;
@@ -690,26 +778,30 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.P = plan.P;
     a.nu_last = plan.nu_last;
     a.desc = d_desc;
+    a.pre = (const MxPre *)d_pre;
     a.prm = prm;
     a.t_maxmis = t_maxmis;
     a.scale = std::ldexp(1.0, F);
     a.tally = d_tally;
+    a.tally1 = d_tally1;
     a.stats = d_stats;
     a.nloci = d_nloci;
     a.const_sum = d_const_sum;
     a.cpart = d_cpart;
     a.timeout = d_timeout;
     void *args[] = {&a};
-    return hipLaunchCooperativeKernel((const void *)fused_mx_kernel, dim3(plan.P), dim3(512), args, kLdsBytes, st);
+    return hipLaunchCooperativeKernel(fn, dim3(plan.P), dim3(512), args, kLdsBytes, st);
 }
 
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
-                          uint64_t n_tally, unsigned int *d_timeout, unsigned long long *d_status) {
+                          uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
+                          unsigned long long *d_status) {
     (void)hipGetLastError();
-    const uint64_t blocks = std::max<uint64_t>(1, (n_samples + 255) / 256);
+    const uint64_t blocks = std::max<uint64_t>(std::max<uint64_t>(1, (n_samples + 255) / 256), std::min<uint64_t>(4096, n_tally1 / 1024));
     hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_flush, plan.P, n_samples,
-                       std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_timeout, d_status);
+                       std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_tally1, n_tally1, d_timeout,
+                       d_status);
     return hipGetLastError();
 }
 

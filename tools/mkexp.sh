@@ -10,7 +10,7 @@ rm -rf "$D"; mkdir -p "$D/nimpress_amd" "$D/oracle" "$D/tools"
 cp "$R"/bench.py "$D"/
 cp "$R"/nimpress_amd/*.py "$D"/nimpress_amd/
 cp "$R"/oracle/*.py "$R"/oracle/*.so "$D"/oracle/ 2>/dev/null || true
-cp "$R"/tools/qb.py "$R"/tools/qb_multi.py "$D"/tools/
+cp "$R"/tools/qb.py "$R"/tools/qb_multi.py "$R"/tools/qb_mx.py "$D"/tools/
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off "$@" \
     -o "$D"/nimpress_amd/libnps.so "$R"/nimpress_amd/csrc/*.hip
 echo "built $D"
