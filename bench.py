@@ -59,6 +59,10 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (config 5 DS pass, streaming entry points, "
                          "config 2 end to end)")
+    ap.add_argument("--layout", choices=["strip", "rows"], default="strip",
+                    help="2-bit cohort layout: strip = NPS_FMT_GT2X (strips of 2048 samples x superblocks of 128 rows, "
+                         "scored by the matrix-core single-read kernel; the headline), rows = NPS_FMT_GT2 (row groups, "
+                         "scored by the table-lookup single-read kernel)")
     ap.add_argument("--no-optimize", action="store_true",
                     help="skip nps_cohort_optimize (the parity layout of the high-bit planes: the table lookups "
                          "spread over twice as many LDS banks)")
@@ -237,8 +241,14 @@ def score_delta(stats, got, nloci, fmt, beta, eaf, seed, n, m, th, tm, tmi, geom
     ref = sums / (2.0 * ref_nloci)
     idx = samples.astype(np.int64)
     delta = np.abs(got[idx] - ref)
-    floor = 1e-12 * float(np.sum(np.abs(beta))) / (2.0 * max(int(nloci), 1))
+    mean_w = float(np.sum(np.abs(beta))) / (2.0 * max(int(nloci), 1))
+    floor = 1e-12 * mean_w
+    # the bar of tests/test_gpu_mx.py: 1e-6 relative, or -- for samples whose own terms cancel to (almost) nothing --
+    # an absolute difference below 2^-50 of the mean absolute weight (the float64 rounding of the terms themselves)
+    within = bool(np.all(delta <= np.maximum(1e-6 * np.maximum(np.abs(ref), floor), 2.0 ** -50 * mean_w)))
     return {"max_abs": float(delta.max()), "max_rel": float((delta / np.maximum(np.abs(ref), floor)).max()),
+            "max_abs_over_mean_abs_weight": float(delta.max() / mean_w) if mean_w > 0 else 0.0,
+            "within_1e-6_relative_or_2^-50_of_mean_weight": within,
             "nloci_equal": bool(int(nloci) == int(ref_nloci) == int(stats["used"].sum())),
             "tally_recount_equal": tally_ok, "samples_checked": int(samples.size),
             "slices_covered": "%d of %d" % (n_slices, max(slices, n_slices)), "rows_recounted": int(rows.size),
@@ -434,6 +444,68 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     return out
 
 
+def layout_sweep(capi, device, n, m, seed, steps=3):
+    """The single-score pass by genotype distribution (the table-lookup kernel's time depends on
+    how a wave's 64 table indices spread over the LDS banks; the matrix-core kernel's must not).  Six synthetic
+    cohorts of the bench shape, each regenerated on the device; best of `steps` passes, HIP events on the
+    library's stream.  Both kernels for the bench distribution and for the table kernel's worst case."""
+    import torch
+    rng = np.random.default_rng(seed)
+    beta = np.round(rng.normal(0.0, 0.02, m), 4)
+    SC = 4294967296.0
+    f = lambda x: np.minimum(np.floor(np.asarray(x, dtype=np.float64) * SC), 4294967295.0).astype(np.uint32)
+    one = np.ones(m)
+
+    def hwe(eaf, miss):
+        return f(eaf * eaf + 2 * eaf * (1 - eaf)), f(eaf * eaf), f(miss)
+
+    bench_miss = rng.uniform(0, 0.02, m)
+    bench_miss[::1000] = 0.10
+    cases = [
+        ("bench (eaf U(0.01,0.5), 1 % missing)", hwe(np.round(rng.uniform(0.01, 0.5, m), 4), bench_miss), {}, True),
+        ("low MAF (eaf U(0.001,0.05))", hwe(rng.uniform(0.001, 0.05, m), rng.uniform(0, 0.02, m)), {}, False),
+        ("eaf 0.5 everywhere", hwe(0.5 * one, rng.uniform(0, 0.02, m)), {}, True),
+        ("all heterozygous (non-HWE)", (f(one), f(0 * one), f(0 * one)), {}, False),
+        ("20 % missing, --maxmis=1", hwe(np.round(rng.uniform(0.01, 0.5, m), 4), 0.2 * one), dict(maxmis=1.0), False),
+        ("uniform codes, --maxmis=1", (f(2 * one / 3), f(one / 3), f(0.25 * one)), dict(maxmis=1.0), False),
+    ]
+    alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
+    d = torch.empty(n, dtype=torch.float64, device="cuda")
+    sdef = capi.ScoreDef(capi.row_descs(beta, 0.3 * one), device=device)
+    out = []
+    for name, (th, tm, tmi), kw, both in cases:
+        row = {"cohort": name}
+        for label, fmt in (("strip_layout_matrix_cores", capi.FMT_GT2X), ("row_layout_table_lookups", capi.FMT_GT2)):
+            if fmt == capi.FMT_GT2 and not both:
+                continue
+            co = capi.Cohort(n, m, fmt=fmt, device=device)
+            for x in range(0, m, 1 << 15):
+                y = min(m, x + (1 << 15))
+                co.synth_at(x, x, seed, th[x:y], tm[x:y], tmi[x:y])
+            if fmt == capi.FMT_GT2:
+                co.optimize()
+            sc = capi.Scorer(n, capi.make_params(**kw), device=device)
+            best = None
+            for i in range(steps + 1):
+                sc.reset()
+                sc.profile_enable(True)
+                sc.profile_get(reset=True)
+                sc.score_cohort_def(co, sdef, 0, capi.MODE_FUSED)
+                sc.finish_device(0.0, d.data_ptr())
+                ms = sc.profile_get(reset=True).ms_fused
+                if i:
+                    best = ms if best is None else min(best, ms)
+            sc.close()
+            co.close()
+            torch.cuda.empty_cache()
+            row[label] = {"ms_per_pass": best, "frac_of_8TBps": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out.append(row)
+    sdef.close()
+    fr = [r["strip_layout_matrix_cores"]["frac_of_8TBps"] for r in out]
+    return {"shape": "%d samples x %d rows" % (n, m), "cases": out, "strip_layout_worst_frac": min(fr),
+            "strip_layout_best_frac": max(fr)}
+
+
 def streaming_rates(capi, device, n, seed):
     """The drop-in entry points (what the command line uses): one call per score row with a HOST buffer, so
     these rates include the pinned copy + PCIe transfer + decode launch per row.  Never `value`."""
@@ -526,7 +598,8 @@ def main():
     mode = {"auto": capi.MODE_AUTO, "twopass": capi.MODE_TWOPASS, "fused": capi.MODE_FUSED}[args.mode]
     is_ds = args.format == "ds"
     strong = args.scaling == "strong" and world > 1
-    fmt = capi.FMT_DS32 if is_ds else capi.FMT_GT2
+    strip = args.layout == "strip" and not is_ds
+    fmt = capi.FMT_DS32 if is_ds else (capi.FMT_GT2X if strip else capi.FMT_GT2)
 
     # synthetic cohort, generated on the device; identical on every rank (same seed)
     _, eaf, miss = synth_score(m, args.seed, args.format)
@@ -544,8 +617,8 @@ def main():
         for x in range(a, b, 1 << 15):      # (the DS generator takes at most 65 535 rows per call)
             y = min(b, x + (1 << 15))
             cohort.synth_at(x - a, x, args.seed, t_het[x:y], t_hom[x:y], t_miss[x:y])
-        if not args.no_optimize:
-            cohort.optimize()  # one-time layout step of a resident cohort (nps_cohort_optimize), untimed
+        if not args.no_optimize and not strip:
+            cohort.optimize()  # one-time layout step of a resident NPS_FMT_GT2 cohort (nps_cohort_optimize), untimed
 
     # this rank's score definition.  weak: its own betas (score files sharded across GPUs); strong: all
     # ranks share ONE score, each holds its rows
@@ -616,6 +689,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    failed = []   # secondary measurements that raised (rank 0): the line is printed, the exit status is 1
     if rank == 0:
         steps = max(args.steps, 1)
         genotypes_per_step = float(n) * float(m)
@@ -631,7 +705,8 @@ def main():
         dominant = max(("tally", "accumulate", "fused"), key=lambda k: kern_ms[k])
         achieved = alg_bytes / (hot_ms_per_step * 1e-3) / 1e9 if hot_ms_per_step > 0 else 0.0
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_ds.json" if is_ds else "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_ds.json" if is_ds else
+                             ("traffic_strip.json" if strip else "traffic.json"))
         if os.path.exists(tpath) and not strong:
             try:
                 tj = json.load(open(tpath))
@@ -664,7 +739,10 @@ def main():
                        "resident_chunks": len(chunks), "chunk_rows": chunk,
                        "persistent_grid": {"slices": geometry[0], "teams": geometry[1],
                                            "samples_per_slice": geometry[2]},
-                       "cohort_layout": "plain" if (args.no_optimize or is_ds) else
+                       "cohort_layout": ("NPS_FMT_GT2X: strips of 2048 samples x superblocks of 128 rows x 1 KiB units; "
+                                         "one workgroup per strip, FP4 codes x FP6 weight digits on the matrix cores, "
+                                         "popcount tallies, time independent of the genotypes") if strip else
+                                        "plain" if (args.no_optimize or is_ds) else
                                         "nps_cohort_optimize (one-time, untimed, data independent: parity layout of "
                                         "the high-bit planes, table lookups over twice as many LDS banks)",
                        "mode": args.mode, "parallelism": parallelism},
@@ -697,31 +775,40 @@ def main():
             torch.cuda.empty_cache()
             import tempfile
             secondary = {}
-            try:
-                secondary["multi_score"] = multi_score(capi, local_rank, args, n, m, args.seed)
-                secondary["multi_score"]["vs_single_score_passes"] = (
-                    args.steps and (elapsed / steps * 1e3) / secondary["multi_score"]["ms_per_score"])
-            except Exception as e:      # a secondary measurement never takes the headline down
-                secondary["multi_score"] = {"error": repr(e)[:300]}
-            torch.cuda.empty_cache()
-            try:
-                secondary["config5_ds"] = ds_config5(capi, local_rank, args)
-            except Exception as e:      # a secondary measurement never takes the headline down
-                secondary["config5_ds"] = {"error": repr(e)[:300]}
-            try:
-                secondary["streaming"] = streaming_rates(capi, local_rank, n, args.seed)
-            except Exception as e:
-                secondary["streaming"] = {"error": repr(e)[:300]}
-            try:
+
+            def leg(name, fn):
+                # a failing secondary measurement never takes the headline line down, but it does fail the run
+                try:
+                    secondary[name] = fn()
+                except Exception as e:
+                    secondary[name] = {"error": repr(e)[:300]}
+                if isinstance(secondary[name], dict) and "error" in secondary[name]:
+                    failed.append(name)
+                torch.cuda.empty_cache()
+
+            leg("layout_sweep", lambda: layout_sweep(capi, local_rank, n, m, args.seed))
+
+            def multi_leg():
+                r = multi_score(capi, local_rank, args, n, m, args.seed)
+                r["vs_single_score_passes"] = args.steps and (elapsed / steps * 1e3) / r["ms_per_score"]
+                return r
+
+            leg("multi_score", multi_leg)
+            leg("config5_ds", lambda: ds_config5(capi, local_rank, args))
+            leg("streaming", lambda: streaming_rates(capi, local_rank, n, args.seed))
+
+            def config2_leg():
                 with tempfile.TemporaryDirectory() as td:
-                    secondary["config2"] = config2_e2e(td)
-            except Exception as e:
-                secondary["config2"] = {"error": repr(e)[:300]}
+                    return config2_e2e(td)
+
+            leg("config2", config2_leg)
             out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: secondary measurement(s) failed: %s" % ", ".join(failed))
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ from nimpress_amd import capi as real  # noqa: E402  (constants and pure-numpy h
 
 RANK = int(os.environ.get("RANK", "0"))
 fake = types.ModuleType("nimpress_amd.capi")
-for name in ("MODE_AUTO", "MODE_TWOPASS", "MODE_FUSED", "FMT_GT2", "FMT_DS32", "FMT_GT2M", "ROW_DESC_DTYPE",
+for name in ("MODE_AUTO", "MODE_TWOPASS", "MODE_FUSED", "FMT_GT2", "FMT_DS32", "FMT_GT2M", "FMT_GT2X", "ROW_DESC_DTYPE",
              "row_descs", "make_params"):
     setattr(fake, name, getattr(real, name))
 fake.load = lambda: None

@@ -193,6 +193,83 @@ def test_gt2x_equals_table_kernel_large():
     assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-10 * scale
 
 
+def test_gt2x_full_size_config3_properties():
+    """BASELINE.json configs[2] at its full size in the strip layout (500 000 samples x 1 000 000 rows, 125 GB
+    resident): decisions of every row, whole-row tallies of 20 000 random rows recounted by the oracle over all
+    samples, samples from EVERY strip (first / middle / last unit, both parities, the last ragged unit) scored
+    over ALL rows by oracle/refcpu.c, exact scaling, row halves adding up."""
+    import torch
+    n, m, seed = 500_000, 1_000_000, 20250103
+    free, total = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        assert total < 256 * (1 << 30), "an MI355X with less than 150 GB of free HBM: is another job on the GPU?"
+        pytest.skip("needs 150 GB of free HBM")
+    rng = np.random.default_rng(seed)
+    beta = np.round(rng.normal(0.0, 0.02, m), 4)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.02, m)
+    miss[::1000] = 0.10
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    for r0 in range(0, m, 1 << 15):
+        r1 = min(m, r0 + (1 << 15))
+        dev.synth(r0, seed, th[r0:r1], tm[r0:r1], tmi[r0:r1])
+    descs = capi.row_descs(beta, eaf)
+
+    def run(rows, row0=0, want_stats=False):
+        sc = capi.Scorer(n, capi.make_params())
+        sc.score_cohort(dev, rows, row0, capi.MODE_FUSED)
+        stats = sc.flush() if want_stats else None
+        part = torch.empty(n, dtype=torch.float64, device="cuda")
+        nloci = sc.partial_device(part.data_ptr())
+        sc.close()
+        return part, nloci, stats
+
+    whole, nloci, stats = run(descs, want_stats=True)
+    assert nloci == m
+    over = stats["reason"] == capi.REASON_MAXMIS
+    assert int(over.sum()) == m // 1000 and bool(over[::1000].all())
+    assert int(stats["used"].sum()) == m
+    rows = np.unique(np.concatenate([np.random.default_rng(1).choice(m, 20000, replace=False),
+                                     [0, 1000, 499_999, m - 1]])).astype(np.uint64)
+    ri = rows.astype(np.int64)
+    g, ms, ne = refcpu.tally_synth_rows(rows, n, seed, th[ri], tm[ri], tmi[ri])
+    assert np.array_equal(g, stats["ngenotyped"][ri].astype(np.float64))
+    assert np.array_equal(ms, stats["nmissing"][ri].astype(np.float64))
+    assert np.array_equal(ne, stats["neffect"][ri])
+    assert np.array_equal(stats["ngenotyped"] + stats["nmissing"], np.full(m, n, dtype=np.uint64))
+    sc0 = capi.Scorer(n, capi.make_params())
+    strips, teams, sps = sc0.fused_geometry(m, capi.FMT_GT2X)
+    sc0.close()
+    assert strips == 245 and teams == 1 and sps == 2048
+    units = (n + 31) // 32
+    us = {units - 1}
+    for p_ in range(strips):
+        first, last = p_ * 64, min(units, (p_ + 1) * 64) - 1
+        us.update(u for u in (first, first + 8, first + 53, first + 54, first + 59, last) if first <= u <= last)
+    samples = np.concatenate([np.arange(u * 32, min(n, (u + 1) * 32)) for u in sorted(us)]).astype(np.uint64)
+    assert samples[-1] == n - 1
+    sums, ref_nloci = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, 0,
+                                          stats["ngenotyped"].astype(np.float64),
+                                          stats["nmissing"].astype(np.float64), stats["neffect"],
+                                          refcpu.make_params())
+    assert ref_nloci == nloci == m
+    expect = sums / (2.0 * ref_nloci)
+    got = (whole / (2.0 * nloci)).cpu().numpy()[samples.astype(np.int64)]
+    check_scores(got, expect, beta, m)
+    # exact scaling: doubling beta doubles every fixed-point weight (same digits one bit up)
+    doubled, _, _ = run(capi.row_descs(2.0 * beta, eaf))
+    assert bool(torch.equal(doubled, 2.0 * whole))
+    del doubled
+    # row halves (the second starts on a superblock boundary)
+    h = 500_096
+    lo, nlo, _ = run(descs[:h])
+    hi, nhi, _ = run(descs[h:], row0=h)
+    assert nlo + nhi == m
+    assert float((lo + hi - whole).abs().max()) <= 1e-12 * float(np.sum(np.abs(beta)))
+    dev.close()
+
+
 def test_gt2x_refusals():
     dev = capi.Cohort(100, 300, fmt=capi.FMT_GT2X)
     sc = capi.Scorer(100, capi.make_params())

@@ -5,7 +5,8 @@ previous pass -- is a different number, not the same bits again); every pass mus
 scores and nloci for its definition (no float atomics, fixed combine order), no bounded wait may expire,
 and the fused result is compared with the two-pass kernels at the start.  Build with -DNPS_DIAGNOSTICS
 (tools/mkexp.sh) to have the DS kernel's partial sums poisoned with NaNs before every launch as well.
-    python tools/soak.py [--format ds|multi] [--samples N] [--variants M] [--passes K]
+    python tools/soak.py [--format ds|multi|strip] [--samples N] [--variants M] [--passes K]
+--format strip: the matrix-core single-score kernel on a NPS_FMT_GT2X cohort (two-stage tally hand-over).
 --format multi: the multi-score product kernel (LDS-DMA staging with hand-counted waits): two sets of 8
 definitions alternate, every pass bit-identical per set, set 0 checked against the single-score fused kernel."""
 import argparse
@@ -74,11 +75,18 @@ if a.format == "multi":
           "set and equal to the single-score kernel, %.1f s" % (a.passes, n, m, time.time() - t0))
     sys.exit(0)
 is_ds = a.format == "ds"
-co = capi.Cohort(n, m, fmt=capi.FMT_DS32 if is_ds else capi.FMT_GT2)
+is_strip = a.format == "strip"   # NPS_FMT_GT2X: the matrix-core kernel, checked against the table kernels on a NPS_FMT_GT2 copy
+co = capi.Cohort(n, m, fmt=capi.FMT_DS32 if is_ds else (capi.FMT_GT2X if is_strip else capi.FMT_GT2))
 for r0 in range(0, m, 1 << 15):
     r1 = min(m, r0 + (1 << 15))
     co.synth(r0, 7, th[r0:r1], tm[r0:r1], tmi[r0:r1])
 co.optimize()
+ref_co = co
+if is_strip:
+    ref_co = capi.Cohort(n, m)
+    for r0 in range(0, m, 1 << 15):
+        r1 = min(m, r0 + (1 << 15))
+        ref_co.synth(r0, 7, th[r0:r1], tm[r0:r1], tmi[r0:r1])
 params = capi.make_params(imp_locus="ps") if is_ds else capi.make_params()
 defs, refs = [], []
 for j in range(2):
@@ -90,9 +98,11 @@ d = torch.empty(n, dtype=torch.float64, device="cuda")
 t0 = time.time()
 for j in range(2):   # reference per definition: the two-pass kernels
     sc.reset()
-    sc.score_cohort_def(co, defs[j], 0, capi.MODE_TWOPASS)
+    sc.score_cohort_def(ref_co, defs[j], 0, capi.MODE_TWOPASS)
     nl = sc.finish_device(0.0, d.data_ptr())
     refs.append([d.clone(), nl, None])
+if is_strip:
+    ref_co.close()
 for k in range(a.passes):
     j = k & 1
     sc.reset()
