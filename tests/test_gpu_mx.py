@@ -8,7 +8,7 @@ import pytest
 
 from nimpress_amd import capi
 from oracle import refcpu
-from tests.test_gpu_parity import PARAM_GRID, assert_stats_equal, make_cohort, oracle_scores, rel_err
+from test_gpu_parity import PARAM_GRID, assert_stats_equal, make_cohort, oracle_scores, rel_err
 
 pytestmark = pytest.mark.gpu
 
