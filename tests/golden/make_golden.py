@@ -103,7 +103,7 @@ def extract_stats():
 
 
 def copy_data():
-    files = ["set1.vcf.gz", "set1.vcf.gz.tbi", "set1.score", "set1.bed", "set1.plink190.result",
+    files = ["set1.vcf.gz", "set1.vcf.gz.tbi", "set1.plink.vcf.gz", "set1.plink.vcf.gz.tbi", "set1.score", "set1.bed", "set1.plink190.result",
              "set1.plink200.result", "set1.plink.freq", "set1.plink.score"]
     for f in files:
         shutil.copyfile(os.path.join(REF, "tests", f), os.path.join(HERE, f))

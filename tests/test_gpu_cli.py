@@ -16,8 +16,8 @@ G = os.path.join(ROOT, "tests", "golden")
 CLI = os.path.join(ROOT, "nimpress_amd", "nimpress")
 
 
-def run_cli(*flags, env=None):
-    r = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), os.path.join(G, "set1.vcf.gz")],
+def run_cli(*flags, env=None, vcf="set1.vcf.gz"):
+    r = subprocess.run([CLI, *flags, os.path.join(G, "set1.score"), os.path.join(G, vcf)],
                        capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     warns = [l for l in r.stdout.splitlines() if l.startswith("WARN ")]
@@ -51,6 +51,37 @@ def test_cli_set1_golden(idx):
                                                 case["ignore_filter"])
     for t, r in zip(texts, ref):
         assert t == refcpu.format_score(r) or abs(float(t) - r) <= 1e-12
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_cli_set1_golden_on_split_records(idx):
+    """the reference's own split of set1 (tests/set1.plink.vcf.gz + .tbi, written by bcftools / tabix; the file
+    set1.plink190.result was computed from): the 13 golden vectors through the command line, with tabix random
+    access and by whole-file scan.  The score row 1:300 GA/CT must take the second record at that position."""
+    case = json.load(open(os.path.join(G, "set1_cases.json")))["cases"][idx]
+    flags = ["--imp-locus=" + case["imp_locus"], "--imp-missing=" + case["imp_missing"],
+             "--imp-sample=" + case["imp_sample"], "--maxmis=%r" % case["maxmis"],
+             "--mincs=%d" % case["mincs"], "--afmisp=%r" % case["afmisp"]]
+    if case["restrict_to_covered"]:
+        flags.append("--cov=" + os.path.join(G, "set1.bed"))
+    if case["ignore_filter"]:
+        flags.append("--ignorefilt")
+    base = run_cli(*flags)
+    for env in ({}, {"NIMPRESS_NO_INDEX": "1"}):
+        names, vals, texts, warns = run_cli(*flags, env=env, vcf="set1.plink.vcf.gz")
+        assert names == ["S1", "S2", "S3", "S4", "S5", "S6"]
+        for got, exp in zip(vals, case["expected"]):
+            assert (exp is None) == bool(np.isnan(got))
+            if exp is not None:
+                assert abs(got - exp) <= 1e-4
+        assert texts == base[2]      # the same numbers, to the last printed digit, as on the unsplit file
+
+
+def test_cli_plink190_on_the_file_plink_read():
+    plink = [float(l.split()[5]) for l in open(os.path.join(G, "set1.plink190.result")).read().splitlines()[1:]]
+    _, vals, _, _ = run_cli("--imp-locus=ignore", "--imp-missing=ignore", "--imp-sample=int_ps", "--maxmis=1.0",
+                            "--mincs=0", "--afmisp=1.0", "--ignorefilt", vcf="set1.plink.vcf.gz")
+    assert np.allclose(vals, [0.123 + p for p in plink], atol=1e-4)
 
 
 def test_cli_streaming_windows_and_whole_file_agree():

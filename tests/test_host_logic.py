@@ -133,6 +133,35 @@ def test_vcf_reader_and_find_variant_match_oracle(host):
         host.nh_vcf_close(h)
 
 
+def test_vcf_reader_on_reference_split_records(host):
+    """tests/set1.plink.vcf.gz (+ .tbi), the other htslib-written file the reference holds: two records at 1:300
+    with the same REF.  Whole-file scan and tabix random access both give the oracle's record for every score row;
+    1:300 GA/CT must skip GA>T (nimpress.nim:359-364)."""
+    path = os.path.join(G, "set1.plink.vcf.gz")
+    score = refcpu.read_score_file(os.path.join(G, "set1.score"))
+    ref_vcf = refcpu.read_vcf(path)
+    for keep in (None, os.path.join(G, "set1.score").encode()):
+        h = host.nh_vcf_open(path.encode(), keep)
+        assert h, host.nh_last_error()
+        assert host.nh_vcf_indexed(h) == (0 if keep is None else 1)
+        assert host.nh_vcf_n_records(h) == (8 if keep is None else 7)
+        for e in score.entries:
+            rec = refcpu.find_variant(ref_vcf, e)
+            pos, ploidy = C.c_long(), C.c_int()
+            filt = C.create_string_buffer(64)
+            gts = np.zeros(64, np.int32)
+            idx = host.nh_vcf_find(h, e.contig.encode(), e.pos, e.refseq.encode(), e.easeq.encode(),
+                                   C.byref(pos), C.byref(ploidy), filt, 64, gts.ctypes.data, 64)
+            if rec is None:
+                assert idx == -1
+            else:
+                assert idx >= 0 and pos.value == rec.pos and filt.value.decode() == rec.filt
+                assert gts[: rec.gts.size].tolist() == rec.gts.tolist()
+                if e.pos == 300:
+                    assert rec.alts == ["CT"]
+        host.nh_vcf_close(h)
+
+
 def test_vcf_reader_plain_text_phased_haploid(host, tmp_path):
     p = tmp_path / "t.vcf"
     p.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\n"

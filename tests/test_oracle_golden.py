@@ -69,6 +69,50 @@ def test_set1_plink190(golden_dir, set1):
     check_floats(scores, [0.123 + p for p in plink])
 
 
+@pytest.fixture(scope="module")
+def set1_split(golden_dir):
+    """tests/set1.plink.vcf.gz: the reference's own `bcftools norm -m-` split of set1 (two records at 1:300 with the
+    same REF, ##contig lines, LF endings) -- the file set1.plink190.result was computed from
+    (tests/set1.plink190.result.txt:1-5)"""
+    score = refcpu.read_score_file(os.path.join(golden_dir, "set1.score"))
+    vcf = refcpu.read_vcf(os.path.join(golden_dir, "set1.plink.vcf.gz"))
+    bed = refcpu.read_bed(os.path.join(golden_dir, "set1.bed"))
+    return score, vcf, bed
+
+
+def test_split_fixture_shape_and_find_variant(set1_split):
+    score, vcf, _ = set1_split
+    assert vcf.samples == ["S1", "S2", "S3", "S4", "S5", "S6"] and len(vcf.records) == 8
+    at300 = [r for r in vcf.records if r.pos == 300]
+    assert [(r.ref, r.alts) for r in at300] == [("GA", ["T"]), ("GA", ["CT"])]
+    # findVariant (nimpress.nim:359-364) skips the first REF-matching record, whose ALT lacks the effect allele
+    e = [x for x in score.entries if x.pos == 300][0]
+    assert (e.refseq, e.easeq) == ("GA", "CT")
+    rec = refcpu.find_variant(vcf, e)
+    assert rec is at300[1] and rec.gts.tolist() == [2, 2, 4, 4, 2, 2, 2, 2, 0, 0, 2, 2]
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_set1_case_on_split_records(golden_dir, set1_split, idx):
+    """the 13 golden vectors hold on the split file too: the score row 1:300 GA/CT takes the GA>CT record"""
+    score, vcf, bed = set1_split
+    case = _load(golden_dir, "set1_cases.json")["cases"][idx]
+    scores, nloci, stats = refcpu.compute_polygenic_scores(
+        score, vcf, case["restrict_to_covered"], bed, case["imp_locus"], case["imp_missing"],
+        case["imp_sample"], case["maxmis"], case["mincs"], case["ignore_filter"])
+    check_floats(scores, case["expected"])
+
+
+def test_set1_plink190_on_the_file_plink_read(golden_dir, set1_split):
+    score, vcf, bed = set1_split
+    plink = [float(l.split()[5]) for l in
+             open(os.path.join(golden_dir, "set1.plink190.result")).read().splitlines()[1:]]
+    scores, nloci, _ = refcpu.compute_polygenic_scores(score, vcf, False, bed, "ignore", "ignore",
+                                                       "int_ps", 1.0, 0, True)
+    assert nloci == 5
+    check_floats(scores, [0.123 + p for p in plink])
+
+
 def test_set1_plink200_five_of_six(golden_dir, set1):
     # tests/test_set1.nim:207-216 (commented out in the reference).  S3 differs by 0.018 because
     # set1.plink.freq lists 0.95 for the ALT allele of 1:100 while set1.score gives it to REF.
