@@ -224,6 +224,41 @@ static bool inflateAll(const std::string &in, std::string &out) {
 
 static const int32_t kVectorEnd = (int32_t)0x80000001u;
 
+// FORMAT/DS instead of FORMAT/GT for records that carry both: NIMPRESS_FORMAT=DS (a record without GT is scored
+// from its DS in any case)
+static bool preferDS() {
+    const char *e = getenv("NIMPRESS_FORMAT");
+    return e && (strcmp(e, "DS") == 0 || strcmp(e, "ds") == 0);
+}
+static float missingFloat() {  // the BCF2 missing float (0x7F800001): a NaN, which is what nps_push_ds calls missing
+    const uint32_t u = 0x7F800001u;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static bool isVectorEndFloat(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u == 0x7F800002u;
+}
+
+const float *Variant::dsRow(int eaidx, size_t n, std::vector<float> &tmp) const {
+    if (ds_per_sample == 1 && eaidx <= 1) return ds.data();
+    tmp.assign(n, missingFloat());
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = &ds[i * (size_t)ds_per_sample];
+        if (eaidx >= 1) {
+            if (eaidx <= ds_per_sample && !isVectorEndFloat(p[eaidx - 1])) tmp[i] = p[eaidx - 1];
+        } else {  // effect allele = REF: 2 - (sum of the ALT dosages); a missing value makes the sample missing
+            float sum = 0.0f;
+            for (int k = 0; k < ds_per_sample; ++k)
+                if (!isVectorEndFloat(p[k])) sum += p[k];
+            tmp[i] = sum;
+        }
+    }
+    return tmp.data();
+}
+
 // one sample's GT subfield -> alleles in the bcf_get_genotypes encoding
 static int encodeGT(const char *p, const char *end, int32_t *out, int cap) {
     int n = 0;
@@ -297,11 +332,57 @@ static bool parseRecordLine(const char *L, size_t len, size_t ns, const RegionMa
     if (ns) {
         if (nc < 10) throw std::runtime_error("VCF record without sample columns");
         const std::vector<std::string> fmt = splitChar(field(8), ':');
-        int gi = -1;
-        for (size_t k = 0; k < fmt.size(); ++k)
+        int gi = -1, di = -1;
+        for (size_t k = 0; k < fmt.size(); ++k) {
             if (fmt[k] == "GT") gi = (int)k;
-        if (gi < 0)
-            throw std::runtime_error("VCF record without FORMAT/GT at " + v.contig + ":" + field(1));
+            if (fmt[k] == "DS") di = (int)k;
+        }
+        if (gi < 0 && di < 0)
+            throw std::runtime_error("VCF record without FORMAT/GT (or FORMAT/DS) at " + v.contig + ":" + field(1));
+        if (di >= 0 && (gi < 0 || preferDS())) {  // FORMAT/DS: one float per ALT allele and sample, "." = missing
+            v.has_gt = false;
+            v.has_ds = true;
+            v.ds_per_sample = 1;
+            std::vector<std::vector<float>> rows(ns);
+            const char *s = col[9];
+            for (size_t i = 0; i < ns; ++i) {
+                const char *t = s;
+                while (t < end && *t != '\t') ++t;
+                const char *g0 = s;
+                for (int k = 0; k < di && g0 < t; ++k) {
+                    while (g0 < t && *g0 != ':') ++g0;
+                    if (g0 < t) ++g0;
+                }
+                const char *g1 = g0;
+                while (g1 < t && *g1 != ':') ++g1;
+                const char *a = g0;  // comma separated values of [g0, g1)
+                while (true) {
+                    const char *b = a;
+                    while (b < g1 && *b != ',') ++b;
+                    if (b == a || (b - a == 1 && *a == '.')) {
+                        rows[i].push_back(missingFloat());
+                    } else {
+                        char *ep = nullptr;
+                        const std::string tok(a, b - a);
+                        const float f = strtof(tok.c_str(), &ep);
+                        if (!ep || *ep) throw std::runtime_error("bad FORMAT/DS value '" + tok + "'");
+                        rows[i].push_back(f);
+                    }
+                    if (b >= g1) break;
+                    a = b + 1;
+                }
+                v.ds_per_sample = std::max(v.ds_per_sample, (int)rows[i].size());
+                if (t >= end && i + 1 < ns) throw std::runtime_error("VCF record with too few sample columns");
+                s = t + 1;
+            }
+            uint32_t eov_bits = 0x7F800002u;
+            float eov;
+            memcpy(&eov, &eov_bits, 4);
+            v.ds.assign(ns * (size_t)v.ds_per_sample, eov);
+            for (size_t i = 0; i < ns; ++i)
+                for (size_t k = 0; k < rows[i].size(); ++k) v.ds[i * (size_t)v.ds_per_sample + k] = rows[i][k];
+            return true;
+        }
         const int cap = 8;
         tmp.assign(ns * cap, kVectorEnd);
         int ploidy = 0;
@@ -806,11 +887,28 @@ static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const u
             v.gt_bytes = type == 1 ? 1 : (type == 2 ? 2 : 4);
             v.gt_raw.assign(f.p, f.p + bytes);
             v.has_gt = true;
+        } else if (key >= 0 && (size_t)key < h.ids.size() && h.ids[(size_t)key] == "DS") {
+            // typed float vector: len values per sample, missing 0x7F800001, end of vector 0x7F800002
+            if (type != 5) throw std::runtime_error("BCF: FORMAT/DS is not a float vector");
+            if (len < 1) throw std::runtime_error("BCF: empty FORMAT/DS vector");
+            v.ds_per_sample = (int)len;
+            v.ds.resize((size_t)len * n_sample);
+            memcpy(v.ds.data(), f.p, bytes);
+            v.has_ds = true;
         }
         f.p += bytes;
     }
-    if (n_sample && !v.has_gt)
-        throw std::runtime_error("BCF record without FORMAT/GT at " + v.contig + ":" + std::to_string(v.pos));
+    if (n_sample && !v.has_gt && !v.has_ds)
+        throw std::runtime_error("BCF record without FORMAT/GT (or FORMAT/DS) at " + v.contig + ":" + std::to_string(v.pos));
+    if (v.has_ds && (!v.has_gt || preferDS())) {  // the selection rule of nimpress_host.hpp: one of the two is kept
+        v.has_gt = false;
+        v.gt_raw.clear();
+        v.gt_raw.shrink_to_fit();
+    } else {
+        v.has_ds = false;
+        v.ds.clear();
+        v.ds.shrink_to_fit();
+    }
     return true;
 }
 
@@ -1524,6 +1622,7 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                 if (atoi(w) > 0) window = (size_t)atoi(w);
         }
         std::vector<Variant> fetched;
+        std::vector<float> ds_tmp;
         RecordIndex index;
         if (!genotypeVcf.streaming) index.build(genotypeVcf.records);
         for (size_t w0 = 0; w0 < entries.size(); w0 += window) {
@@ -1558,7 +1657,10 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                                     break;
                                 }
                         }
-                        if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
+                        if (v->has_ds)  // FORMAT/DS row (build-defined; the seam of nim:381-391 for float dosages)
+                            npsCheck(nps_push_ds(ctx, v->dsRow(eaidx, (size_t)nsamples, ds_tmp), rie, e.beta, e.eaf),
+                                     "nps_push_ds");
+                        else if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
                             npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0, rie,
                                                   e.beta, e.eaf),
                                      "nps_push_bed");
@@ -1788,6 +1890,26 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
                         : v->gt_raw.empty() ? v->gts.size() : v->gt_raw.size() / (size_t)v->gt_bytes;
     for (size_t i = 0; i < nval && (long)i < gts_cap; ++i) gts[i] = v->gtValue(i);
     return (long)(v - vcf.records.data());
+}
+
+// the FORMAT/DS row the score loop would push for this score row (see Variant::dsRow): returns the number of
+// values written (= samples), 0 when the record found is scored from GT, -1 when no record matches
+long nh_vcf_find_ds(void *h, const char *contig, long pos, const char *ref, const char *ea, float *out, long cap) {
+    const VCF &vcf = ((nh_vcf *)h)->vcf;
+    const Variant *v = findVariant(contig, pos, ref, ea, vcf);
+    if (!v) return -1;
+    if (!v->has_ds) return 0;
+    int eaidx = 0;
+    if (std::string(ref) != ea) {
+        eaidx = -1;
+        for (size_t k = 0; k < v->alt.size(); ++k)
+            if (v->alt[k] == ea) eaidx = (int)k + 1;
+    }
+    std::vector<float> tmp;
+    const float *row = v->dsRow(eaidx, vcf.samples.size(), tmp);
+    const long n = std::min<long>((long)vcf.samples.size(), cap);
+    memcpy(out, row, sizeof(float) * (size_t)n);
+    return n;
 }
 
 // whole run (needs a GPU): the reference's main() minus printing.  Returns the number of samples,

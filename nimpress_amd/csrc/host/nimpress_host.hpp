@@ -70,6 +70,15 @@ struct Variant {
     std::vector<int32_t> gts;
     std::vector<uint8_t> gt_raw;
     bool has_gt = true;
+    // FORMAT/DS (build-defined extension: the reference decodes GT only, nim:381-391): float32 ALT dosages,
+    // ds_per_sample values per sample (1, or one per ALT allele for Number=A), NaN = missing.  A record's DS is used
+    // INSTEAD of its GT when it has no GT, or when NIMPRESS_FORMAT=DS is set and it has DS (then GT is not kept).
+    bool has_ds = false;
+    int ds_per_sample = 0;
+    std::vector<float> ds;
+    // the dosage row the loop scores for effect allele index eaidx (0 = REF: the sum of the ALT dosages, which
+    // nps_push_ds turns into 2 - sum; k = ALT[k-1]): `tmp` is used unless the record's own vector can be handed over
+    const float *dsRow(int eaidx, size_t n_samples, std::vector<float> &tmp) const;
     // PLINK 1 .bed source (build-defined extension): gt_raw holds the variant's ceil(N/4) .bed bytes,
     // ref = A2 and alt = {A1} of the .bim line.  A .bim has no notion of REF, so findVariant also
     // accepts a score row whose ref is A1.

@@ -435,8 +435,9 @@ class VcfRecord:
     ref: str
     alts: List[str]
     filt: str
-    gts: np.ndarray  # int32 [n_samples * ploidy], bcf_get_genotypes layout
+    gts: np.ndarray  # int32 [n_samples * ploidy], bcf_get_genotypes layout (None: the record is scored from FORMAT/DS)
     ploidy: int
+    ds: Optional[np.ndarray] = None  # float32 [n_samples, values per sample] ALT dosages, NaN = missing (build-defined)
 
 
 @dataclass
@@ -469,8 +470,23 @@ def _encode_gt(field_: str) -> List[int]:
     return out
 
 
-def read_vcf(path: str) -> Vcf:
-    """Text VCF (plain or gzip/BGZF).  CRLF tolerant (tests/set1.vcf.gz has CRLF endings)."""
+def ds_row(rec: "VcfRecord", eaidx: int) -> np.ndarray:
+    """The float32 dosage row scored for effect allele index eaidx (build-defined FORMAT/DS extension): ALT[k-1]'s
+    column, or for the REF allele the float32 sum of the ALT dosages (ref_row_ds then takes 2 - sum)."""
+    d = rec.ds
+    if eaidx >= 1:
+        return d[:, eaidx - 1].copy() if eaidx <= d.shape[1] else np.full(d.shape[0], np.nan, np.float32)
+    out = np.zeros(d.shape[0], dtype=np.float32)
+    for k in range(d.shape[1]):          # float32, column after column, as the host does
+        col = d[:, k]
+        pad = np.isnan(col) & (col.view(np.uint32) == 0x7F800002)   # end-of-vector padding is skipped
+        out = (out + np.where(pad, np.float32(0), col)).astype(np.float32)
+    return out
+
+
+def read_vcf(path: str, prefer_ds: bool = False) -> Vcf:
+    """Text VCF (plain or gzip/BGZF).  CRLF tolerant (tests/set1.vcf.gz has CRLF endings).  A record is read from
+    FORMAT/DS instead of FORMAT/GT when it has no GT, or when prefer_ds is set and it has DS (build-defined)."""
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rt", newline="") as fh:
         text = fh.read()
@@ -486,6 +502,18 @@ def read_vcf(path: str) -> Vcf:
             continue
         f = ln.split("\t")
         fmt = f[8].split(":")
+        if "DS" in fmt and ("GT" not in fmt or prefer_ds):
+            di = fmt.index("DS")
+            vals = [[np.float32(np.nan) if (x in (".", "")) else np.float32(x) for x in
+                     (s.split(":")[di] if len(s.split(":")) > di else ".").split(",")] for s in f[9:]]
+            per_s = max(len(v) for v in vals) if vals else 1
+            eov = np.array([0x7F800002], dtype=np.uint32).view(np.float32)[0]
+            ds = np.full((len(vals), per_s), eov, dtype=np.float32)
+            for i, v in enumerate(vals):
+                ds[i, :len(v)] = v
+            vcf.records.append(VcfRecord(f[0], int(f[1]), f[3], f[4].split(",") if f[4] != "." else [],
+                                         f[6], None, 0, ds))
+            continue
         gi = fmt.index("GT")
         per = [_encode_gt(s.split(":")[gi]) for s in f[9:]]
         ploidy = max(len(x) for x in per) if per else 2
@@ -532,7 +560,10 @@ def compute_polygenic_scores(score: ScoreFile, vcf: Vcf, restrict_to_covered: bo
             sc.row_locus(ROW_FILTERED, rie, e.beta, e.eaf)
             continue
         eaidx = 0 if rie else rec.alts.index(e.easeq) + 1                    # :375-379
-        sc.row_gt(rec.gts, rec.ploidy, eaidx, rie, e.beta, e.eaf)
+        if rec.ds is not None:                                               # build-defined FORMAT/DS row
+            sc.row_ds(ds_row(rec, eaidx), rie, e.beta, e.eaf)
+        else:
+            sc.row_gt(rec.gts, rec.ploidy, eaidx, rie, e.beta, e.eaf)
     scores, nloci = sc.finish(score.offset)
     return scores, nloci, sc.stats
 

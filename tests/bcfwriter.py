@@ -1,7 +1,8 @@
 """Test helper: a minimal BCF2.2 (+ CSI index) writer following the VCF/BCF specification
 (hts-specs VCFv4.3 section 6) -- there is no htslib / bcftools in this image, so the fixtures for the
 C++ BCF reader are produced here.  Only what the reader consumes is written: CHROM, POS, ID, alleles,
-FILTER and FORMAT/GT (as int8, int16 or int32 vectors, with end-of-vector padding for mixed ploidy).
+FILTER, FORMAT/GT (as int8, int16 or int32 vectors, with end-of-vector padding for mixed ploidy) and FORMAT/DS
+(float32 vectors, missing = 0x7F800001, end of vector = 0x7F800002).
 """
 import struct
 import zlib
@@ -75,6 +76,9 @@ def write_bcf(path, contigs, samples, records, gt_dtype=np.int8, filters=("PASS"
         hdr.append("##contig=<ID=%s>" % c)
     hdr.append('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">')
     ids.append("GT")
+    if any(r.get("ds") is not None for r in records):
+        hdr.append('##FORMAT=<ID=DS,Number=A,Type=Float,Description="ALT allele dosage">')
+        ids.append("DS")
     hdr.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples))
     text = ("\n".join(hdr) + "\n").encode() + b"\0"
     gt_key = ids.index("GT")
@@ -113,9 +117,12 @@ def write_bcf(path, contigs, samples, records, gt_dtype=np.int8, filters=("PASS"
         rlen = len(r["ref"])
         alleles = [r["ref"]] + list(r["alts"])
         shared = struct.pack("<iiiI", chrom, pos0, rlen, 0x7F800001)
-        g = np.asarray(r["gts"], dtype=np.int64)
+        has_gt = r.get("gts") is not None
+        g = np.asarray(r["gts"], dtype=np.int64) if has_gt else np.zeros((0, 0), np.int64)
         ns, ploidy = (g.shape if g.ndim == 2 else (len(samples), 0))
-        shared += struct.pack("<II", (len(alleles) << 16) | 0, ((1 if ns else 0) << 24) | len(samples))
+        ds = r.get("ds")
+        n_fmt = (1 if ns else 0) + (1 if ds is not None else 0)
+        shared += struct.pack("<II", (len(alleles) << 16) | 0, (n_fmt << 24) | len(samples))
         shared += typed_str(r.get("id", ".") if r.get("id", ".") != "." else "")
         for a in alleles:
             shared += typed_str(a)
@@ -128,6 +135,11 @@ def write_bcf(path, contigs, samples, records, gt_dtype=np.int8, filters=("PASS"
         if ns:
             g = np.where(g == INT32_END, vend, g).astype(gt_dtype)
             indiv = typed_int(gt_key) + typed_desc(ploidy, ttype) + g.tobytes()
+        if ds is not None:   # float vector: NaN -> the BCF missing value; 0x7F800002 payloads (end of vector) stay
+            d = np.ascontiguousarray(ds, dtype=np.float32).reshape(len(samples), -1)
+            bits = d.view(np.uint32).copy()
+            bits[np.isnan(d) & (bits != 0x7F800002)] = 0x7F800001
+            indiv += typed_int(ids.index("DS")) + typed_desc(d.shape[1], 5) + bits.tobytes()
         vs, ve = add(struct.pack("<II", len(shared), len(indiv)) + shared + indiv)
         index[chrom].setdefault(reg2bin(pos0, pos0 + rlen), []).append((vs, ve))
     flush()

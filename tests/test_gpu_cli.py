@@ -300,3 +300,88 @@ def test_af_mismatch_warnings_at_default_afmisp_100k_samples(tmp_path):
     assert n_nan == 1                                      # the MAXIT case really is in the fixture
     assert sum("cohort EAF is" in w for w in expected) == 7
     assert warns == expected
+
+
+# ------------------------------------------------------------------------------------------
+# FORMAT/DS through the host reader and the command line (build-defined extension; oracle = ref_row_ds)
+def _ds_cohort(n, m, seed):
+    """m score rows / records of float32 ALT dosages (HWE genotype + N(0, 0.05), clipped to [0, 2], 3 decimals),
+    per-row missing rate U(0, 0.1) (about half the rows over --maxmis 0.05), some rows with the REF allele as the
+    effect allele, with eaf = NaN, absent from the file or FILTER-failed"""
+    rng = np.random.default_rng(seed)
+    entries, recs = [], []
+    for j in range(m):
+        pos = 1000 + 37 * j
+        eaf = float(np.round(rng.uniform(0.02, 0.5), 4))
+        beta = float(np.round(rng.normal(0, 0.05), 4))
+        rie = j % 5 == 2
+        ref, alt = "A", "G"
+        entries.append(refcpu.ScoreEntry("7", pos, ref, ref if rie else alt, beta, float("nan") if j % 9 == 4 else eaf))
+        if j % 13 == 6:
+            continue                                   # absent
+        g = (rng.random(n) < eaf).astype(np.float32) + (rng.random(n) < eaf).astype(np.float32)
+        d = np.round(np.clip(g + rng.normal(0, 0.05, n), 0, 2), 3).astype(np.float32)
+        nan_eaf = j % 9 == 4    # (such a row must stay genotyped: locus imputation with ps would make every score NaN)
+        d[rng.random(n) < (0.01 if nan_eaf else rng.uniform(0, 0.1))] = np.nan
+        recs.append(refcpu.VcfRecord("7", pos, ref, [alt], "FAIL" if (j % 17 == 3 and not nan_eaf) else ("PASS" if j % 2 else "."),
+                                     None, 0, d.reshape(n, 1)))
+    return entries, recs
+
+
+def _write_ds_files(tmp_path, n, entries, recs, text):
+    import bcfwriter
+    samples = ["D%06d" % i for i in range(n)]
+    spath = str(tmp_path / "ds.score")
+    with open(spath, "w") as f:
+        f.write("ds test\n\n\nGRCh37\n0.25\n")
+        f.write("\n".join("%s\t%d\t%s\t%s\t%r\t%s" % (e.contig, e.pos, e.refseq, e.easeq, e.beta,
+                                                     "NaN" if np.isnan(e.eaf) else repr(e.eaf)) for e in entries))
+    if text:
+        import gzip
+        path = str(tmp_path / "ds.vcf.gz")
+        with gzip.open(path, "wt") as f:
+            f.write("##fileformat=VCFv4.2\n##contig=<ID=7>\n"
+                    '##FORMAT=<ID=DS,Number=A,Type=Float,Description="ALT allele dosage">\n')
+            f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n")
+            for r in recs:
+                vals = ["." if np.isnan(x) else ("%.3f" % x).rstrip("0").rstrip(".") for x in r.ds[:, 0]]
+                f.write("%s\t%d\t.\t%s\t%s\t.\t%s\t.\tDS\t%s\n" % (r.contig, r.pos, r.ref, ",".join(r.alts), r.filt,
+                                                                   "\t".join(vals)))
+    else:
+        path = str(tmp_path / "ds.bcf")
+        bcfwriter.LEVEL = 1
+        bcfwriter.write_bcf(path, ["7"], samples,
+                            [dict(contig=r.contig, pos=r.pos, id=".", ref=r.ref, alts=r.alts,
+                                  filters=[] if r.filt == "." else [r.filt], gts=None, ds=r.ds) for r in recs])
+        bcfwriter.LEVEL = 6
+    return spath, path, samples
+
+
+@pytest.mark.parametrize("kind,n", [("bcf", 100_000), ("text", 20_000)])
+def test_cli_format_ds_equals_oracle(tmp_path, kind, n):
+    """a 100 000-sample BCF2 whose records carry FORMAT/DS only (typed float vectors, missing = 0x7F800001), and a
+    text vcf.gz with the same kind of rows: the command line scores them through nps_push_ds; scores, nloci (through
+    the scores) and the warnings' rows equal the oracle's ref_row_ds on the same rows -- rows over --maxmis, NaN
+    eaf, REF-effect rows (2 - DS), absent and FILTER-failed records included"""
+    m = 60
+    entries, recs = _ds_cohort(n, m, 77 + n)
+    spath, path, samples = _write_ds_files(tmp_path, n, entries, recs, kind == "text")
+    score = refcpu.ScoreFile("ds test", "", "", "GRCh37", 0.25, entries)
+    vcf = refcpu.Vcf(samples=samples, records=recs)
+    for flags, args in ((["--imp-locus=ps", "--afmisp=0"], ("ps", "homref", "int_ps", 0.05, 100, False)),
+                        (["--imp-locus=homref", "--imp-sample=ps", "--maxmis=1.0", "--afmisp=0", "--ignorefilt"],
+                         ("homref", "homref", "ps", 1.0, 100, True))):
+        r = subprocess.run([CLI, *flags, spath, path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows = [l.split("\t") for l in r.stdout.splitlines() if not l.startswith(("WARN ", "FATAL "))]
+        assert [x[0] for x in rows] == samples
+        got = np.array([float(x[1]) for x in rows])
+        ref, nloci, stats = refcpu.compute_polygenic_scores(score, vcf, False, None, *args)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert ok.sum() > n // 2          # (samples missing at a NaN-eaf row are NaN under --imp-sample=ps)
+        scale = sum(abs(e.beta) for e in entries) / (2.0 * max(nloci, 1))
+        assert np.max(np.abs(got[ok] - ref[ok])) <= 1e-9 * scale, (kind, flags)
+        # the FILTER / maxmis warnings name the same rows as the oracle's decisions
+        over = sum(1 for s_ in stats if s_[4] == 4)
+        assert sum("missingness" in l or "missing" in l.lower() for l in r.stdout.splitlines() if l.startswith("WARN ")) >= (1 if over else 0)

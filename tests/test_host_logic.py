@@ -47,6 +47,8 @@ def host():
     L.nh_vcf_find.argtypes = [C.c_void_p, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p,
                               C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_char_p, C.c_long,
                               C.c_void_p, C.c_long]
+    L.nh_vcf_find_ds.restype = C.c_long
+    L.nh_vcf_find_ds.argtypes = [C.c_void_p, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p, C.c_void_p, C.c_long]
     for f in ("nh_dbinom", "nh_pbinom", "nh_binom_test", "nh_binom_test_fast"):
         getattr(L, f).restype = C.c_double
         getattr(L, f).argtypes = [C.c_long, C.c_long, C.c_double]
@@ -159,6 +161,68 @@ def test_vcf_reader_on_reference_split_records(host):
                 assert gts[: rec.gts.size].tolist() == rec.gts.tolist()
                 if e.pos == 300:
                     assert rec.alts == ["CT"]
+        host.nh_vcf_close(h)
+
+
+DS_VCF = """##fileformat=VCFv4.2
+##contig=<ID=1>
+##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
+##FORMAT=<ID=DS,Number=A,Type=Float,Description="ALT allele dosage">
+#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\tD
+1\t100\t.\tA\tC\t.\tPASS\t.\tGT:DS\t0/1:1.004\t1/1:1.75\t./.:.\t0/0:0
+1\t200\t.\tG\tT\t.\t.\t.\tDS\t0.25\t.\t2\t1.5
+1\t300\t.\tGA\tT,CT\t.\tPASS\t.\tDS:GT\t0.5,1:0/2\t0,0:0/0\t.,.:./.\t1.25:1/1
+1\t400\t.\tT\tC\t.\tFAIL\t.\tGT\t0/1\t1/1\t./.\t0/0
+"""
+DS_SCORE = "t\n\n\nhg19\n0.5\n" + "\n".join([
+    "1\t100\tA\tC\t0.1\t0.3", "1\t100\tA\tA\t0.2\t0.7", "1\t200\tG\tT\t-0.3\tNaN",
+    "1\t300\tGA\tCT\t0.4\t0.2", "1\t300\tGA\tGA\t0.05\t0.6", "1\t300\tGA\tT\t0.15\t0.2",
+    "1\t400\tT\tC\t0.25\t0.1"])
+
+
+@pytest.mark.parametrize("prefer", [False, True])
+@pytest.mark.parametrize("kind", ["text", "bcf"])
+def test_format_ds_rows_match_oracle(host, tmp_path, monkeypatch, prefer, kind):
+    """FORMAT/DS (build-defined: the reference reads GT only): the dosage row handed to nps_push_ds for every score
+    row -- records without GT, records with both under NIMPRESS_FORMAT=DS, multi-allelic Number=A vectors (effect
+    allele = second ALT, = REF: the sum of the ALT dosages), missing values, a vector shorter than the ALT count --
+    from the text reader and from the BCF2 typed float vectors equals the oracle's reading."""
+    import bcfwriter
+    vpath, spath = str(tmp_path / "ds.vcf"), str(tmp_path / "ds.score")
+    open(vpath, "w").write(DS_VCF)
+    open(spath, "w").write(DS_SCORE)
+    ref_vcf = refcpu.read_vcf(vpath, prefer_ds=prefer)
+    assert [r.ds is not None for r in ref_vcf.records] == ([True, True, True, False] if prefer else [False, True, False, False])
+    path = vpath
+    if kind == "bcf":
+        both = refcpu.read_vcf(vpath, prefer_ds=True), refcpu.read_vcf(vpath, prefer_ds=False)
+        recs = []
+        for rd, rg in zip(both[0].records, both[1].records):
+            recs.append(dict(contig=rd.contig, pos=rd.pos, id=".", ref=rd.ref, alts=rd.alts,
+                             filters=[] if rd.filt == "." else rd.filt.split(";"),
+                             gts=None if rg.gts is None else np.asarray(rg.gts).reshape(4, rg.ploidy),
+                             ds=rd.ds))
+        path = str(tmp_path / "ds.bcf")
+        bcfwriter.write_bcf(path, ["1"], ["A", "B", "C", "D"], recs, gt_dtype=np.int8)
+    if prefer:
+        monkeypatch.setenv("NIMPRESS_FORMAT", "DS")
+    else:
+        monkeypatch.delenv("NIMPRESS_FORMAT", raising=False)
+    score = refcpu.read_score_file(spath)
+    for keep in (None, spath.encode()) if kind == "bcf" else (None,):
+        h = host.nh_vcf_open(path.encode(), keep)
+        assert h, host.nh_last_error()
+        for e in score.entries:
+            rec = refcpu.find_variant(ref_vcf, e)
+            out = np.zeros(4, np.float32)
+            k = host.nh_vcf_find_ds(h, e.contig.encode(), e.pos, e.refseq.encode(), e.easeq.encode(), out.ctypes.data, 4)
+            if rec.ds is None:
+                assert k == 0
+                continue
+            eaidx = 0 if e.refseq == e.easeq else rec.alts.index(e.easeq) + 1
+            want = refcpu.ds_row(rec, eaidx)
+            assert k == 4 and np.array_equal(np.isnan(out), np.isnan(want)), (e, out, want)
+            assert np.array_equal(out[~np.isnan(want)], want[~np.isnan(want)]), (e, out, want)
         host.nh_vcf_close(h)
 
 
