@@ -245,6 +245,14 @@ int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t nrows, void
  * row_stride_bytes = ceil(n_samples/4)) and are recoded + interleaved on the device. */
 int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrows, const uint8_t *bed_rows,
                           size_t row_stride_bytes, const uint8_t *effect_is_a1);
+/* One row of a NPS_FMT_GT2 cohort straight from the buffer a record holds -- the typed FORMAT/GT vector of a VCF/BCF
+ * record (see nps_push_gt_raw; elem_bytes 4 = the bcf_get_genotypes buffer of nimpress.nim:381-384) or a PLINK .bed
+ * row (see nps_push_bed) -- decoded on the device by the kernels of the streaming entry points, with the cohort as
+ * the destination: getRawDosages (nimpress.nim:367-391) for a matrix that stays resident (a cohort holding the union
+ * of several score files' loci, scored with nps_score_cohort_multi after nps_cohort_convert).  ploidy 1 or 2.  The
+ * caller may reuse its buffer on return; calls that read the cohort wait for the pushed rows. */
+int nps_cohort_push_gt_raw(nps_cohort *c, uint64_t row, const void *gt, int elem_bytes, int ploidy, int eaidx);
+int nps_cohort_push_bed(nps_cohort *c, uint64_t row, const uint8_t *bed_row, int effect_is_a1);
 /* Fill rows on the device with the counter-based synthetic generator (DESIGN.md "Synthetic
  * cohorts"): per-row uint32 thresholds, code(seed,row,sample) reproducible on the CPU. */
 /* One-time layout change of a resident 2-bit cohort (no-op for the other formats): inside every group of

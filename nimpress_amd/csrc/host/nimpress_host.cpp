@@ -1733,6 +1733,215 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
     nps_destroy(ctx);
 }
 
+void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const std::vector<const ScoreFile *> &scoreFiles,
+                                 const VCF &genotypeVcf, bool restrictToCoveredRgns, const GenomeIntervals &coveredIvals,
+                                 ImputeMethodLocus imputeMethodLocus, ImputeMethodMissing imputeMethodMissing,
+                                 ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
+                                 int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs, int device,
+                                 std::vector<uint64_t> *nloci_out) {
+    const size_t S = scoreFiles.size();
+    const int64_t nsamples = genotypeVcf.n_samples();
+    scores.assign(S, std::vector<double>());
+    logs.assign(S, Log());
+    for (Log &l : logs) l.echo = false;
+    if (nloci_out) nloci_out->assign(S, 0);
+    if (S == 0) return;
+    nps_params p;
+    p.imp_locus = (int32_t)imputeMethodLocus;
+    p.imp_missing = (int32_t)imputeMethodMissing;
+    p.imp_sample = (int32_t)imputeMethodSample;
+    p.reserved = 0;
+    p.max_missing_rate = maxMissingRate;
+    p.min_cs = minGtForInternalImput;
+
+    // ---- the union of the files' score rows: one position (= cohort row) per distinct (contig, pos, ref, ea)
+    struct Position {
+        ScoreEntry e;   // beta / eaf of the first file that lists it (only the locus is used)
+        int how = 0;    // 0 = genotyped row, else nps_row_kind (the same for every file that lists the row)
+        std::string filter, pre_warning;
+    };
+    std::vector<Position> pos;
+    std::map<std::string, size_t> where;
+    std::vector<std::vector<size_t>> rows_of(S);  // per file, in file order: the position of each score row
+    for (size_t s = 0; s < S; ++s)
+        for (const ScoreEntry &e : scoreFiles[s]->entries) {
+            const std::string key = e.contig + "\t" + std::to_string(e.pos) + "\t" + e.refseq + "\t" + e.easeq;
+            auto it = where.find(key);
+            if (it == where.end()) {
+                it = where.emplace(key, pos.size()).first;
+                Position q;
+                q.e = e;
+                pos.push_back(q);
+            }
+            rows_of[s].push_back(it->second);
+        }
+    const size_t U = pos.size();
+
+    nps_cohort *gt2 = nullptr, *gt2m = nullptr;
+    nps_multi *msc = nullptr;
+    nps_multidef *mdef = nullptr;
+    auto cleanup = [&]() {
+        if (mdef) nps_multidef_destroy(mdef);
+        if (msc) nps_multi_destroy(msc);
+        if (gt2) nps_cohort_destroy(gt2);
+        if (gt2m) nps_cohort_destroy(gt2m);
+        mdef = nullptr; msc = nullptr; gt2 = nullptr; gt2m = nullptr;
+    };
+    try {
+        // ---- locate every position once and decode its record into the resident cohort (nim:526-561)
+        npsCheck(nps_cohort_create(&gt2, device, (uint64_t)nsamples, (uint64_t)U, NPS_FMT_GT2), "nps_cohort_create");
+        std::vector<ScoreEntry> uent(U);
+        for (size_t j = 0; j < U; ++j) uent[j] = pos[j].e;
+        size_t window = U;
+        if (genotypeVcf.streaming) {
+            const size_t per_row = (size_t)std::max<int64_t>(nsamples, 1) * 8;
+            window = std::min<size_t>(std::max<size_t>((512u << 20) / per_row, 64), 8192);
+            if (const char *w = getenv("NIMPRESS_WINDOW"))
+                if (atoi(w) > 0) window = (size_t)atoi(w);
+        }
+        std::vector<Variant> fetched;
+        RecordIndex index;
+        if (!genotypeVcf.streaming) index.build(genotypeVcf.records);
+        for (size_t w0 = 0; w0 < U; w0 += std::max<size_t>(window, 1)) {
+            const size_t w1 = std::min(U, w0 + std::max<size_t>(window, 1));
+            if (genotypeVcf.streaming) {
+                fetched = genotypeVcf.fetch(uent.data() + w0, w1 - w0);
+                index.build(fetched);
+            }
+            for (size_t j = w0; j < w1; ++j) {
+                Position &q = pos[j];
+                const ScoreEntry &e = q.e;
+                if (restrictToCoveredRgns && !isVariantCovered(e, coveredIvals, &q.pre_warning)) {
+                    q.how = NPS_ROW_UNCOVERED;
+                    continue;
+                }
+                const Variant *v = index.find(e.contig, e.pos, e.refseq, e.easeq);
+                if (!v) {
+                    q.how = NPS_ROW_ABSENT;
+                    continue;
+                }
+                if (!ignoreFilterField && v->filter != "." && v->filter != "PASS") {
+                    q.how = NPS_ROW_FILTERED;
+                    q.filter = v->filter;
+                    continue;
+                }
+                if (v->has_ds) throw std::runtime_error("FORMAT/DS records are not covered by the one-pass multi-score path");
+                int eaidx = 0;
+                if (e.refseq != e.easeq) {
+                    eaidx = -1;
+                    for (size_t k = 0; k < v->alt.size(); ++k)
+                        if (v->alt[k] == e.easeq) {
+                            eaidx = (int)k + 1;
+                            break;
+                        }
+                }
+                if (v->is_bed)
+                    npsCheck(nps_cohort_push_bed(gt2, j, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0), "nps_cohort_push_bed");
+                else
+                    npsCheck(nps_cohort_push_gt_raw(gt2, j, v->gtData(), v->gt_raw.empty() ? 4 : v->gt_bytes, v->ploidy, eaidx),
+                             "nps_cohort_push_gt_raw");
+            }
+        }
+        fetched.clear();
+        npsCheck(nps_cohort_create(&gt2m, device, (uint64_t)nsamples, (uint64_t)U, NPS_FMT_GT2M), "nps_cohort_create");
+        npsCheck(nps_cohort_convert(gt2m, gt2), "nps_cohort_convert");
+        nps_cohort_destroy(gt2);
+        gt2 = nullptr;
+        std::vector<uint64_t> nmiss(U, 0), neff(U, 0);
+        if (U) npsCheck(nps_cohort_row_tallies(gt2m, 0, U, nmiss.data(), neff.data()), "nps_cohort_row_tallies");
+
+        // ---- the definitions, NPS_MULTI_MAX_SCORES files at a time
+        for (size_t s0 = 0; s0 < S; s0 += NPS_MULTI_MAX_SCORES) {
+            const size_t ns = std::min<size_t>(NPS_MULTI_MAX_SCORES, S - s0);
+            std::vector<nps_row_desc> descs(ns * U);
+            for (size_t k = 0; k < ns * U; ++k) {
+                descs[k].beta = 0.0;
+                descs[k].eaf = 0.0;
+                descs[k].kind = NPS_ROW_NOT_IN_SCORE;
+                descs[k].ref_is_effect = 0;
+            }
+            for (size_t s = 0; s < ns; ++s) {
+                const ScoreFile &sf = *scoreFiles[s0 + s];
+                for (size_t r = 0; r < sf.entries.size(); ++r) {
+                    const size_t j = rows_of[s0 + s][r];
+                    nps_row_desc &d = descs[s * U + j];
+                    if (d.kind != NPS_ROW_NOT_IN_SCORE)
+                        throw std::runtime_error("a score file lists the same locus and alleles twice: not covered by "
+                                                 "the one-pass multi-score path");
+                    d.beta = sf.entries[r].beta;
+                    d.eaf = sf.entries[r].eaf;
+                    d.kind = pos[j].how ? pos[j].how : NPS_ROW_PRESENT;
+                    d.ref_is_effect = sf.entries[r].refseq == sf.entries[r].easeq ? 1 : 0;
+                }
+            }
+            npsCheck(nps_multidef_create(&mdef, device, descs.data(), (int)ns, (uint64_t)U), "nps_multidef_create");
+            npsCheck(nps_multi_create(&msc, device, (uint64_t)nsamples, &p, (int)ns), "nps_multi_create");
+            if (U) npsCheck(nps_score_cohort_multi(msc, gt2m, 0, mdef), "nps_score_cohort_multi");
+            std::vector<double> offs(ns), flat(ns * (size_t)std::max<int64_t>(nsamples, 1));
+            std::vector<uint64_t> nl(ns, 0);
+            for (size_t s = 0; s < ns; ++s) offs[s] = scoreFiles[s0 + s]->offset;
+            npsCheck(nps_multi_finish(msc, offs.data(), flat.data(), nl.data()), "nps_multi_finish");
+            for (size_t s = 0; s < ns; ++s) {
+                scores[s0 + s].assign(flat.begin() + (ptrdiff_t)(s * (size_t)nsamples),
+                                      flat.begin() + (ptrdiff_t)((s + 1) * (size_t)nsamples));
+                if (nloci_out) (*nloci_out)[s0 + s] = nl[s];
+            }
+            nps_multi_destroy(msc);
+            msc = nullptr;
+            nps_multidef_destroy(mdef);
+            mdef = nullptr;
+        }
+
+        // ---- the reference's warnings, per file in its own row order (nim:527-579), from the rows' tallies
+        for (size_t s = 0; s < S; ++s) {
+            Log &log = logs[s];
+            const ScoreFile &sf = *scoreFiles[s];
+            for (size_t r = 0; r < sf.entries.size(); ++r) {
+                const ScoreEntry &e = sf.entries[r];
+                const Position &q = pos[rows_of[s][r]];
+                const size_t j = rows_of[s][r];
+                const std::string locus = e.contig + ":" + std::to_string(e.pos);
+                const std::string var = locus + ":" + e.refseq + ":" + e.easeq;
+                if (!q.pre_warning.empty()) log.warn(q.pre_warning);
+                switch (q.how) {
+                case NPS_ROW_UNCOVERED:
+                    log.warn("Locus " + locus + "-" + std::to_string(e.stop()) +
+                             " is not covered by the sequence coverage BED.  Imputing all dosages at this locus.");
+                    break;
+                case NPS_ROW_ABSENT:
+                    if (!std::isnan(e.eaf) && binomTestFast(0, nsamples * 2, e.eaf) < afMismatchPthresh)
+                        log.warn("Variant " + var + " cohort EAF is 0 in " + std::to_string(nsamples) +
+                                 " samples.  This is highly unlikely given polygenic score EAF of " + formatFloat(e.eaf));
+                    break;
+                case NPS_ROW_FILTERED:
+                    log.warn("Variant " + var + " has a FILTER flag set (value \"" + q.filter +
+                             "\").  Imputing all dosages at this locus.");
+                    break;
+                default: {
+                    const double missingrate = (double)nmiss[j] / (double)nsamples;  // nim:565
+                    if (missingrate > maxMissingRate) {
+                        log.warn("Locus " + locus + "-" + std::to_string(e.stop()) + " has " + formatFloat(missingrate * 100) +
+                                 "% of samples missing a genotype. This exceeds the missingness threshold; "
+                                 "imputing all dosages at this locus.");
+                    } else {
+                        const int64_t nobs = (nsamples - (int64_t)nmiss[j]) * 2;
+                        if (!std::isnan(e.eaf) && binomTestFast((int64_t)neff[j], nobs, e.eaf) < afMismatchPthresh)
+                            log.warn("Variant " + var + " cohort EAF is " + formatFloat((double)neff[j] / (double)nobs) +
+                                     " in " + std::to_string(nsamples) +
+                                     " samples.  This is highly unlikely given polygenic score EAF of " + formatFloat(e.eaf));
+                    }
+                    break;
+                }
+                }
+            }
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+}
+
 }  // namespace nimpress
 
 // ------------------------------------------------------------------------------------------
@@ -1951,6 +2160,63 @@ long nh_compute(const char *score_path, const char *vcf_path, const char *bed_pa
             log_out[log_cap - 1] = 0;
         }
         return (long)scores.size();
+    } catch (const std::exception &ex) {
+        g_nh_error = ex.what();
+        return -2;
+    }
+}
+
+// S score files on one genotype file in ONE pass over the genotypes (computePolygenicScoresMulti).  score_paths:
+// newline-separated.  scores_out: [S][n] doubles (cap = room per file); log lines come back prefixed "<file index>\t".
+// Returns the number of samples, < 0 on error.
+long nh_compute_multi(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
+                      int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
+                      int device, double *scores_out, long cap, unsigned long long *nloci_out, char *log_out,
+                      long log_cap) {
+    try {
+        std::vector<std::string> paths = splitChar(score_paths, '\n');
+        std::vector<ScoreFile> files(paths.size());
+        std::vector<const ScoreFile *> ptrs;
+        std::vector<ScoreEntry> all;
+        for (size_t i = 0; i < paths.size(); ++i) {
+            if (!files[i].open(paths[i])) {
+                g_nh_error = "Could not open polygenic score file " + paths[i];
+                return -1;
+            }
+            ptrs.push_back(&files[i]);
+            all.insert(all.end(), files[i].entries.begin(), files[i].entries.end());
+        }
+        VCF vcf;
+        const bool stream = getenv("NIMPRESS_STREAM") != nullptr;
+        if (!((stream && vcf.openStreaming(vcf_path)) || vcf.open(vcf_path, &all))) {
+            g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
+            return -1;
+        }
+        GenomeIntervals cov;
+        const bool restrict = bed_path_or_null != nullptr;
+        std::vector<Log> logs;
+        std::string pre;
+        if (restrict && !loadBedIntervals(cov, bed_path_or_null))
+            pre = std::string("FATAL Could not open coverage BED file ") + bed_path_or_null;
+        std::vector<std::vector<double>> scores;
+        std::vector<uint64_t> nloci;
+        computePolygenicScoresMulti(scores, ptrs, vcf, restrict, cov, (ImputeMethodLocus)imp_locus,
+                                    (ImputeMethodMissing)imp_missing, (ImputeMethodSample)imp_sample, maxmis, afmisp, mincs,
+                                    ignorefilt != 0, logs, device, &nloci);
+        for (size_t s = 0; s < scores.size(); ++s) {
+            for (size_t i = 0; i < scores[s].size() && (long)i < cap; ++i) scores_out[s * (size_t)cap + i] = scores[s][i];
+            if (nloci_out) nloci_out[s] = nloci[s];
+        }
+        if (log_out && log_cap > 0) {
+            std::string allt;
+            for (size_t s = 0; s < logs.size(); ++s) {
+                if (!pre.empty()) allt += std::to_string(s) + "\t" + pre + "\n";
+                for (const std::string &l : logs[s].lines) allt += std::to_string(s) + "\t" + l + "\n";
+            }
+            strncpy(log_out, allt.c_str(), (size_t)log_cap - 1);
+            log_out[log_cap - 1] = 0;
+        }
+        return (long)vcf.n_samples();
     } catch (const std::exception &ex) {
         g_nh_error = ex.what();
         return -2;

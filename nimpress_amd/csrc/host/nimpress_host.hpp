@@ -157,6 +157,20 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                             bool ignoreFilterField, Log &log, int device = 0,
                             uint64_t *nloci_out = nullptr);
 
+// S score files against ONE genotype file in one pass over the genotypes (the reference runs
+// its loop nim:634-641 once per file): the union of the files' loci is located once (findVariant), every located
+// record is decoded on the device straight into a resident 2-bit cohort (nps_cohort_push_gt_raw / _push_bed), and
+// the S definitions are applied together on the matrix cores (nps_score_cohort_multi), at most NPS_MULTI_MAX_SCORES
+// at a time.  Results, nloci and warnings per file are those of computePolygenicScores run file by file (scores up
+// to the 2^-49 quantisation of the weights).  Throws std::runtime_error (also for what this path does not cover:
+// FORMAT/DS records, ploidy above 2, non-finite beta -- callers fall back to the per-file path).
+void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const std::vector<const ScoreFile *> &scoreFiles,
+                                 const VCF &genotypeVcf, bool restrictToCoveredRgns, const GenomeIntervals &coveredIvals,
+                                 ImputeMethodLocus imputeMethodLocus, ImputeMethodMissing imputeMethodMissing,
+                                 ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
+                                 int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs,
+                                 int device = 0, std::vector<uint64_t> *nloci_out = nullptr);
+
 // nim:652-757
 int cliMain(int argc, char **argv);
 

@@ -61,7 +61,20 @@ struct nps_cohort {
     bool optimized = false;
     // NPS_FMT_GT2M: whole-row tallies (nmissing << 32 | neffect) produced by whatever packed the rows
     unsigned long long *d_row_tally = nullptr;
+    // nps_cohort_push_*: rows decoded on the device straight into the cohort (a pinned ring the decode kernel reads
+    // over PCIe, on a stream of the cohort's own); every call that reads the cohort waits for it (cohort_quiesce)
+    hipStream_t push_stream = nullptr;
+    void *h_push[2] = {nullptr, nullptr};
+    hipEvent_t ev_push[2] = {nullptr, nullptr};
+    size_t push_cap = 0;
+    int push_next = 0;
+    unsigned long long *d_push_tally = nullptr;  // scratch word for the decode kernel's tally (a GT2 cohort keeps none)
 };
+
+static int cohort_quiesce(const nps_cohort *c) {
+    if (c && c->push_stream) HIP_TRY(hipStreamSynchronize(c->push_stream));
+    return NPS_OK;
+}
 
 struct PendingRow {
     int32_t batch_idx;  // >= 0: index into the open GT / DS batch's device stats; -1: host stat
@@ -972,6 +985,12 @@ extern "C" void nps_cohort_destroy(nps_cohort *c) {
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_data);
     (void)hipFree(c->d_row_tally);
+    (void)hipFree(c->d_push_tally);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipHostFree(c->h_push[k]);
+        if (c->ev_push[k]) (void)hipEventDestroy(c->ev_push[k]);
+    }
+    if (c->push_stream) (void)hipStreamDestroy(c->push_stream);
     delete c;
 }
 
@@ -1121,6 +1140,82 @@ extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrow
     return gt2_upload(c, row0, nrows, bed_rows, row_stride_bytes, width, effect_is_a1);
 }
 
+// one row of a NPS_FMT_GT2 cohort from the buffer a VCF/BCF record holds, decoded on the device (the resident form of
+// nps_push_gt_raw / nps_push_bed: same kernels, the cohort is the destination)
+static int cohort_push_prepare(nps_cohort *c, uint64_t row, size_t bytes, int *slot) {
+    if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
+    if (c->format != NPS_FMT_GT2) return fail(NPS_E_UNSUPPORTED, "rows are pushed into NPS_FMT_GT2 cohorts only");
+    if (row >= c->n_rows) return fail(NPS_E_INVAL, "row %llu outside cohort of %llu rows", (unsigned long long)row,
+                                      (unsigned long long)c->n_rows);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->push_stream) {
+        HIP_TRY(hipDeviceSynchronize());  // whatever wrote or read the cohort before
+        int rc = cohort_unoptimize(c);
+        if (rc) return rc;
+        HIP_TRY(hipStreamCreateWithFlags(&c->push_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&c->d_push_tally, 256));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&c->ev_push[k], hipEventDisableTiming));
+    }
+    if (c->optimized) {
+        HIP_TRY(hipDeviceSynchronize());
+        int rc = cohort_unoptimize(c);
+        if (rc) return rc;
+    }
+    if (bytes > c->push_cap) {
+        HIP_TRY(hipStreamSynchronize(c->push_stream));
+        for (int k = 0; k < 2; ++k) {
+            (void)hipHostFree(c->h_push[k]);
+            c->h_push[k] = nullptr;
+        }
+        c->push_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->h_push[0], bytes));
+        HIP_TRY(hipHostMalloc(&c->h_push[1], bytes));
+        c->push_cap = bytes;
+    }
+    *slot = c->push_next;
+    c->push_next ^= 1;
+    HIP_TRY(hipEventSynchronize(c->ev_push[*slot]));
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_push_gt_raw(nps_cohort *c, uint64_t row, const void *gt, int elem_bytes, int ploidy,
+                                      int eaidx) {
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
+        return fail(NPS_E_INVAL, "elem_bytes %d (1, 2 or 4)", elem_bytes);
+    if (ploidy < 1) return fail(NPS_E_INVAL, "ploidy %d < 1", ploidy);
+    if (ploidy > 2) return fail(NPS_E_UNSUPPORTED, "ploidy %d > 2 does not fit the 2-bit cohort", ploidy);
+    if (eaidx < 0) return fail(NPS_E_INVAL, "eaidx %d < 0 (nimpress.nim:380 doAssert)", eaidx);
+    if (c && c->n_samples && !gt) return fail(NPS_E_INVAL, "gt is NULL");
+    const size_t bytes = c ? (size_t)elem_bytes * (size_t)ploidy * c->n_samples : 0;
+    int k = 0;
+    int rc = cohort_push_prepare(c, row, std::max<size_t>(bytes, 16), &k);
+    if (rc) return rc;
+    if (c->n_samples == 0) return NPS_OK;
+    memcpy(c->h_push[k], gt, bytes);
+    const uint64_t sw = c->stride_bytes / 4;
+    HIP_TRY(launch_decode_gt(c->push_stream, c->h_push[k], elem_bytes, c->n_samples, ploidy, eaidx,
+                             (uint32_t *)c->d_data + (row >> 2) * sw * 4, (int)(row & 3), c->d_push_tally));
+    HIP_TRY(hipEventRecord(c->ev_push[k], c->push_stream));
+    return NPS_OK;
+}
+
+extern "C" int nps_cohort_push_bed(nps_cohort *c, uint64_t row, const uint8_t *bed_row, int effect_is_a1) {
+    if (c && c->n_samples && !bed_row) return fail(NPS_E_INVAL, "bed_row is NULL");
+    const size_t bytes = c ? (size_t)((c->n_samples + 3) / 4) : 0;
+    int k = 0;
+    int rc = cohort_push_prepare(c, row, std::max<size_t>((bytes + 3) / 4 * 4 + 16, 16), &k);
+    if (rc) return rc;
+    if (c->n_samples == 0) return NPS_OK;
+    memset(c->h_push[k], 0, (bytes + 3) / 4 * 4 + 16);
+    memcpy(c->h_push[k], bed_row, bytes);
+    const uint64_t sw = c->stride_bytes / 4;
+    HIP_TRY(launch_tally_scatter_row(c->push_stream, reinterpret_cast<const uint32_t *>(c->h_push[k]), c->n_samples,
+                                     effect_is_a1 ? 1 : 0, (uint32_t *)c->d_data + (row >> 2) * sw * 4, (int)(row & 3),
+                                     c->d_push_tally));
+    HIP_TRY(hipEventRecord(c->ev_push[k], c->push_stream));
+    return NPS_OK;
+}
+
 extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
@@ -1153,6 +1248,7 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
+    { int qrc = cohort_quiesce(c); if (qrc) return qrc; }
     if (c->format == NPS_FMT_GT2) return gt2_transfer(c, row0, nrows, host_rows, host_stride, false);
     if (c->format == NPS_FMT_GT2X) return gt2x_transfer(c, row0, nrows, host_rows, host_stride, false);
     HIP_TRY(hipMemcpy2D(host_rows, host_stride, (const char *)c->d_data + row0 * c->stride_bytes,
@@ -1373,6 +1469,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (rc) return rc;
     if (co->format == NPS_FMT_GT2M)
         return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are scored with nps_score_cohort_multi");
+    rc = cohort_quiesce(co);  // rows pushed into the cohort (nps_cohort_push_*) are complete
+    if (rc) return rc;
     const bool is_ds = co->format == NPS_FMT_DS32;
     const bool is_mx = co->format == NPS_FMT_GT2X;
     if (is_mx && (cohort_row0 & 127))
@@ -1718,6 +1816,7 @@ extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     if (src->optimized)
         return fail(NPS_E_STATE, "the source cohort is in the nps_cohort_optimize layout; convert it before optimising");
     HIP_TRY(hipSetDevice(dst->device));
+    { int qrc = cohort_quiesce(src); if (qrc) return qrc; }
     HIP_TRY(hipDeviceSynchronize());
     if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;
     if (dst->format == NPS_FMT_GT2X) {

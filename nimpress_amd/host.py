@@ -27,6 +27,10 @@ def load():
         L.nh_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_long, C.c_int, C.c_int, C.c_void_p,
                                  C.c_long, C.POINTER(C.c_ulonglong), C.c_char_p, C.c_long]
+        L.nh_compute_multi.restype = C.c_long
+        L.nh_compute_multi.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_double, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
+                                       C.c_char_p, C.c_long]
         L.nh_vcf_open.restype = C.c_void_p
         L.nh_vcf_open.argtypes = [C.c_char_p, C.c_char_p]
         L.nh_vcf_close.argtypes = [C.c_void_p]
@@ -59,6 +63,41 @@ def compute_polygenic_scores(score_path: str, vcf_path: str, cov: Optional[str] 
     if n < 0:
         raise capi.NpsError(-3 if n == -2 else -1, L.nh_last_error().decode("utf-8", "replace"))
     return scores[:n].copy(), int(nloci.value), [l for l in log.value.decode().split("\n") if l]
+
+
+def compute_polygenic_scores_multi(score_paths, vcf_path: str, cov: Optional[str] = None, imp_locus: str = "ps",
+                                   imp_missing: str = "homref", imp_sample: str = "int_ps", maxmis: float = 0.05,
+                                   mincs: int = 100, afmisp: float = 0.001, ignorefilt: bool = False, device: int = 0,
+                                   max_samples: int = 1 << 22):
+    """Several score files on one genotype file in ONE pass over the genotypes (computePolygenicScoresMulti: the union
+    of the files' loci decoded once into a resident cohort, all definitions applied together on the matrix cores).
+    Returns (scores [files, samples], nloci [files], log lines per file)."""
+    L = load()
+    S = len(score_paths)
+    scores = np.empty((S, max_samples), dtype=np.float64)
+    nloci = np.zeros(S, dtype=np.uint64)
+    log = C.create_string_buffer(4 << 20)
+    n = L.nh_compute_multi("\n".join(score_paths).encode(), vcf_path.encode(), cov.encode() if cov else None,
+                           capi.LOCUS[imp_locus], capi.MISSING[imp_missing], capi.SAMPLE[imp_sample], float(maxmis),
+                           float(afmisp), int(mincs), int(ignorefilt), device, scores.ctypes.data, max_samples,
+                           nloci.ctypes.data, log, len(log))
+    if n < 0:
+        raise capi.NpsError(-3 if n == -2 else -1, L.nh_last_error().decode("utf-8", "replace"))
+    logs = [[] for _ in range(S)]
+    for l in log.value.decode().split("\n"):
+        if l:
+            k, _, text = l.partition("\t")
+            logs[int(k)].append(text)
+    return scores[:, :n].copy(), nloci.astype(np.int64), logs
+
+
+def format_scores(x: np.ndarray) -> List[str]:
+    """format_score over an array, without a C call per value: "%.16g" with ".0" appended where the text has no
+    '.', 'e', 'n' or 'i' (nimpress.nim:753; pinned by scores/*_nimpress_res.txt)"""
+    out = np.char.mod("%.16g", np.asarray(x, dtype=np.float64))
+    plain = ~(np.char.find(out, ".") >= 0) & ~(np.char.find(out, "e") >= 0) & ~(np.char.find(out, "n") >= 0) & \
+        ~(np.char.find(out, "i") >= 0)
+    return np.where(plain, np.char.add(out, ".0"), out).tolist()
 
 
 def sample_names(vcf_path: str) -> List[str]:

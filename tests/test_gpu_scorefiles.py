@@ -108,7 +108,36 @@ def test_eight_scores_sharded_and_gathered(cohort_vcf):
                            equal_nan=True), f
 
 
-def test_score_many_eight_files_on_500k_sample_bcf(tmp_path):
+def test_one_pass_multi_equals_file_by_file(cohort_vcf):
+    """computePolygenicScoresMulti (union of the loci decoded once into a resident cohort, the 8 definitions applied
+    together on the matrix cores) gives, per file, the scores, nloci and warnings of the reference's loop run file
+    by file -- default flags and a second set, AF-mismatch warnings on"""
+    vcf = refcpu.read_vcf(cohort_vcf)
+    files = SCORES[:-1]
+    for kw in (dict(afmisp=0.001), dict(imp_locus="homref", imp_missing="ignore", imp_sample="ps", maxmis=0.5,
+                                        ignorefilt=True, afmisp=0.001)):
+        got, nloci, logs = host.compute_polygenic_scores_multi(files, cohort_vcf, **kw)
+        assert got.shape == (len(files), 1500)
+        for i, f in enumerate(files):
+            s1, n1, log1 = host.compute_polygenic_scores(f, cohort_vcf, **kw)
+            assert nloci[i] == n1, f
+            assert logs[i] == log1, (f, logs[i][:3], log1[:3])
+            okw = {k: v for k, v in kw.items() if k != "afmisp"}
+            ref, ref_nloci, _ = oracle_run(f, vcf, **okw)
+            assert n1 == ref_nloci
+            assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), f
+            ok = ~np.isnan(ref)
+            scale = 1e-12 + (np.max(np.abs(ref[ok])) if ok.any() else 0.0)
+            assert np.max(np.abs(got[i][ok] - ref[ok]), initial=0.0) <= 1e-6 * scale, f
+
+
+def test_vectorised_float_format_equals_scalar():
+    x = np.concatenate([np.random.default_rng(1).normal(0, 1, 2000), [0.0, 1.0, -2.0, 1e22, 1e-7, np.nan, np.inf, 123456789.0]])
+    assert host.format_scores(x) == [host.format_score(float(v)) for v in x]
+
+
+@pytest.mark.parametrize("one_pass", [False, True])
+def test_score_many_eight_files_on_500k_sample_bcf(tmp_path, one_pass):
     """BASELINE.json configs[3] at its cohort size: the 8 score-format files of the reference tree on ONE
     500 000-sample BCF2 (+CSI) holding the union of their loci, through tools/score_many.py (one score
     definition per rank at a time; a single rank here, the gather is exercised with 2 ranks on the CPU in
@@ -124,8 +153,10 @@ def test_score_many_eight_files_on_500k_sample_bcf(tmp_path):
     path, samples, recs = config2.write_union_cohort(tmp_path, files, n)
     out = str(tmp_path / "matrix.tsv")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1",
-                        "--afmisp=0", "--out", out] + files + [path], capture_output=True, text=True)
+                        "--afmisp=0", "--out", out] + (["--one-pass"] if one_pass else []) + files + [path],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    assert ("one pass over the genotypes" in r.stderr) == one_pass, r.stderr[-500:]
     rows = [l.rstrip("\n").split("\t") for l in open(out)]
     assert [x[0] for x in rows] == samples
     got = np.array([[float(v) for v in x[1:]] for x in rows]).T           # [scores, samples]

@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 def parse_args(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--one-pass", action="store_true",
+                    help="this rank's score files in ONE pass over the genotypes: the union of their loci is decoded once "
+                         "into a resident cohort and the definitions are applied together on the matrix cores (falls back "
+                         "to the per-file loop for inputs that path does not cover, e.g. FORMAT/DS records)")
     ap.add_argument("--out", default="-", help="output TSV (default: stdout)")
     ap.add_argument("--cov", default=None)
     ap.add_argument("--imp-locus", default="ps", choices=["ps", "homref", "fail", "ignore"])
@@ -104,22 +108,38 @@ def main(argv=None):
         logs[i] = log
         out_row.copy_(torch.from_numpy(s).to(out_row.device))
 
+    one_pass_used = False
     t0 = time.perf_counter()
+    if args.one_pass:
+        mine = list(range(rank, len(score_files), world))
+        try:
+            sc, _nl, lg = host.compute_polygenic_scores_multi(
+                [score_files[i] for i in mine], cohort, cov=args.cov, imp_locus=args.imp_locus,
+                imp_missing=args.imp_missing, imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs,
+                afmisp=args.afmisp, ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1)) if mine else (None, None, [])
+            cache = {i: sc[k] for k, i in enumerate(mine)}
+            for k, i in enumerate(mine):
+                logs[i] = lg[k]
+            one_pass_used = True
+
+            def score_fn(i, out_row):  # noqa: F811  (the rows are there already)
+                out_row.copy_(torch.from_numpy(cache[i]).to(out_row.device))
+        except capi.NpsError as e:
+            sys.stderr.write("score_many: one-pass path not applicable (%s); scoring file by file\n" % e)
     full = multi.evaluate_sharded(len(score_files), n, score_fn, device if world > 1 else torch.device("cpu"))
     elapsed = time.perf_counter() - t0
     for i in sorted(logs):
         for line in logs[i]:
             sys.stderr.write("[%s] %s\n" % (os.path.basename(score_files[i]), line))
     if rank == 0:
-        from nimpress_amd.host import format_score
         mat = full.cpu().numpy()
+        cols = [host.format_scores(mat[i]) for i in range(mat.shape[0])]   # the reference's float format, vectorised
         out = sys.stdout if args.out == "-" else open(args.out, "w")
-        for j, name in enumerate(names):
-            out.write(name + "\t" + "\t".join(format_score(float(mat[i, j])) for i in range(mat.shape[0])) + "\n")
+        out.write("".join(name + "\t" + "\t".join(c[j] for c in cols) + "\n" for j, name in enumerate(names)))
         if out is not sys.stdout:
             out.close()
-        sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s\n"
-                         % (len(score_files), n, world, elapsed))
+        sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s%s\n"
+                         % (len(score_files), n, world, elapsed, " (one pass over the genotypes)" if one_pass_used else ""))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
