@@ -210,7 +210,7 @@ def cover_columns(n_per_thread_samples, n, samples_per_slice):
 
 
 def score_delta(stats, got, nloci, fmt, beta, eaf, seed, n, m, th, tm, tmi, geometry, row0=0,
-                recount=1000, params=None):
+                recount=20000, params=None):
     """The second half of BASELINE.json's metric ("+ max-abs score delta vs reference"), outside the timed
     region, rank 0 only.  `stats` / `got` / `nloci` come from one more pass with per-row statistics.
     The oracle (oracle/refcpu.c, the checker -- nothing of it is timed or shipped) then
@@ -568,6 +568,42 @@ def config2_e2e(tmpdir):
                         "int8 GT, CSI random access), process start to exit, best of 2"}
 
 
+def config4_e2e(tmpdir, n=500_000):
+    """BASELINE.json configs[3] end to end on one GPU: the 8 score-format files of the reference tree on ONE
+    500 000-sample BCF2 (+CSI) holding the union of their loci (tests/config2.py), through tools/score_many.py --
+    file by file (the reference's loop, 8 times) and with --one-pass (the union decoded once into a resident cohort,
+    the 8 definitions applied together on the matrix cores).  Process start to the matrix written."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config2
+    g = os.path.join(ROOT, "tests", "golden")
+    files = sorted(os.path.join(g, "scores", f) for f in os.listdir(os.path.join(g, "scores"))) + [os.path.join(g, "set1.score")]
+    path, samples, recs = config2.write_union_cohort(tmpdir, files, n)
+    gt_bytes = sum(int(r["gts"].size) for r in recs)            # int8 FORMAT/GT bytes in the file's records
+    out = {"workload": "tools/score_many.py --gpus 1 --afmisp=0 <8 score files> union.bcf (%d samples, %d records, "
+                       "int8 GT, CSI random access), process start to the samples x scores matrix written" % (n, len(recs)),
+           "score_files": len(files), "records": len(recs), "samples": n}
+    res = {}
+    for label, extra in (("per_file", []), ("one_pass", ["--one-pass"])):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1", "--afmisp=0",
+                                "--out", os.path.join(tmpdir, label + ".tsv")] + extra + files + [path],
+                               capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            best = dt if best is None else min(best, dt)
+        res[label] = best
+    a = open(os.path.join(tmpdir, "per_file.tsv")).read().split("\n")
+    b = open(os.path.join(tmpdir, "one_pass.tsv")).read().split("\n")
+    same_rows = len(a) == len(b) and all(x.split("\t")[0] == y.split("\t")[0] for x, y in zip(a, b))
+    out.update({"e2e_s": res["one_pass"], "per_file_e2e_s": res["per_file"],
+                "one_pass_vs_per_file": res["per_file"] / res["one_pass"],
+                "ingest_GBps": gt_bytes / res["one_pass"] / 1e9, "outputs_have_the_same_samples": bool(same_rows)})
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -802,6 +838,12 @@ def main():
                     return config2_e2e(td)
 
             leg("config2", config2_leg)
+
+            def config4_leg():
+                with tempfile.TemporaryDirectory() as td:
+                    return config4_e2e(td)
+
+            leg("config4", config4_leg)
             out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2063,7 +2063,10 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
         HIP_TRY(hipMalloc(&m->d_partial, sizeof(int32_t) * std::max<uint64_t>(pl.partial_elems(), 1)));
         m->partial_cap = pl.partial_elems();
     }
-    multi_drain_timing(m);  // (the events are about to be re-recorded)
+    // (the timing events are about to be re-recorded: read the previous pass's times only if it has completed already --
+    //  a caller that queues pass after pass is never blocked here; its per-pass times are then not accumulated)
+    if (m->timed && hipEventQuery(m->ev[3]) == hipSuccess) multi_drain_timing(m);
+    m->timed = false;
     // Everything that can be refused has been checked and allocated.  From here a HIP failure leaves the running
     // sums and counts of the context undefined: it is marked broken (NPS_E_STATE until nps_multi_reset).
     // (multi_params_kernel writes every fragment of the table, zeros for unused columns and padding rows)

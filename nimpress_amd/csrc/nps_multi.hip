@@ -194,7 +194,9 @@ hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, 
                        d_t_hom, d_t_miss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(d_tally + row0, 0, sizeof(unsigned long long) * n_rows, st);
+    // whole 1 KiB units are written: the rows of the last superblock past n_rows are zero genotypes now, so their
+    // tallies go back to zero as well (the tally array is padded to whole superblocks)
+    e = hipMemsetAsync(d_tally + row0, 0, sizeof(unsigned long long) * n_sb * 128, st);
     if (e != hipSuccess) return e;
     for (uint64_t r = 0; r < n_rows; r += 65535) {
         const uint64_t k = std::min<uint64_t>(65535, n_rows - r);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
         } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
             locus();
         }  // else: the row is not part of this score
-        const bool m_nan = wM != wM;
+        const bool m_nan = !(fabs(wM) < __builtin_huge_val());  // NaN, or an infinite eaf: llrint(inf) is undefined
         int dd[8], dmm[8];
         weight_digits(llrint(ldexp(wD, fx)), 0, f, 0, false, dd);
         weight_digits(m_nan ? 0ll : llrint(ldexp(wM, fx)), 1, f, m_nan ? 1 : 0, coarse_missing && NT == 2, dmm);
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
         any_m_nan |= m_nan;
         n_used += used;
         if (has_const) {
-            if (cst != cst) {
+            if (!(fabs(cst) < __builtin_huge_val())) {
                 c_nan = true;
             } else {
                 const long long V = llrint(ldexp(cst, fx));  // exact, order-independent sums of both halves

@@ -134,9 +134,9 @@ def lib():
     return L
 
 
-def host_threads(cap: int = 16) -> int:
-    """threads for the checker's OpenMP helpers: the CPUs this process may use, at most `cap` (a GPU box
-    gives one GPU's job 16 cores)"""
+def host_threads(cap: int = 64) -> int:
+    """threads for the checker's OpenMP helpers: the CPUs this process may use, at most `cap` (the CPU baseline of
+    bench.py asks for 16, the share of a GPU box one GPU's job gets; the full-size checks take what is there)"""
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:

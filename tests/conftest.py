@@ -26,3 +26,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def need_free_hbm(gib):
+    """Full-size tests need most of an MI355X's 288 GB.  On a smaller part they are skipped; on an MI355X whose HBM is
+    taken by something else they FAIL (a busy GPU must be an error, not an "s" in a green run)."""
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free >= gib * (1 << 30):
+        return
+    assert total < 256 * (1 << 30), ("this device has %.0f GB of HBM but only %.0f GB are free (%d GB needed): "
+                                     "another job holds the GPU" % (total / 2 ** 30, free / 2 ** 30, gib))
+    pytest.skip("needs %d GB of free HBM (device has %.0f GB)" % (gib, total / 2 ** 30))

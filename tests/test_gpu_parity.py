@@ -452,7 +452,7 @@ def test_full_size_config3_properties():
     """BASELINE.json configs[2] at its full size (500 000 samples x 1 000 000 rows, 125 GB of 2-bit
     codes resident in HBM): far beyond what the oracle can score, so parity goes through
     size-independent properties plus the oracle on what it CAN reach:
-      * every row's decision (1000 rows over --maxmis, nloci = M); the whole-row tallies of 1000 random
+      * every row's decision (1000 rows over --maxmis, nloci = M); the whole-row tallies of 20 000 random
         rows recounted by the oracle over all 500 000 samples;
       * 2 800 samples taken from every one of the 35 slices of the persistent grid (and the last ragged
         word) scored over ALL rows by oracle/refcpu.c (ref_score_subset: the restated procs of
@@ -462,9 +462,8 @@ def test_full_size_config3_properties():
       * the two row halves scored separately add up to the whole."""
     import torch
     n, m, seed = 500_000, 1_000_000, 20250103
-    free, _total = torch.cuda.mem_get_info()
-    if free < 150 * (1 << 30):
-        pytest.skip("needs 150 GB of free HBM")
+    from conftest import need_free_hbm
+    need_free_hbm(150)
     rng = np.random.default_rng(seed)
     beta = np.round(rng.normal(0.0, 0.02, m), 4)
     eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
@@ -493,7 +492,7 @@ def test_full_size_config3_properties():
     assert int(stats["used"].sum()) == m
     # whole-row tallies of 1000 random rows (+ first, last, an over-maxmis one) recounted by the oracle
     # over all 500 000 samples: decode nim:367-391 + tallyAlleles nim:32-47, bit for bit
-    rows = np.unique(np.concatenate([np.random.default_rng(1).choice(m, 1000, replace=False),
+    rows = np.unique(np.concatenate([np.random.default_rng(1).choice(m, 20000, replace=False),
                                      [0, 1000, 499_999, m - 1]])).astype(np.uint64)
     ri = rows.astype(np.int64)
     g, ms, ne = refcpu.tally_synth_rows(rows, n, seed, th[ri], tm[ri], tmi[ri])
@@ -710,9 +709,8 @@ def test_ds_large_fused_equals_twopass_and_scaling():
     the sums exactly; one row's tally is recounted by the oracle's generator."""
     import torch
     n, m, seed = 200_000, 65_536, 20250105
-    free, _total = torch.cuda.mem_get_info()
-    if free < 70 * (1 << 30):
-        pytest.skip("needs 70 GB of free HBM")
+    from conftest import need_free_hbm
+    need_free_hbm(70)
     rng = np.random.default_rng(seed)
     beta = np.round(rng.normal(0.0, 0.02, m), 4)
     eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
@@ -764,9 +762,8 @@ def test_ds_config5_resident_chunks_vs_oracle_subset():
       * scores(2 beta) == 2 scores(beta) bit for bit on the chunked path."""
     import torch
     n, m, seed = 200_000, 300_000, 20250105
-    free, _total = torch.cuda.mem_get_info()
-    if free < 250 * (1 << 30):
-        pytest.skip("needs 250 GB of free HBM")
+    from conftest import need_free_hbm
+    need_free_hbm(250)
     rng = np.random.default_rng(seed)
     beta = np.round(rng.normal(0.0, 0.02, m), 4)
     eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
