@@ -68,25 +68,33 @@ def parse_args():
                          "spread over twice as many LDS banks)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20250103)
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="--gpus N without a launcher: seconds after which all ranks are killed (exit status 124)")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s):
     """Start the N rank processes (this process never touches a GPU), wait for them, pass on the
-    highest exit code.  Rank 0 inherits stdout, so its JSON line is this command's JSON line."""
+    highest exit code.  Rank 0 inherits stdout, so its JSON line is this command's JSON line.  Every rank's
+    stderr is kept (rank 0: inherited; the others: a file each, replayed with a rank prefix when a rank fails or
+    the run times out).  A run that exceeds `timeout_s` is killed as a whole and exits with status 124."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ef = None if r == 0 else tempfile.TemporaryFile(mode="w+")
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=ef))
     rc = 0
+    deadline = time.monotonic() + timeout_s
     try:
         pending = list(procs)
         while pending:
@@ -99,11 +107,24 @@ def spawn_ranks(n):
                     rc = rc or code
                     for q in pending:  # a rank died: the others would wait in a collective for ever
                         q.terminate()
+            if pending and time.monotonic() > deadline:
+                sys.stderr.write("bench.py: %d rank(s) still running after %.0f s: killing the run\n" % (len(pending), timeout_s))
+                rc = rc or 124
+                for q in pending:
+                    q.kill()
+                break
             time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        if rc:
+            for r, ef in enumerate(errs):
+                if ef is not None:
+                    ef.seek(0)
+                    tail = ef.read()[-4000:]
+                    if tail.strip():
+                        sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in tail.splitlines()))
     sys.exit(rc)
 
 
@@ -608,7 +629,7 @@ def config4_e2e(tmpdir, n=500_000):
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        spawn_ranks(args.gpus)  # does not return
+        spawn_ranks(args.gpus, args.rank_timeout)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -628,7 +649,7 @@ def main():
         one = torch.ones(1, dtype=torch.int64, device="cuda")
         dist.all_reduce(one)               # sanity: every rank takes part in an RCCL collective
         rccl_ranks = int(one.item())
-        assert rccl_ranks == dist.get_world_size() == world
+        assert rccl_ranks == dist.get_world_size() == world == args.gpus, (rccl_ranks, world, args.gpus)
 
     n, m = args.samples, args.variants
     mode = {"auto": capi.MODE_AUTO, "twopass": capi.MODE_TWOPASS, "fused": capi.MODE_FUSED}[args.mode]

@@ -327,6 +327,12 @@ int nps_score_cohort_multi(nps_multi *m, const nps_cohort *c, uint64_t cohort_ro
 /* scores_out: [n_scores][n_samples]; nloci_out: [n_scores]; offsets: [n_scores]  (nimpress.nim:643-649) */
 int nps_multi_finish(nps_multi *m, const double *offsets, double *scores_out, uint64_t *nloci_out);
 int nps_multi_finish_device(nps_multi *m, const double *offsets, double *d_scores_out, uint64_t *nloci_out);
+/* Row-sharded evaluation of S scores over several GPUs (each GPU holds a block of the union's rows and ALL samples:
+ * tallies stay local and exact, and the cohort is split instead of replicated): the state of the reference's loop
+ * before its normalisation (nimpress.nim:639-641), d_sums_out[n_scores][n_samples] and nloci_out[n_scores] of this
+ * context's rows, for the one exchange of that layout -- a sum all-reduce of both (RCCL).  The caller then applies
+ * nimpress.nim:643-649: sums / (2 nloci) + offset (nimpress_amd/multi.py: normalize_matrix). */
+int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64_t *nloci_out);
 int nps_multi_reset(nps_multi *m, const nps_params *params /* NULL = keep */);
 void nps_multi_destroy(nps_multi *m);
 /* device time (HIP events) of the calls since the last reset: weight digits, the product, the fold */

@@ -61,7 +61,7 @@ SYMBOLS = [
     "nps_multidef_create", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
     "nps_cohort_convert", "nps_cohort_row_tallies", "nps_multi_set_missing_weight_bits",
-    "nps_cohort_push_gt_raw", "nps_cohort_push_bed",
+    "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device",
 ]
 
 
@@ -177,6 +177,7 @@ def load():
     L.nps_score_cohort_multi.argtypes = [vp, vp, u64, vp]
     L.nps_multi_finish.argtypes = [vp, vp, vp, vp]
     L.nps_multi_finish_device.argtypes = [vp, vp, vp, vp]
+    L.nps_multi_partial_device.argtypes = [vp, vp, vp]
     L.nps_multi_reset.argtypes = [vp, C.POINTER(NpsParams)]
     L.nps_multi_destroy.argtypes = [vp]
     L.nps_multi_destroy.restype = None
@@ -488,6 +489,12 @@ class MultiScorer:
         nloci = np.zeros(self.n_scores, dtype=np.uint64)
         _check(load().nps_multi_finish(self._h, off.ctypes.data, scores.ctypes.data, nloci.ctypes.data))
         return scores[:, : self.n], nloci
+
+    def partial_device(self, d_sums_ptr: int) -> np.ndarray:
+        """un-normalised sums [n_scores, n_samples] of this context's rows -> device buffer; returns nloci per score"""
+        nloci = np.zeros(self.n_scores, dtype=np.uint64)
+        _check(load().nps_multi_partial_device(self._h, C.c_void_p(d_sums_ptr), nloci.ctypes.data))
+        return nloci
 
     def finish_device(self, offsets, d_scores_ptr: int) -> np.ndarray:
         off = np.ascontiguousarray(offsets, dtype=np.float64)

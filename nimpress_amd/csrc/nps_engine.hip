@@ -2102,13 +2102,14 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
 }
 
 static int multi_finish_common(nps_multi *m, const double *offsets, double *d_dst, double *h_scores_out,
-                               uint64_t *nloci_out) {
-    if (!offsets) return fail(NPS_E_INVAL, "offsets is NULL");
+                               uint64_t *nloci_out, int normalise = 1) {
+    if (!offsets && normalise) return fail(NPS_E_INVAL, "offsets is NULL");
     if (m->broken) return fail(NPS_E_STATE, "an earlier pass failed on the device: nps_multi_reset first");
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemcpyAsync(m->d_offsets, offsets, sizeof(double) * m->S, hipMemcpyHostToDevice, m->stream));
+    if (normalise)
+        HIP_TRY(hipMemcpyAsync(m->d_offsets, offsets, sizeof(double) * m->S, hipMemcpyHostToDevice, m->stream));
     HIP_TRY(launch_multi_finish(m->stream, m->d_part, m->n, m->S, m->d_state, m->d_offsets, m->have_sums ? 1 : 0,
-                                d_dst));
+                                d_dst, normalise));
     std::vector<char> st(multi_state_bytes() * m->S);
     HIP_TRY(hipMemcpyAsync(st.data(), m->d_state, st.size(), hipMemcpyDeviceToHost, m->stream));
     if (h_scores_out && m->n)
@@ -2131,6 +2132,12 @@ extern "C" int nps_multi_finish_device(nps_multi *m, const double *offsets, doub
     if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
     if (m->n && !d_scores_out) return fail(NPS_E_INVAL, "d_scores_out is NULL");
     return multi_finish_common(m, offsets, d_scores_out, nullptr, nloci_out);
+}
+
+extern "C" int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64_t *nloci_out) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (m->n && !d_sums_out) return fail(NPS_E_INVAL, "d_sums_out is NULL");
+    return multi_finish_common(m, nullptr, d_sums_out, nullptr, nloci_out, 0);
 }
 
 extern "C" int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold) {

@@ -234,7 +234,7 @@ hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state);
 hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,
-                               const double *d_offsets, int have_sums, double *d_scores);
+                               const double *d_offsets, int have_sums, double *d_scores, int normalise = 1);
 
 // ---- single-read kernel on the matrix cores for the strip layout NPS_FMT_GT2X (nps_mx.hip) -----------------
 // cohort = [strip of 2048 samples][superblock of 128 rows][unit of 32 samples][row][8 bytes]; codes 0, 1, 2 =

@@ -634,14 +634,16 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restri
 __global__ __launch_bounds__(256) void multi_finish_kernel(const double *__restrict__ part, uint64_t n_samples, int S,
                                                            const MultiState *__restrict__ state,
                                                            const double *__restrict__ offsets, int have_sums,
-                                                           double *__restrict__ scores) {
+                                                           int normalise, double *__restrict__ scores) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (i >= n_samples) return;
     double v = have_sums ? part[(uint64_t)s * n_samples + i] : 0.0;
     v += state[s].const_sum;
-    v /= (double)state[s].nloci * 2.0;
-    v += offsets[s];
+    if (normalise) {  // (normalise = 0: the un-normalised sums of a row-sharded run, for the all-reduce)
+        v /= (double)state[s].nloci * 2.0;
+        v += offsets[s];
+    }
     scores[(uint64_t)s * n_samples + i] = v;
 }
 
@@ -709,11 +711,11 @@ hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t 
 }
 
 hipError_t launch_multi_finish(hipStream_t st, const double *d_part, uint64_t n_samples, int S, const void *d_state,
-                               const double *d_offsets, int have_sums, double *d_scores) {
+                               const double *d_offsets, int have_sums, double *d_scores, int normalise) {
     if (n_samples == 0) return hipSuccess;
     (void)hipGetLastError();
     hipLaunchKernelGGL(multi_finish_kernel, dim3((uint32_t)((n_samples + 255) / 256), (uint32_t)S), dim3(256), 0, st,
-                       d_part, n_samples, S, (const MultiState *)d_state, d_offsets, have_sums, d_scores);
+                       d_part, n_samples, S, (const MultiState *)d_state, d_offsets, have_sums, normalise, d_scores);
     return hipGetLastError();
 }
 

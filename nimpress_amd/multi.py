@@ -79,3 +79,24 @@ def all_reduce_partial(sums: torch.Tensor, nloci: int, group=None):
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return sums, int(cnt.item())
+
+
+def all_reduce_partial_matrix(sums: torch.Tensor, nloci, group=None):
+    """Rows sharded over the GPUs AND all S scores on every GPU (one multi-score pass per GPU over its block of the
+    cohort's rows: 1 / world of the matrix per GPU instead of a replica): the one exchange is a sum all-reduce of
+    the un-normalised [S, N] sums (from nps_multi_partial_device) and of the S nloci counts.  Returns
+    (sums, nloci_total [S] int64 tensor on the CPU)."""
+    cnt = torch.as_tensor([int(x) for x in nloci], dtype=torch.int64, device=sums.device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return sums, cnt.cpu()
+
+
+def normalize_matrix(sums: torch.Tensor, nloci: torch.Tensor, offsets) -> torch.Tensor:
+    """nimpress.nim:643-649 per score, in place: sums[s] / (nloci[s] * 2.0) + offset[s] (float64; nloci = 0 gives NaN
+    as in the reference)."""
+    d = (nloci.to(torch.float64) * 2.0).to(sums.device).view(-1, 1)
+    off = torch.as_tensor(list(offsets), dtype=torch.float64, device=sums.device).view(-1, 1)
+    sums.div_(d).add_(off)
+    return sums

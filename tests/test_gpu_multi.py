@@ -259,3 +259,37 @@ def test_multi_bad_arguments():
         co.upload(0, np.zeros((128, 4), dtype=np.uint32))
     for x in (sc, msc, mdef, co, gt):
         x.close()
+
+
+def test_multi_partial_sums_of_row_blocks_add_up():
+    """rows sharded x all S scores per GPU: two contexts score the two 128-aligned row blocks of
+    the cohort; the un-normalised sums and nloci (nps_multi_partial_device) added up and normalised
+    (multi.normalize_matrix) equal the one-context run"""
+    import torch
+    from nimpress_amd import multi
+    n, m, S = 20_000, 640, 5
+    eaf_c, th, tm, tmi, descs = make_case(n, m, S, 4321, with_kinds=True)
+    co = capi.Cohort(n, m, fmt=capi.FMT_GT2M)
+    co.synth(0, 4321, th, tm, tmi)
+    offsets = np.arange(S) * 0.25
+    whole = capi.MultiScorer(n, capi.make_params(), S)
+    mdef = capi.MultiDef(descs)
+    whole.score_cohort(co, mdef)
+    ref, ref_nloci = whole.finish(offsets)
+    whole.close()
+    mdef.close()
+    sums = torch.zeros((S, n), dtype=torch.float64, device="cuda")
+    total = np.zeros(S, np.int64)
+    for r0, r1 in ((0, 384), (384, m)):
+        part = capi.MultiScorer(n, capi.make_params(), S)
+        d = capi.MultiDef(np.ascontiguousarray(descs[:, r0:r1]))
+        part.score_cohort(co, d, r0)
+        buf = torch.empty((S, n), dtype=torch.float64, device="cuda")
+        total += part.partial_device(buf.data_ptr()).astype(np.int64)
+        sums += buf
+        part.close()
+        d.close()
+    got = multi.normalize_matrix(sums, torch.from_numpy(total), offsets).cpu().numpy()
+    assert np.array_equal(total, ref_nloci.astype(np.int64))
+    assert np.allclose(got, ref, rtol=0, atol=1e-12 * float(np.abs(descs["beta"]).sum()), equal_nan=True)
+    co.close()

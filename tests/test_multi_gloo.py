@@ -123,6 +123,48 @@ def test_row_sharded_all_reduce(m):
         assert np.allclose(got, ref, rtol=0, atol=1e-13 * max(1.0, np.abs(beta).sum()))
 
 
+# ---- rows sharded over ranks x ALL S scores on every rank: one all-reduce of the [S, N] sums ----
+def _row_matrix_worker(rank, world, port, n, m, S, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eaf, codes = _cohort(n, m, 13)
+        r0, r1 = multi.shard_rows(m, world, rank, align=128)   # (the multi-score cohort layout has 128-row superblocks)
+        sums = np.zeros((S, n))
+        nloci = np.zeros(S, np.int64)
+        for s_ in range(S):      # stand-in for ONE multi-score pass over this rank's block (nps_multi_partial_device)
+            beta = np.round(np.random.default_rng(300 + s_).normal(0, 0.05, m), 4)
+            sc = refcpu.RefScorer(n, refcpu.make_params("ps", "homref", "int_ps", 0.05, 10))
+            for j in range(r0, r1):
+                sc.row_gt(refcpu.codes_to_gt(codes[j], n), 2, 1, False, beta[j], eaf[j])
+            sums[s_], nloci[s_] = sc.partial()
+            sc.finish(0.0)
+        t, total = multi.all_reduce_partial_matrix(torch.from_numpy(sums), nloci)
+        out = multi.normalize_matrix(t, total, [0.1 * s_ for s_ in range(S)])
+        ret[rank] = (out.numpy().copy(), total.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m", [300, 129, 5])
+def test_row_sharded_multi_score_all_reduce(m):
+    world, n, S = 2, 97, 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_row_matrix_worker, args=(world, port, n, m, S, ret), nprocs=world, join=True)
+    eaf, codes = _cohort(n, m, 13)
+    for s_ in range(S):
+        beta = np.round(np.random.default_rng(300 + s_).normal(0, 0.05, m), 4)
+        ref, _, ref_nloci = refcpu.score_packed(codes, n, np.zeros(m, np.int32), np.zeros(m, np.int32), beta, eaf,
+                                                refcpu.make_params("ps", "homref", "int_ps", 0.05, 10), 0.1 * s_)
+        for r in range(world):
+            got, total = ret[r]
+            assert total[s_] == ref_nloci
+            assert np.allclose(got[s_], ref, rtol=0, atol=1e-13 * max(1.0, np.abs(beta).sum()))
+
+
 def test_shard_rows_partition():
     for n_rows in (0, 1, 3, 4, 5, 17, 1000, 1_000_003):
         for world in (1, 2, 3, 8):
