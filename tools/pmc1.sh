@@ -15,7 +15,7 @@ run() { # name, counters...
 import csv,sys,collections
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'fused_cw' in r['Kernel_Name']:
+    if 'fused_cw' in r['Kernel_Name'] or 'fused_mx' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in sorted(acc.items()): print(k, sum(v)/len(v), len(v))
 PY

@@ -35,7 +35,7 @@ def pmc(name, counter):
         return None
     rd = csv.DictReader(open(f))
     for r in rd:
-        if "fused" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "fused" in r["Kernel_Name"] and "fold" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
             rows.append(r)
             kernel_names.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
@@ -63,6 +63,7 @@ if fetch and write:
         "hbm_bytes_per_step": 2.0 * fetch[0] * 1024.0 + write[0] * 1024.0})
 if kernel_names:
     traffic["kernel"] = sorted(kernel_names)[0]
-json.dump(traffic, open(os.path.join(dst, "traffic_ds.json" if is_ds else "traffic.json"), "w"), indent=1)
+is_strip = "NPS_FMT_GT2X" in cfg.get("cohort_layout", "")
+json.dump(traffic, open(os.path.join(dst, "traffic_ds.json" if is_ds else ("traffic_strip.json" if is_strip else "traffic.json")), "w"), indent=1)
 print(json.dumps(traffic))
 print(open(os.path.join(out_dir, "bench.json")).read().strip()[:600])
