@@ -9,13 +9,13 @@
 //   * cooperative grid = Q teams x P workgroups (one per CU).  Workgroup (q,p) owns 7 680 samples
 //     (8 per data thread: two float4 columns 256 samples apart, so every wave instruction reads
 //     1 KiB contiguously) and the row batches q, q+Q, ... (2 rows per batch).
-//   * 15 data waves: 5-deep register ring of batches; per phase they accumulate batch k in the
+//   * 15 data waves: 6-deep register ring of batches; per phase they accumulate batch k in the
 //     reference's own order and operations (row after row, float64 `dosage * beta` then `+=`,
-//     not fused), tally batch k+4 (NaN count by wave ballot, dosage sum by a fixed-shape tree) and
+//     not fused), tally batch k+5 (NaN count by wave ballot, dosage sum by a fixed-shape tree) and
 //     refill the ring.
 //   * control wave: combines the waves' partial tallies in fixed order, stores the workgroup's
 //     partial dosage sum to psum[row][slice] (sc1 store, drained) and then signals with one 64-bit
-//     agent-scope atomic (arrivals<<56 | nmissing); two phases later it polls the row's word until
+//     agent-scope atomic (arrivals<<56 | nmissing); two phases after that it looks at the row's word until
 //     all P slices have arrived, adds the P partial sums (sc1 loads) in fixed order -- deterministic,
 //     and derives the row's parameters for the data waves.  One workgroup barrier per batch.
 //
@@ -32,7 +32,7 @@ namespace nps {
 
 constexpr int kDsRows = 2;     // rows per batch
 constexpr int kDsPerThread = 8;
-constexpr int kDsRing = 5;     // batches in flight per data thread
+constexpr int kDsRing = 6;     // batches held per data thread: one accumulated, four tallied and waiting for the hand-over, one on its way
 // workgroup size T: wave 0 is the control wave, T/64 - 1 data waves of 512 samples each
 static constexpr uint32_t ds_slice_samples(int threads) { return (uint32_t)(threads - 64) * kDsPerThread; }
 constexpr uint32_t kDsSpinLimit = 1u << 20;
@@ -112,10 +112,12 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     auto batch_row0 = [&](uint32_t k) -> uint64_t { return (uint64_t)(team + (uint64_t)k * a.Q) * R; };
 
     // Barrier #j closes the phase in which the data waves tallied batch j.
-    //   data waves, phase k (between #(k+3) and #(k+4)): accumulate batch k with rowp[k&1], tally
-    //       batch k+4, refill the ring slot of batch k with batch k+5
-    //   control wave, same phase: publish batch k+3; parameters of batch k+1 (its tallies were
-    //       published by every slice two phases ago) -> rowp[(k+1)&1]
+    //   data waves, phase k (between #(k+4) and #(k+5)): accumulate batch k with rowp[k&1], tally
+    //       batch k+5, refill the ring slot of batch k with batch k+6
+    //   control wave, same phase: publish batch k+4; look at batch k+2 (published by every slice two
+    //       phases ago: a look that finds a word incomplete costs the phase a second round trip, and
+    //       with one phase of distance that happened often enough to cost 17 % of the pass);
+    //       parameters of batch k+1 -> rowp[(k+1)&1]
     if (wave == 0) {
         // ------------------------------------------------------------------ control wave
         uint32_t nloci_local = 0;
@@ -286,21 +288,23 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         publish(1);
         __syncthreads();  // #2
         publish(2);
+        __syncthreads();  // #3
+        publish(3);
         Polled cur = poll_issue(0);
         poll_finish(0, cur);
         psum_issue(0, v);
         params(0, cur, v);
         cur = poll_issue(1);
         poll_finish(1, cur);
-        __syncthreads();  // #3
+        __syncthreads();  // #4
         for (uint32_t k = 0; k < n_steps; ++k) {
             psum_issue(k + 1, v);             // batch k+1: arrival word matched a phase ago
-            Polled nxt = poll_issue(k + 2);   // batch k+2: published by every slice a phase ago
-            publish(k + 3);                   // drains the loads above with its own store
+            Polled nxt = poll_issue(k + 2);   // batch k+2: published by every slice TWO phases ago: complete unless a slice lags
+            publish(k + 4);                   // drains the loads above with its own store
             poll_finish(k + 2, nxt);
             params(k + 1, cur, v);
             cur = nxt;
-            __syncthreads();  // #(k+4)
+            __syncthreads();  // #(k+5)
         }
         if (slice == 0 && lane == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
         return;
@@ -392,11 +396,11 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
 
     auto step = [&](uint32_t k, float(&r_cur)[R * kDsPerThread], const float(&r_tal)[R * kDsPerThread]) {
         accumulate(k, r_cur);
-        load_batch(k + 5, r_cur);  // in flight during the tally below and the next accumulation
+        load_batch(k + 6, r_cur);  // in flight during the tally below and the next accumulation
         __builtin_amdgcn_sched_barrier(0);
-        tally(k + 4, r_tal);
+        tally(k + 5, r_tal);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();  // #(k+4)
+        __syncthreads();  // #(k+5)
     };
 
     load_batch(0, ring[0]);
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     load_batch(2, ring[2]);
     load_batch(3, ring[3]);
     load_batch(4, ring[4]);
+    load_batch(5, ring[5]);
     tally(0, ring[0]);
     __syncthreads();  // #0
     tally(1, ring[1]);
@@ -412,12 +417,15 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     __syncthreads();  // #2
     tally(3, ring[3]);
     __syncthreads();  // #3
+    tally(4, ring[4]);
+    __syncthreads();  // #4
     for (uint32_t k = 0; k < n_steps; k += D) {
-        step(k, ring[0], ring[4]);
+        step(k, ring[0], ring[5]);
         step(k + 1, ring[1], ring[0]);
         step(k + 2, ring[2], ring[1]);
         step(k + 3, ring[3], ring[2]);
         step(k + 4, ring[4], ring[3]);
+        step(k + 5, ring[5], ring[4]);
     }
     double *dst = a.part + (uint64_t)team * a.part_team_stride;
 #pragma unroll
