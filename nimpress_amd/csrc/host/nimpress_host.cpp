@@ -2234,4 +2234,57 @@ void nh_format_float(double x, char *out, long cap) {
     out[cap - 1] = 0;
 }
 
+// The samples x scores matrix of several score files, one line per sample: name TAB score 1 TAB score 2 ..., every
+// value as the reference prints a score (nimpress.nim:752-753: formatFloat).  scores = [n_scores][row_stride]
+// doubles, names_nl = the n sample names separated by '\n'.  Formatting millions of values is what a multi-file run
+// spends its time on once the genotypes are scored in one pass, so the lines are made by up to 16 threads and
+// written in order.  path "-" = stdout.  Returns 0, or -1 with the message in nh_last_error().
+long nh_write_matrix_tsv(const char *path, const char *names_nl, long n, const double *scores, long n_scores,
+                         long row_stride) {
+    try {
+        if (n < 0 || n_scores < 0 || row_stride < n) throw std::runtime_error("nh_write_matrix_tsv: bad shape");
+        std::vector<std::pair<const char *, size_t>> names((size_t)n);
+        const char *p = names_nl;
+        for (long i = 0; i < n; ++i) {
+            const char *q = strchr(p, '\n');
+            if (!q) q = p + strlen(p);
+            names[(size_t)i] = {p, (size_t)(q - p)};
+            p = *q ? q + 1 : q;
+        }
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const long n_thr = std::max<long>(1, std::min<long>({16, (long)hw, n / 2048 + 1}));
+        std::vector<std::string> parts((size_t)n_thr);
+        auto work = [&](long t) {
+            const long a = n * t / n_thr, b = n * (t + 1) / n_thr;
+            std::string &o = parts[(size_t)t];
+            o.reserve((size_t)(b - a) * (size_t)(16 + 24 * n_scores));
+            for (long i = a; i < b; ++i) {
+                o.append(names[(size_t)i].first, names[(size_t)i].second);
+                for (long k = 0; k < n_scores; ++k) {
+                    o.push_back('\t');
+                    o += formatFloat(scores[k * row_stride + i]);
+                }
+                o.push_back('\n');
+            }
+        };
+        std::vector<std::thread> thr;
+        for (long t = 1; t < n_thr; ++t) thr.emplace_back(work, t);
+        work(0);
+        for (auto &t : thr) t.join();
+        FILE *f = strcmp(path, "-") == 0 ? stdout : fopen(path, "w");
+        if (!f) throw std::runtime_error(std::string("cannot open ") + path + ": " + strerror(errno));
+        bool ok = true;
+        for (const std::string &o : parts) ok = ok && fwrite(o.data(), 1, o.size(), f) == o.size();
+        if (f == stdout)
+            ok = fflush(f) == 0 && ok;
+        else
+            ok = fclose(f) == 0 && ok;
+        if (!ok) throw std::runtime_error(std::string("write to ") + path + " failed: " + strerror(errno));
+        return 0;
+    } catch (const std::exception &e) {
+        g_nh_error = e.what();
+        return -1;
+    }
+}
+
 }  // extern "C"

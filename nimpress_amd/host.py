@@ -42,6 +42,8 @@ def load():
         L.nh_vcf_sample.argtypes = [C.c_void_p, C.c_long]
         L.nh_format_float.restype = None
         L.nh_format_float.argtypes = [C.c_double, C.c_char_p, C.c_long]
+        L.nh_write_matrix_tsv.restype = C.c_long
+        L.nh_write_matrix_tsv.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_long]
         _lib = L
     return _lib
 
@@ -98,6 +100,24 @@ def format_scores(x: np.ndarray) -> List[str]:
     plain = ~(np.char.find(out, ".") >= 0) & ~(np.char.find(out, "e") >= 0) & ~(np.char.find(out, "n") >= 0) & \
         ~(np.char.find(out, "i") >= 0)
     return np.where(plain, np.char.add(out, ".0"), out).tolist()
+
+
+def write_matrix_tsv(path: str, names: List[str], scores: np.ndarray) -> None:
+    """scores [n_scores, n_samples] -> one line per sample, `name TAB score 1 TAB score 2 ...`, every value in the
+    reference's float format (nimpress.nim:752-753); formatted by up to 16 threads of the host library
+    (nh_write_matrix_tsv).  path "-" writes to stdout."""
+    m = np.ascontiguousarray(scores, dtype=np.float64)
+    if m.ndim != 2 or m.shape[1] != len(names):
+        raise ValueError("scores must be [n_scores, %d]" % len(names))
+    if any("\n" in s for s in names):
+        raise ValueError("a sample name contains a newline")
+    if path == "-":
+        import sys
+        sys.stdout.flush()
+    rc = load().nh_write_matrix_tsv(path.encode(), "\n".join(names).encode(), len(names), m.ctypes.data, m.shape[0],
+                                    m.shape[1])
+    if rc != 0:
+        raise capi.NpsError(-1, load().nh_last_error().decode("utf-8", "replace"))
 
 
 def sample_names(vcf_path: str) -> List[str]:

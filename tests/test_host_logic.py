@@ -276,6 +276,38 @@ def test_host_float_format(host):
     assert buf.value == b"nan"
 
 
+def test_write_matrix_tsv_equals_the_reference_format(tmp_path):
+    """nh_write_matrix_tsv (threaded C++ writer of the samples x scores matrix, tools/score_many.py): every value
+    as the reference prints a score -- the 3 528 values of scores/*_nimpress_res.txt re-print identically -- plus
+    nan / inf / integers, with enough samples for several worker threads; equal to the per-value formatter."""
+    from nimpress_amd import host as H
+    vals = []
+    rf = os.path.join(G, "result_format")
+    for f in sorted(os.listdir(rf)):
+        vals += [line.split("\t")[1] for line in open(os.path.join(rf, f)).read().splitlines()]
+    assert len(vals) == 3528
+    rng = np.random.default_rng(5)
+    n = 3 * 3528
+    m = np.empty((3, n))
+    m[0] = np.tile(np.array([float(v) for v in vals]), 3)
+    m[1] = rng.normal(0, 1e-3, n)
+    m[2] = rng.integers(-5, 5, n).astype(np.float64)
+    m[1, 7], m[1, 8], m[1, 9], m[2, 0] = np.nan, np.inf, -np.inf, 1e22
+    names = ["S%05d" % i for i in range(n)]
+    out = tmp_path / "m.tsv"
+    H.write_matrix_tsv(str(out), names, m)
+    lines = out.read_text().split("\n")
+    assert lines[-1] == "" and len(lines) == n + 1
+    for j in (0, 1, 7, 8, 9, 3527, 3528, n - 1):
+        f = lines[j].split("\t")
+        assert f[0] == names[j] and f[1:] == [H.format_score(m[k, j]) for k in range(3)], (j, f)
+    assert [ln.split("\t")[1] for ln in lines[:3528]] == vals
+    cols = [H.format_scores(m[k]) for k in range(3)]
+    assert lines[:-1] == [names[j] + "\t" + "\t".join(c[j] for c in cols) for j in range(n)]
+    with pytest.raises(ValueError):
+        H.write_matrix_tsv(str(out), names[:-1], m)
+
+
 def test_cli_surface():
     if not os.path.exists(CLI):
         from nimpress_amd import build

@@ -85,14 +85,17 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    from nimpress_amd import capi, host, multi
+    import numpy as np
+    from nimpress_amd import capi, host
     capi.load()
     if capi.device_count() < 1:
         sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
-    device = torch.device("cuda", local_rank)
-    if world > 1:
+    torch = dist = multi = device = None
+    if world > 1:   # (one process, one GPU: no exchange, and torch's import is a fifth of such a run)
+        import torch
+        import torch.distributed as dist
+        from nimpress_amd import multi
+        device = torch.device("cuda", local_rank)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=device)
     score_files, cohort = args.files[:-1], args.files[-1]
@@ -100,16 +103,17 @@ def main(argv=None):
     n = len(names)
     logs = {}
 
-    def score_fn(i, out_row):
+    def score_file(i):
         s, nloci, log = host.compute_polygenic_scores(
             score_files[i], cohort, cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing,
             imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp,
             ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1))
         logs[i] = log
-        out_row.copy_(torch.from_numpy(s).to(out_row.device))
+        return s
 
     one_pass_used = False
     t0 = time.perf_counter()
+    cache = {}
     if args.one_pass:
         mine = list(range(rank, len(score_files), world))
         try:
@@ -121,23 +125,26 @@ def main(argv=None):
             for k, i in enumerate(mine):
                 logs[i] = lg[k]
             one_pass_used = True
-
-            def score_fn(i, out_row):  # noqa: F811  (the rows are there already)
-                out_row.copy_(torch.from_numpy(cache[i]).to(out_row.device))
         except capi.NpsError as e:
             sys.stderr.write("score_many: one-pass path not applicable (%s); scoring file by file\n" % e)
-    full = multi.evaluate_sharded(len(score_files), n, score_fn, device if world > 1 else torch.device("cpu"))
+
+    def row(i):  # scores of file i (from the one pass, if there was one)
+        return cache[i] if i in cache else score_file(i)
+
+    if world == 1:
+        mat = np.empty((len(score_files), n), dtype=np.float64)
+        for i in range(len(score_files)):
+            mat[i] = row(i)
+    else:
+        full = multi.evaluate_sharded(len(score_files), n,
+                                      lambda i, out_row: out_row.copy_(torch.from_numpy(row(i)).to(out_row.device)), device)
+        mat = full.cpu().numpy()
     elapsed = time.perf_counter() - t0
     for i in sorted(logs):
         for line in logs[i]:
             sys.stderr.write("[%s] %s\n" % (os.path.basename(score_files[i]), line))
     if rank == 0:
-        mat = full.cpu().numpy()
-        cols = [host.format_scores(mat[i]) for i in range(mat.shape[0])]   # the reference's float format, vectorised
-        out = sys.stdout if args.out == "-" else open(args.out, "w")
-        out.write("".join(name + "\t" + "\t".join(c[j] for c in cols) + "\n" for j, name in enumerate(names)))
-        if out is not sys.stdout:
-            out.close()
+        host.write_matrix_tsv(args.out, names, mat)   # the reference's float format, 16 threads in C++
         sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s%s\n"
                          % (len(score_files), n, world, elapsed, " (one pass over the genotypes)" if one_pass_used else ""))
     if world > 1:
