@@ -333,6 +333,8 @@ int nps_multi_finish_device(nps_multi *m, const double *offsets, double *d_score
  * context's rows, for the one exchange of that layout -- a sum all-reduce of both (RCCL).  The caller then applies
  * nimpress.nim:643-649: sums / (2 nloci) + offset (nimpress_amd/multi.py: normalize_matrix). */
 int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64_t *nloci_out);
+/* the same into host memory: sums_out[n_scores][n_samples] (a host caller that exchanges through its own transport) */
+int nps_multi_partial(nps_multi *m, double *sums_out, uint64_t *nloci_out);
 int nps_multi_reset(nps_multi *m, const nps_params *params /* NULL = keep */);
 void nps_multi_destroy(nps_multi *m);
 /* device time (HIP events) of the calls since the last reset: weight digits, the product, the fold */

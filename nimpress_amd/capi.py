@@ -61,7 +61,7 @@ SYMBOLS = [
     "nps_multidef_create", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
     "nps_cohort_convert", "nps_cohort_row_tallies", "nps_multi_set_missing_weight_bits",
-    "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device",
+    "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device", "nps_multi_partial",
 ]
 
 

@@ -1738,7 +1738,8 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                                  ImputeMethodLocus imputeMethodLocus, ImputeMethodMissing imputeMethodMissing,
                                  ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
                                  int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs, int device,
-                                 std::vector<uint64_t> *nloci_out) {
+                                 std::vector<uint64_t> *nloci_out, int shard, int n_shards, bool partial) {
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("computePolygenicScoresMulti: bad shard");
     const size_t S = scoreFiles.size();
     const int64_t nsamples = genotypeVcf.n_samples();
     scores.assign(S, std::vector<double>());
@@ -1775,7 +1776,10 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             }
             rows_of[s].push_back(it->second);
         }
-    const size_t U = pos.size();
+    // this call's block of the union's rows (all of them unless the rows are sharded over several GPUs): cohort row
+    // j - A for position j in [A, B); a file's rows outside the block are simply not part of this call's definitions
+    const size_t A = pos.size() * (size_t)shard / (size_t)n_shards, B = pos.size() * ((size_t)shard + 1) / (size_t)n_shards;
+    const size_t U = B - A;
 
     nps_cohort *gt2 = nullptr, *gt2m = nullptr;
     nps_multi *msc = nullptr;
@@ -1791,7 +1795,7 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
         // ---- locate every position once and decode its record into the resident cohort (nim:526-561)
         npsCheck(nps_cohort_create(&gt2, device, (uint64_t)nsamples, (uint64_t)U, NPS_FMT_GT2), "nps_cohort_create");
         std::vector<ScoreEntry> uent(U);
-        for (size_t j = 0; j < U; ++j) uent[j] = pos[j].e;
+        for (size_t j = 0; j < U; ++j) uent[j] = pos[A + j].e;
         size_t window = U;
         if (genotypeVcf.streaming) {
             const size_t per_row = (size_t)std::max<int64_t>(nsamples, 1) * 8;
@@ -1808,8 +1812,8 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                 fetched = genotypeVcf.fetch(uent.data() + w0, w1 - w0);
                 index.build(fetched);
             }
-            for (size_t j = w0; j < w1; ++j) {
-                Position &q = pos[j];
+            for (size_t j = w0; j < w1; ++j) {  // (cohort row j = position A + j)
+                Position &q = pos[A + j];
                 const ScoreEntry &e = q.e;
                 if (restrictToCoveredRgns && !isVariantCovered(e, coveredIvals, &q.pre_warning)) {
                     q.how = NPS_ROW_UNCOVERED;
@@ -1863,14 +1867,15 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             for (size_t s = 0; s < ns; ++s) {
                 const ScoreFile &sf = *scoreFiles[s0 + s];
                 for (size_t r = 0; r < sf.entries.size(); ++r) {
-                    const size_t j = rows_of[s0 + s][r];
+                    if (rows_of[s0 + s][r] < A || rows_of[s0 + s][r] >= B) continue;
+                    const size_t j = rows_of[s0 + s][r] - A;
                     nps_row_desc &d = descs[s * U + j];
                     if (d.kind != NPS_ROW_NOT_IN_SCORE)
                         throw std::runtime_error("a score file lists the same locus and alleles twice: not covered by "
                                                  "the one-pass multi-score path");
                     d.beta = sf.entries[r].beta;
                     d.eaf = sf.entries[r].eaf;
-                    d.kind = pos[j].how ? pos[j].how : NPS_ROW_PRESENT;
+                    d.kind = pos[A + j].how ? pos[A + j].how : NPS_ROW_PRESENT;
                     d.ref_is_effect = sf.entries[r].refseq == sf.entries[r].easeq ? 1 : 0;
                 }
             }
@@ -1880,7 +1885,10 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             std::vector<double> offs(ns), flat(ns * (size_t)std::max<int64_t>(nsamples, 1));
             std::vector<uint64_t> nl(ns, 0);
             for (size_t s = 0; s < ns; ++s) offs[s] = scoreFiles[s0 + s]->offset;
-            npsCheck(nps_multi_finish(msc, offs.data(), flat.data(), nl.data()), "nps_multi_finish");
+            if (partial)
+                npsCheck(nps_multi_partial(msc, flat.data(), nl.data()), "nps_multi_partial");
+            else
+                npsCheck(nps_multi_finish(msc, offs.data(), flat.data(), nl.data()), "nps_multi_finish");
             for (size_t s = 0; s < ns; ++s) {
                 scores[s0 + s].assign(flat.begin() + (ptrdiff_t)(s * (size_t)nsamples),
                                       flat.begin() + (ptrdiff_t)((s + 1) * (size_t)nsamples));
@@ -1897,9 +1905,10 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             Log &log = logs[s];
             const ScoreFile &sf = *scoreFiles[s];
             for (size_t r = 0; r < sf.entries.size(); ++r) {
+                if (rows_of[s][r] < A || rows_of[s][r] >= B) continue;
                 const ScoreEntry &e = sf.entries[r];
                 const Position &q = pos[rows_of[s][r]];
-                const size_t j = rows_of[s][r];
+                const size_t j = rows_of[s][r] - A;
                 const std::string locus = e.contig + ":" + std::to_string(e.pos);
                 const std::string var = locus + ":" + e.refseq + ":" + e.easeq;
                 if (!q.pre_warning.empty()) log.warn(q.pre_warning);
@@ -2169,10 +2178,10 @@ long nh_compute(const char *score_path, const char *vcf_path, const char *bed_pa
 // S score files on one genotype file in ONE pass over the genotypes (computePolygenicScoresMulti).  score_paths:
 // newline-separated.  scores_out: [S][n] doubles (cap = room per file); log lines come back prefixed "<file index>\t".
 // Returns the number of samples, < 0 on error.
-long nh_compute_multi(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
-                      int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
-                      int device, double *scores_out, long cap, unsigned long long *nloci_out, char *log_out,
-                      long log_cap) {
+static long nh_compute_multi_impl(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
+                                  int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
+                                  int device, int shard, int n_shards, bool partial, double *scores_out, long cap,
+                                  unsigned long long *nloci_out, double *offsets_out, char *log_out, long log_cap) {
     try {
         std::vector<std::string> paths = splitChar(score_paths, '\n');
         std::vector<ScoreFile> files(paths.size());
@@ -2185,9 +2194,12 @@ long nh_compute_multi(const char *score_paths, const char *vcf_path, const char 
             }
             ptrs.push_back(&files[i]);
             all.insert(all.end(), files[i].entries.begin(), files[i].entries.end());
+            if (offsets_out) offsets_out[i] = files[i].offset;
         }
         VCF vcf;
-        const bool stream = getenv("NIMPRESS_STREAM") != nullptr;
+        // (a shard of the rows reads only its own records: an indexed file is opened for window-by-window fetches,
+        // which computePolygenicScoresMulti asks for its block alone)
+        const bool stream = getenv("NIMPRESS_STREAM") != nullptr || n_shards > 1;
         if (!((stream && vcf.openStreaming(vcf_path)) || vcf.open(vcf_path, &all))) {
             g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
             return -1;
@@ -2202,7 +2214,7 @@ long nh_compute_multi(const char *score_paths, const char *vcf_path, const char 
         std::vector<uint64_t> nloci;
         computePolygenicScoresMulti(scores, ptrs, vcf, restrict, cov, (ImputeMethodLocus)imp_locus,
                                     (ImputeMethodMissing)imp_missing, (ImputeMethodSample)imp_sample, maxmis, afmisp, mincs,
-                                    ignorefilt != 0, logs, device, &nloci);
+                                    ignorefilt != 0, logs, device, &nloci, shard, n_shards, partial);
         for (size_t s = 0; s < scores.size(); ++s) {
             for (size_t i = 0; i < scores[s].size() && (long)i < cap; ++i) scores_out[s * (size_t)cap + i] = scores[s][i];
             if (nloci_out) nloci_out[s] = nloci[s];
@@ -2221,6 +2233,28 @@ long nh_compute_multi(const char *score_paths, const char *vcf_path, const char 
         g_nh_error = ex.what();
         return -2;
     }
+}
+
+long nh_compute_multi(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
+                      int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
+                      int device, double *scores_out, long cap, unsigned long long *nloci_out, char *log_out,
+                      long log_cap) {
+    return nh_compute_multi_impl(score_paths, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp,
+                                 mincs, ignorefilt, device, 0, 1, false, scores_out, cap, nloci_out, nullptr, log_out,
+                                 log_cap);
+}
+
+// Block `shard` of n_shards of the union's rows, ALL files, before the normalisation: sums_out [S][cap] un-normalised
+// sums, nloci_out [S] the block's counts, offsets_out [S] the files' offsets (computePolygenicScoresMulti with
+// partial = true: the rows-sharded x all-scores layout; the caller sum-all-reduces sums and nloci over the shards and
+// applies sums / (2 nloci) + offset).
+long nh_compute_multi_partial(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
+                              int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
+                              int device, int shard, int n_shards, double *sums_out, long cap,
+                              unsigned long long *nloci_out, double *offsets_out, char *log_out, long log_cap) {
+    return nh_compute_multi_impl(score_paths, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp,
+                                 mincs, ignorefilt, device, shard, n_shards, true, sums_out, cap, nloci_out, offsets_out,
+                                 log_out, log_cap);
 }
 
 double nh_dbinom(long x, long n, double p) { return dbinom(x, n, p); }

@@ -169,7 +169,14 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                                  ImputeMethodLocus imputeMethodLocus, ImputeMethodMissing imputeMethodMissing,
                                  ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
                                  int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs,
-                                 int device = 0, std::vector<uint64_t> *nloci_out = nullptr);
+                                 int device = 0, std::vector<uint64_t> *nloci_out = nullptr, int shard = 0,
+                                 int n_shards = 1, bool partial = false);
+// shard / n_shards / partial: the rows-sharded x all-scores layout over several GPUs.  The
+// union's rows are cut into n_shards contiguous blocks; this call locates, decodes and scores block `shard` only
+// (1 / n_shards of the ingest and of the cohort) for ALL files, and with partial = true returns the state of the
+// reference's loop BEFORE its normalisation -- scores[s] = the un-normalised sums, nloci_out[s] = the block's count
+// (nps_multi_partial) -- for the caller's sum all-reduce over the shards followed by sums / (2 nloci) + offset
+// (nim:643-649).  Warnings are those of the block's rows.
 
 // nim:652-757
 int cliMain(int argc, char **argv);

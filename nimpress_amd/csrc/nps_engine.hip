@@ -2140,6 +2140,12 @@ extern "C" int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64
     return multi_finish_common(m, nullptr, d_sums_out, nullptr, nloci_out, 0);
 }
 
+extern "C" int nps_multi_partial(nps_multi *m, double *sums_out, uint64_t *nloci_out) {
+    if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
+    if (m->n && !sums_out) return fail(NPS_E_INVAL, "sums_out is NULL");
+    return multi_finish_common(m, nullptr, m->d_scores, sums_out, nloci_out, 0);
+}
+
 extern "C" int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold) {
     if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(m->device));

@@ -31,6 +31,10 @@ def load():
         L.nh_compute_multi.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.c_double, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
                                        C.c_char_p, C.c_long]
+        L.nh_compute_multi_partial.restype = C.c_long
+        L.nh_compute_multi_partial.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                               C.c_double, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_long, C.c_void_p, C.c_void_p, C.c_char_p, C.c_long]
         L.nh_vcf_open.restype = C.c_void_p
         L.nh_vcf_open.argtypes = [C.c_char_p, C.c_char_p]
         L.nh_vcf_close.argtypes = [C.c_void_p]
@@ -91,6 +95,37 @@ def compute_polygenic_scores_multi(score_paths, vcf_path: str, cov: Optional[str
             k, _, text = l.partition("\t")
             logs[int(k)].append(text)
     return scores[:, :n].copy(), nloci.astype(np.int64), logs
+
+
+def compute_polygenic_scores_multi_partial(score_paths, vcf_path: str, shard: int, n_shards: int, cov: Optional[str] = None,
+                                           imp_locus: str = "ps", imp_missing: str = "homref",
+                                           imp_sample: str = "int_ps", maxmis: float = 0.05, mincs: int = 100,
+                                           afmisp: float = 0.001, ignorefilt: bool = False, device: int = 0,
+                                           max_samples: int = 1 << 22):
+    """Rows sharded over several GPUs x ALL score files on each: block `shard` of `n_shards` of
+    the union of the files' loci is located, decoded and scored on this GPU -- 1 / n_shards of the ingest and of the
+    cohort.  Returns (sums [files, samples] BEFORE the normalisation, nloci [files] of the block, offsets [files],
+    log lines per file for the block's rows); the caller sum-all-reduces sums and nloci over the shards
+    (multi.all_reduce_partial_matrix) and applies sums / (2 nloci) + offset (multi.normalize_matrix)."""
+    L = load()
+    S = len(score_paths)
+    sums = np.zeros((S, max_samples), dtype=np.float64)
+    nloci = np.zeros(S, dtype=np.uint64)
+    offsets = np.zeros(S, dtype=np.float64)
+    log = C.create_string_buffer(4 << 20)
+    n = L.nh_compute_multi_partial("\n".join(score_paths).encode(), vcf_path.encode(), cov.encode() if cov else None,
+                                   capi.LOCUS[imp_locus], capi.MISSING[imp_missing], capi.SAMPLE[imp_sample],
+                                   float(maxmis), float(afmisp), int(mincs), int(ignorefilt), device, int(shard),
+                                   int(n_shards), sums.ctypes.data, max_samples, nloci.ctypes.data, offsets.ctypes.data,
+                                   log, len(log))
+    if n < 0:
+        raise capi.NpsError(-3 if n == -2 else -1, L.nh_last_error().decode("utf-8", "replace"))
+    logs = [[] for _ in range(S)]
+    for l in log.value.decode().split("\n"):
+        if l:
+            k, _, text = l.partition("\t")
+            logs[int(k)].append(text)
+    return sums[:, :n].copy(), nloci.astype(np.int64), offsets, logs
 
 
 def format_scores(x: np.ndarray) -> List[str]:

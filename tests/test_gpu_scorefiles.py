@@ -171,3 +171,49 @@ def test_score_many_eight_files_on_500k_sample_bcf(tmp_path, one_pass):
         ok = ~np.isnan(ref)
         scale = 1e-12 + (np.max(np.abs(ref[ok])) if ok.any() else 0.0)
         assert np.max(np.abs(got[i][ok] - ref[ok]), initial=0.0) <= 1e-6 * scale, f
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_score_many_rows_sharded_over_ranks_all_files_per_rank(tmp_path, world):
+    """The rows-sharded x all-scores layout from FILES (tools/score_many.py --shard rows): every
+    rank locates, decodes and scores only its block of the union of the 8 files' loci -- for all 8 files, one
+    matrix-core pass -- and one sum all-reduce of the [files, samples] sums and of the per-file locus counts follows.
+    Three ranks share this box's one GPU here (exchange over gloo on CPU tensors; on a node it is RCCL, one GPU per
+    rank); the matrix is checked against the oracle's own driver for every file and sample, the warnings against
+    the single-rank run."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config2
+    n = 30_000
+    files = SCORES
+    path, samples, recs = config2.write_union_cohort(tmp_path, files, n)
+    out = str(tmp_path / "matrix.tsv")
+    env = dict(os.environ, NIMPRESS_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", str(world), "--shard", "rows",
+                        "--out", out] + files + [path], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "rows sharded over the GPUs" in r.stderr, r.stderr[-500:]
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert [x[0] for x in rows] == samples
+    got = np.array([[float(v) for v in x[1:]] for x in rows]).T
+    assert got.shape == (8, n)
+    vcf = refcpu.Vcf(samples=samples, records=[
+        refcpu.VcfRecord(contig=q["contig"], pos=q["pos"], ref=q["ref"], alts=q["alts"],
+                         filt=";".join(q["filters"]) if q["filters"] else ".",
+                         gts=q["gts"].reshape(-1), ploidy=2) for q in recs])
+    for i, f in enumerate(files):
+        ref, nloci, stats = oracle_run(f, vcf)
+        assert np.array_equal(np.isnan(got[i]), np.isnan(ref)), f
+        ok = ~np.isnan(ref)
+        scale = 1e-12 + (np.max(np.abs(ref[ok])) if ok.any() else 0.0)
+        assert np.max(np.abs(got[i][ok] - ref[ok]), initial=0.0) <= 1e-6 * scale, f
+    # the warnings (default --afmisp): the same set as the one-pass run of a single process
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1", "--one-pass",
+                         "--out", str(tmp_path / "m1.tsv")] + files + [path], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+
+    def warnings(text):
+        return sorted(l for l in text.splitlines() if l.startswith("[") and "] WARN " in l)
+    assert warnings(r.stderr) == warnings(r1.stderr)
+    assert len(warnings(r.stderr)) > 0

@@ -30,6 +30,12 @@ def parse_args(argv=None):
                     help="this rank's score files in ONE pass over the genotypes: the union of their loci is decoded once "
                          "into a resident cohort and the definitions are applied together on the matrix cores (falls back "
                          "to the per-file loop for inputs that path does not cover, e.g. FORMAT/DS records)")
+    ap.add_argument("--shard", choices=["files", "rows"], default="files",
+                    help="what the GPUs split.  files: each GPU takes every N-th score file (the whole cohort file is read "
+                         "by every GPU).  rows: each GPU takes 1/N of the ROWS of the union of the files' loci and scores "
+                         "ALL files on it in one matrix-core pass -- 1/N of the ingest and of the cohort per GPU -- and one "
+                         "sum all-reduce of the [files, samples] sums and the per-file locus counts follows (implies "
+                         "--one-pass; inputs that path does not cover are an error)")
     ap.add_argument("--out", default="-", help="output TSV (default: stdout)")
     ap.add_argument("--cov", default=None)
     ap.add_argument("--imp-locus", default="ps", choices=["ps", "homref", "fail", "ignore"])
@@ -91,13 +97,20 @@ def main(argv=None):
     if capi.device_count() < 1:
         sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
     torch = dist = multi = device = None
+    # (ranks that share a GPU exist only in tests: NIMPRESS_DIST_BACKEND=gloo, the exchange on CPU tensors)
+    backend = os.environ.get("NIMPRESS_DIST_BACKEND", "nccl")
+    local_rank %= capi.device_count()
     if world > 1:   # (one process, one GPU: no exchange, and torch's import is a fifth of such a run)
         import torch
         import torch.distributed as dist
         from nimpress_amd import multi
-        device = torch.device("cuda", local_rank)
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            device = torch.device("cpu")
+            dist.init_process_group(backend)
     score_files, cohort = args.files[:-1], args.files[-1]
     names = host.sample_names(cohort)
     n = len(names)
@@ -114,7 +127,23 @@ def main(argv=None):
     one_pass_used = False
     t0 = time.perf_counter()
     cache = {}
-    if args.one_pass:
+    mat = None
+    if args.shard == "rows":
+        # rows sharded over the GPUs x all files on every GPU: one partial pass, one all-reduce, the normalisation
+        sums, nl, offs, lg = host.compute_polygenic_scores_multi_partial(
+            score_files, cohort, rank, world, cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing,
+            imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp,
+            ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1))
+        for i, lines in enumerate(lg):
+            logs[i] = lines
+        one_pass_used = True
+        if world > 1:
+            t, cnt = multi.all_reduce_partial_matrix(torch.from_numpy(sums).to(device), nl)
+            mat = multi.normalize_matrix(t, cnt, offs).cpu().numpy()
+        else:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mat = sums / (nl.astype(np.float64) * 2.0)[:, None] + offs[:, None]
+    elif args.one_pass:
         mine = list(range(rank, len(score_files), world))
         try:
             sc, _nl, lg = host.compute_polygenic_scores_multi(
@@ -131,7 +160,9 @@ def main(argv=None):
     def row(i):  # scores of file i (from the one pass, if there was one)
         return cache[i] if i in cache else score_file(i)
 
-    if world == 1:
+    if mat is not None:
+        pass
+    elif world == 1:
         mat = np.empty((len(score_files), n), dtype=np.float64)
         for i in range(len(score_files)):
             mat[i] = row(i)
@@ -146,7 +177,9 @@ def main(argv=None):
     if rank == 0:
         host.write_matrix_tsv(args.out, names, mat)   # the reference's float format, 16 threads in C++
         sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s%s\n"
-                         % (len(score_files), n, world, elapsed, " (one pass over the genotypes)" if one_pass_used else ""))
+                         % (len(score_files), n, world, elapsed,
+                            " (rows sharded over the GPUs, all files per GPU in one pass)" if args.shard == "rows" else
+                            " (one pass over the genotypes)" if one_pass_used else ""))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
