@@ -226,7 +226,11 @@ void nps_destroy(nps_ctx *ctx);
  * NPS_MODE_AUTO or NPS_MODE_FUSED) with results identical in meaning to the NPS_FMT_GT2 kernels: tallies, nloci
  * and decisions bit-exact, scores equal up to the quantisation of the row weights (2^-56 of the largest one: the size
  * of float64 rounding of the terms themselves).  The kernel's time does
- * not depend on the genotypes.  Needs ceil(n_samples / 2048) <= compute units of the device. */
+ * not depend on the genotypes.  Any cohort size (the reference scores any N, nimpress.nim:626-628): with
+ * P = ceil(n_samples / 2048) strips, P <= compute units (N <= 522 240 on an MI355X) is ONE read of the matrix --
+ * floor(CUs / P) row teams per strip fill the chip for small cohorts; more strips than that (or NPS_MODE_TWOPASS)
+ * are scored in two reads (a tally pass, then the same accumulation with the tallies given); NPS_MODE_FUSED
+ * insists on the single read and returns NPS_E_UNSUPPORTED where it cannot be had. */
 #define NPS_FMT_GT2X 3
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,

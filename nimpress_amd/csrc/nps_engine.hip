@@ -159,7 +159,7 @@ struct nps_ctx {
     double *d_mx_const = nullptr;           // ... and the locus constants of rows over --maxmis (zero between passes)
     unsigned long long *d_mx_tally1 = nullptr;  // first-stage tally words (groups of 16 strips), zero between passes
     uint64_t mx_tally1_cap = 0;
-    bool mx_plan_valid = false;
+    bool mx_plan_valid = false, mx_plan_two_pass = false;
     uint64_t mx_plan_m = 0;
     MxPlan mx_plan_cache{};
     bool rtally_clean = false;              // d_rtally is all zero (allocation, or the last fused epilogue)
@@ -1475,25 +1475,30 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     const bool is_mx = co->format == NPS_FMT_GT2X;
     if (is_mx && (cohort_row0 & 127))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 128 for NPS_FMT_GT2X cohorts");
-    if (is_mx && mode == NPS_MODE_TWOPASS)
-        return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2X cohorts are scored by the single-read kernel only");
     if (!is_ds && (cohort_row0 & 3))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
     if (is_mx && m && c->n) {
-        if (c->mx_plan_valid && c->mx_plan_m == m) {
+        const bool two_pass = mode == NPS_MODE_TWOPASS;
+        if (c->mx_plan_valid && c->mx_plan_m == m && c->mx_plan_two_pass == two_pass) {
             mxp = c->mx_plan_cache;
         } else {
-            HIP_TRY(mx_plan(c->device, c->n, m, &mxp));
+            HIP_TRY(mx_plan(c->device, c->n, m, two_pass, &mxp));
             c->mx_plan_cache = mxp;
             c->mx_plan_m = m;
+            c->mx_plan_two_pass = two_pass;
             c->mx_plan_valid = true;
         }
         if (!mxp.ok)
+            return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) is beyond the NPS_FMT_GT2X kernels (2^27 samples)",
+                        (unsigned long long)c->n, (unsigned long long)m);
+        // more strips than compute units: the single-read kernel cannot hold the grid resident; AUTO takes the
+        // tally + accumulate pair (two reads), an explicit NPS_MODE_FUSED is refused
+        if (mxp.given && mode == NPS_MODE_FUSED)
             return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the persistent grid of the "
-                        "NPS_FMT_GT2X kernel (one 2048-sample strip per compute unit)", (unsigned long long)c->n,
-                        (unsigned long long)m);
+                        "single-read NPS_FMT_GT2X kernel (one 2048-sample strip per compute unit); NPS_MODE_AUTO "
+                        "scores it in two reads", (unsigned long long)c->n, (unsigned long long)m);
     }
     FusedPlan plan;
     if (!is_mx && mode != NPS_MODE_TWOPASS && m && c->n) {
@@ -1631,9 +1636,14 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         rc = tally_ready();
         if (rc) return rc;
+        if (mxp.given) {
+            ProfScope ps(c, P_TALLY);
+            HIP_TRY(launch_mx_tally(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n,
+                                    c->d_rtally));
+        }
         hipError_t fe;
         {
-            ProfScope ps(c, P_FUSED);
+            ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
             fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                  def->d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally, c->d_mx_tally1, c->d_rstats,
                                  c->d_nloci,
@@ -1641,7 +1651,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         if (fe != hipSuccess) {
             (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
-            c->rtally_clean = true;
+            c->rtally_clean = !mxp.given;
             return fail(NPS_E_HIP, "NPS_FMT_GT2X kernel launch failed: %s", hipGetErrorString(fe));
         }
         guard.armed = true;
@@ -2183,10 +2193,11 @@ extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint3
     HIP_TRY(hipSetDevice(c->device));
     if (format == NPS_FMT_GT2X) {
         MxPlan mp;
-        HIP_TRY(mx_plan(c->device, c->n, n_rows, &mp));
-        if (slices) *slices = mp.ok ? mp.P : 0;
-        if (teams) *teams = mp.ok ? 1 : 0;
-        if (samples_per_slice) *samples_per_slice = mp.ok ? 2048 : 0;
+        HIP_TRY(mx_plan(c->device, c->n, n_rows, false, &mp));
+        const bool single_read = mp.ok && !mp.given;  // (a shape with more strips than compute units is scored in two reads)
+        if (slices) *slices = single_read ? mp.P : 0;
+        if (teams) *teams = single_read ? mp.Q : 0;
+        if (samples_per_slice) *samples_per_slice = single_read ? 2048 : 0;
         return NPS_OK;
     }
     FusedPlan plan;

@@ -265,10 +265,13 @@ static __host__ __device__ inline uint64_t gt2x_unit_index(uint64_t unit, uint64
 }
 struct MxPlan {
     bool ok = false;
-    uint32_t P = 0, nu_last = 0, n_sb = 0, n_flush = 0;
+    bool given = false;  // the shape does not fit one cooperative grid (more strips than compute units): the row
+                         // tallies come from launch_mx_tally, the accumulation runs as an ordinary grid (two reads)
+    uint32_t P = 0, Q = 0, nu_last = 0, n_sb = 0, n_flush = 0;  // strips, row teams per strip (superblock k belongs to team k % Q)
     uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
 };
-hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan);
+// two_pass: plan the tally + accumulate pair whatever the shape (NPS_MODE_TWOPASS)
+hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pass, MxPlan *plan);
 // d_tally: [n_sb*128] zeroed; d_tally1: [ceil(P/16)][n_sb*128] zeroed (both are zero again after launch_mx_fold); d_cpart: [plan.cpart_floats]; d_const_sum: one double, zero on entry; d_pre: 32 bytes
 // per row (scratch, written by the pass's first launch);
 // t_maxmis: largest nmissing with !((double)nmissing / (double)N > --maxmis); F: fixed-point scale 2^F with
@@ -278,6 +281,9 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                            int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
                            unsigned long long *d_tally1, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout);
+// plan.given only: the whole-row tallies of the run's rows into d_tally (zero on entry), one read of the matrix
+hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                           uint64_t n_samples, unsigned long long *d_tally);
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,

@@ -59,17 +59,18 @@ struct MxArgs {
     uint64_t n_rows;         // rows of this run
     uint64_t n_samples;
     uint32_t P, nu_last;     // strips, units of the last one
+    uint32_t Q;              // row teams per strip: superblock k of the run belongs to team k % Q (grid = Q * P workgroups)
     const nps_row_desc *desc;
     const MxPre *pre;        // per score row, from mx_prep_kernel: what does not depend on the tallies
     DevParams prm;
     int64_t t_maxmis;        // the largest nmissing for which nmissing / N > --maxmis is false (-1: none)
     double scale;            // 2^F
-    unsigned long long *tally;  // [n_sb * 128], zero on entry
+    unsigned long long *tally;  // [n_sb * 128], zero on entry (GIVEN: the complete whole-row tallies, from mx_tally_kernel)
     unsigned long long *tally1;  // [groups of 16 strips][n_sb * 128], zero on entry: first stage of the hand-over
     nps_locus_stat *stats;
     unsigned long long *nloci;
     double *const_sum;       // += the locus constants of rows over --maxmis (added to every sample by mx_fold_kernel)
-    float *cpart;            // [n_flush][P][64][2][256]
+    float *cpart;            // [n_flush][Q][P][64][2][256]
     unsigned int *timeout;
 };
 
@@ -225,11 +226,19 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // hold nothing of it)
 // DBG (diagnostics builds only): 1 no tally popcounts, 2 no accumulation, 4 no hand-over (no atomics, no wait),
 // 8 no weight digits (zero tables), 16 no parking
-template <int NU, bool GUARD, bool CTL, int DBG>
+// GIVEN: a.tally holds the complete tallies (mx_tally_kernel ran before): no popcounts, no hand-over, no waiting --
+// the workgroups are independent of each other and the grid need not be resident as a whole
+//
+// Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
+// (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
+// between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
-    const uint32_t strip = blockIdx.x;
+    const uint32_t strip = blockIdx.x % a.P, team = blockIdx.x / a.P;
+    const uint32_t n_t = team < a.n_sb ? (a.n_sb - team + a.Q - 1) / a.Q : 0u;  // superblocks of this team
+    if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
     const int u0 = wave < 6 ? wave * kUD : 6 * kUD + (wave - 6) * kUC;
@@ -241,8 +250,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     const int woff = mx_rowoff(2 * lane);
     const int r1off = mx_rowoff(32 * g + q), r2off = mx_rowoff(32 * g + 16 + q);
     const int fr0 = (32 * g + q) * 16, fr1 = (32 * g + 16 + q) * 16;
-    const v4u *const base = a.units + ((uint64_t)strip * 64 * a.n_sb_cohort + (uint64_t)a.sb0 * nu + u0) * 64 + lane;
-    const uint64_t sb_stride = (uint64_t)nu * 64;
+    const v4u *const base =
+        a.units + ((uint64_t)strip * 64 * a.n_sb_cohort + (uint64_t)(a.sb0 + team) * nu + u0) * 64 + lane;
+    const uint64_t sb_stride = (uint64_t)nu * 64 * a.Q;  // from one superblock of the team to its next
 
     v4f C[NU][2];
 #pragma unroll
@@ -257,7 +267,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         return __builtin_nontemporal_load(base + (uint64_t)k * sb_stride + u * 64);
     };
     auto load_sb = [&](uint32_t k, v4u(&dst)[NU]) {
-        if (k >= a.n_sb) return;
+        if (k >= n_t) return;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
             if (full || u < n_my) dst[u] = load_unit(k, u);
@@ -270,7 +280,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         uint32_t xa = 0, ya = 0, za = 0, xb = 0, yb = 0, zb = 0;
     };
     auto tally_unit = [&](Tal &t, const v4u w) {
-        if (DBG & 1) return;
+        if ((DBG & 1) || GIVEN) return;
         const uint32_t sx = w.x >> 1, sy = w.y >> 1, sz = w.z >> 1, sw = w.w >> 1;
         t.xa = bcnt_acc(w.y, bcnt_acc(w.x, t.xa));
         t.ya = bcnt_acc((w.x & 0xAAAAAAAAu) | (sy & 0x55555555u), t.ya);
@@ -280,6 +290,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         t.zb = bcnt_acc((w.z & sz & 0x55555555u) | ((w.w & sw & 0x55555555u) << 1), t.zb);
     };
     auto tally_add = [&](uint32_t kt, const Tal &t) {
+        if (GIVEN) return;
         const unsigned long long pa = (t.xa + t.ya - 3u * t.za) | (t.za << 16), pb = (t.xb + t.yb - 3u * t.zb) | (t.zb << 16);
         unsigned long long *T = reinterpret_cast<unsigned long long *>(smem + kLdsTally) + (kt & 1) * 64 + lane;
         atomicAdd(T, pa | (pb << 32));  // the 16-bit fields of a word never carry: a strip has 2048 samples
@@ -289,7 +300,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     auto front = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park) {
         if (n_my == 0) return;
         Tal t;
-        if (k + 3 < a.n_sb) {  // steady state: no per-unit conditions
+        if (k + 3 < n_t) {  // steady state: no per-unit conditions
 #pragma unroll
             for (int u = 0; u < NU; ++u)
                 if (full || u < n_my) {
@@ -299,7 +310,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 }
             tally_add(k + 2, t);
         } else {
-            const bool do_t = k + 2 < a.n_sb, do_p = k + 1 < a.n_sb;
+            const bool do_t = k + 2 < n_t, do_p = k + 1 < n_t;
 #pragma unroll
             for (int u = 0; u < NU; ++u)
                 if (full || u < n_my) {
@@ -312,7 +323,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 
     // scores += code * Wc + is_missing * Wm for the wave's units of superblock k (parked in `slot`)
     auto accumulate = [&](uint32_t k, const char *slot) {
-        if (k >= a.n_sb || n_my == 0 || (DBG & 2)) return;
+        if (k >= n_t || n_my == 0 || (DBG & 2)) return;
         const char *tab = smem + kLdsTables + (k & 1) * 6144;
         v8i Bc, Bme, Bmo;
         {
@@ -347,7 +358,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     };
 
     auto store_c = [&](uint32_t f, bool zero) {
-        float *dst = a.cpart + ((((uint64_t)f * a.P + strip) * 64 + u0) * 2) * 256 + lane * 4;
+        float *dst = a.cpart + (((((uint64_t)f * a.Q + team) * a.P + strip) * 64 + u0) * 2) * 256 + lane * 4;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (full || u < n_my) {
@@ -366,8 +377,8 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     npre.c[0] = npre.c[1] = npre.c[2] = npre.flags = 0u;
     npre.w1 = npre.wfb = 0;
     auto ctl_fetch_pre = [&](uint32_t k) {  // the row's precomputed part, a step before it is needed
-        const uint64_t row = (uint64_t)k * 128 + crow;
-        if (k < a.n_sb && row < a.n_rows) {
+        const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
+        if (k < n_t && row < a.n_rows) {
             const v4u *p = reinterpret_cast<const v4u *>(a.pre + row);
             const v4u p0 = p[0], p1 = p[1];
             npre.c[0] = p0.x;
@@ -380,13 +391,15 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     };
     // the tally words of superblock k were published by every strip more than a step ago: normally one poll
     auto ctl_tables = [&](uint32_t k) {
-        if (k >= a.n_sb) return;
-        const uint64_t row = (uint64_t)k * 128 + crow;
+        if (k >= n_t) return;
+        const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
         const bool valid = row < a.n_rows;
-        unsigned long long x = valid ? __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        bool ok = !valid || (uint32_t)(x >> 56) == a.P || (DBG & 4);
+        unsigned long long x = !valid  ? 0ull
+                               : GIVEN ? a.tally[row]
+                                       : __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
         uint32_t spins = 0;
-        while (!__all(ok) && !timed_out) {
+        while (!GIVEN && !__all(ok) && !timed_out) {
             __builtin_amdgcn_s_sleep(1);
             if (!ok) {
                 x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -403,7 +416,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         uint32_t wc[3], wme[3], wmo[3];
         int used;
         double cst;
-        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);
+        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
         char *p = smem + kLdsTables + (k & 1) * 6144 + crow * 16;
         *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
         *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
@@ -420,11 +433,12 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     unsigned long long pub_old = 0ull, pub_add = 0ull;
     bool pub_live = false;
     auto ctl_publish_begin = [&](uint32_t kp) {
+        if (GIVEN) return;
         uint32_t *T = reinterpret_cast<uint32_t *>(smem + kLdsTally) + (kp & 1) * 128;
         const uint32_t v = T[crow];
         T[crow] = 0u;
-        const uint64_t row = (uint64_t)kp * 128 + crow;
-        pub_live = kp < a.n_sb && row < a.n_rows && !(DBG & 4);
+        const uint64_t row = ((uint64_t)team + (uint64_t)kp * a.Q) * 128 + crow;
+        pub_live = kp < n_t && row < a.n_rows && !(DBG & 4);
         if (pub_live) {
             pub_add = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
             pub_old = __hip_atomic_fetch_add(&a.tally1[(uint64_t)grp * a.n_sb * 128 + row], pub_add, __ATOMIC_RELAXED,
@@ -435,7 +449,8 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         if (pub_live) {
             const unsigned long long tot = pub_old + pub_add;
             if ((uint32_t)(tot >> 56) == grp_size)
-                __hip_atomic_fetch_add(&a.tally[(uint64_t)kp * 128 + crow], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&a.tally[((uint64_t)team + (uint64_t)kp * a.Q) * 128 + crow], tot, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
@@ -445,7 +460,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     load_sb(1, bank[1]);
     if (is_ctl) ctl_fetch_pre(0);
     __syncthreads();
-    if (n_my != 0 && a.n_sb > 0) {
+    if (n_my != 0) {
         Tal t;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
@@ -457,18 +472,16 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         ctl_publish_begin(0);
         ctl_publish_end(0);
     }
-    if (n_my != 0 && a.n_sb > 1) {
+    if (n_my != 0 && n_t > 1) {
         Tal t;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
             if (full || u < n_my) tally_unit(t, bank[1][u]);
         tally_add(1, t);
     }
-    if (a.n_sb > 0) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
-            if (full || u < n_my) *reinterpret_cast<v4u *>(slot0 + u * 1024 + woff) = bank[0][u];
-    }
+    for (int u = 0; u < NU; ++u)
+        if (full || u < n_my) *reinterpret_cast<v4u *>(slot0 + u * 1024 + woff) = bank[0][u];
     load_sb(2, bank[0]);
     __syncthreads();
     if (is_ctl) {
@@ -487,14 +500,14 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         }
         accumulate(k, s_acc);
         if (is_ctl) ctl_publish_end(k + 2);
-        if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < a.n_sb) store_c(k / kFlushSb, true);
+        if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
     };
-    const uint32_t n_steps = (a.n_sb + 1) / 2 * 2;
+    const uint32_t n_steps = (n_t + 1) / 2 * 2;
     for (uint32_t k = 0; k < n_steps; k += 2) {
         step(k + 0, bank[0], bank[1], slot1, slot0);
         step(k + 1, bank[1], bank[0], slot0, slot1);
     }
-    store_c((a.n_sb - 1) / kFlushSb, false);
+    store_c((n_t - 1) / kFlushSb, false);
     if (is_ctl && strip == 0) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
@@ -505,23 +518,23 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-template <int DBG>
+template <int DBG, bool GIVEN>
 __global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
-    const int nu = blockIdx.x == a.P - 1 ? (int)a.nu_last : 64;
+    const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
     if (wave >= 6)
-        mx_body<kUC, true, true, DBG>(a, smem);
+        mx_body<kUC, true, true, DBG, GIVEN>(a, smem);
     else if (nu - wave * kUD >= kUD)
-        mx_body<kUD, false, false, DBG>(a, smem);
+        mx_body<kUD, false, false, DBG, GIVEN>(a, smem);
     else
-        mx_body<kUD, true, false, DBG>(a, smem);
+        mx_body<kUD, true, false, DBG, GIVEN>(a, smem);
 }
 
 // Epilogue of a pass: the sixteen digit sums of a sample -> float64, plus the pass's locus constants, into chunk 0
 // of the context's partial scores; the tally words go back to zero; a raised bounded-wait word is recorded.
-__global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_flush, uint32_t P,
+__global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_sb, uint32_t Q, uint32_t P,
                                                       uint64_t n, double inv_scale, const double *__restrict__ const_sum,
                                                       double *__restrict__ part0, int overwrite,
                                                       unsigned long long *__restrict__ tally, uint64_t n_tally,
@@ -542,17 +555,56 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
     const uint32_t e = s & 1u, ii = s >> 1;
     double total = 0.0;
     bool isnan_ = false;
-    for (uint32_t f = 0; f < n_flush; ++f) {
-        const float *t = cpart + ((((uint64_t)f * P + strip) * 64 + unit) * 2 + e) * 256 + ((ii >> 2) * 16) * 4 + (ii & 3);
-        double v = (double)t[13 * 4];
+    for (uint32_t tm = 0; tm < Q && tm < n_sb; ++tm) {  // fixed order: teams, then flushes
+        const uint32_t n_flush = ((n_sb - tm + Q - 1) / Q + kFlushSb - 1) / kFlushSb;
+        for (uint32_t f = 0; f < n_flush; ++f) {
+            const float *t =
+                cpart + (((((uint64_t)f * Q + tm) * P + strip) * 64 + unit) * 2 + e) * 256 + ((ii >> 2) * 16) * 4 + (ii & 3);
+            double v = (double)t[13 * 4];
 #pragma unroll
-        for (int d = 12; d >= 0; --d) v = v * 16.0 + (double)t[d * 4];
-        total += v;
-        isnan_ = isnan_ || t[15 * 4] != 0.f;
+            for (int d = 12; d >= 0; --d) v = v * 16.0 + (double)t[d * 4];
+            total += v;
+            isnan_ = isnan_ || t[15 * 4] != 0.f;
+        }
     }
     double r = total * inv_scale + *const_sum;
     if (isnan_) r = __longlong_as_double(0x7ff8000000000000ll);
     part0[i] = overwrite ? r : part0[i] + r;
+}
+
+// Whole-row tallies of a run whose strips do not fit one cooperative grid (plan.given): one workgroup = one
+// superblock x a group of 16 strips (1 MiB, read once); a lane holds rows 2 lane, 2 lane + 1 of every unit its wave
+// reads, exactly as in the fused kernel; the four waves meet in LDS and the workgroup adds one word per row.
+__global__ __launch_bounds__(256) void mx_tally_kernel(const v4u *__restrict__ units, uint64_t n_sb_cohort, uint32_t sb0,
+                                                       uint32_t P, uint32_t nu_last, unsigned long long *__restrict__ tally) {
+    __shared__ uint32_t s_eff[128], s_mis[128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t sb = blockIdx.x, grp = blockIdx.y;
+    if (tid < 128) s_eff[tid] = s_mis[tid] = 0u;
+    __syncthreads();
+    uint32_t xa = 0, ya = 0, za = 0, xb = 0, yb = 0, zb = 0;
+    const uint32_t s_end = min(P, grp * 16 + 16);
+    for (uint32_t strip = grp * 16; strip < s_end; ++strip) {
+        const uint32_t nu = strip == P - 1 ? nu_last : 64u;
+        const v4u *base = units + ((uint64_t)strip * 64 * n_sb_cohort + (uint64_t)(sb0 + sb) * nu) * 64 + lane;
+        for (uint32_t u = wave; u < nu; u += 4) {
+            const v4u w = __builtin_nontemporal_load(base + (uint64_t)u * 64);
+            const uint32_t sx = w.x >> 1, sy = w.y >> 1, sz = w.z >> 1, sw = w.w >> 1;
+            xa = bcnt_acc(w.y, bcnt_acc(w.x, xa));
+            ya = bcnt_acc((w.x & 0xAAAAAAAAu) | (sy & 0x55555555u), ya);
+            za = bcnt_acc((w.x & sx & 0x55555555u) | ((w.y & sy & 0x55555555u) << 1), za);
+            xb = bcnt_acc(w.w, bcnt_acc(w.z, xb));
+            yb = bcnt_acc((w.z & 0xAAAAAAAAu) | (sw & 0x55555555u), yb);
+            zb = bcnt_acc((w.z & sz & 0x55555555u) | ((w.w & sw & 0x55555555u) << 1), zb);
+        }
+    }
+    atomicAdd(&s_eff[2 * lane], xa + ya - 3u * za);
+    atomicAdd(&s_mis[2 * lane], za);
+    atomicAdd(&s_eff[2 * lane + 1], xb + yb - 3u * zb);
+    atomicAdd(&s_mis[2 * lane + 1], zb);
+    __syncthreads();
+    if (tid < 128)
+        atomicAdd(&tally[(uint64_t)sb * 128 + tid], ((unsigned long long)s_mis[tid] << 28) | (unsigned long long)s_eff[tid]);
 }
 
 // ---- packing: generator, plain rows <-> units -------------------------------------------------------------
@@ -712,7 +764,7 @@ hipError_t launch_gt2_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t st
     return hipGetLastError();
 }
 
-hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan) {
+hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pass, MxPlan *plan) {
     *plan = MxPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;
     static int cus_cached[64] = {0};
@@ -725,14 +777,36 @@ hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, MxPlan *plan
         if (device >= 0 && device < 64) cus_cached[device] = cus;
     }
     const MxGeom gm = mx_geom(n_samples, n_rows);
-    if (gm.P > (uint32_t)cus || gm.P > 255 || gm.n_sb > 0x1fffffffull) return hipSuccess;  // 8-bit arrival count
+    if (gm.n_sb > 0x1fffffffull || gm.P > 65535u) return hipSuccess;
     plan->P = gm.P;
     plan->nu_last = gm.nu_last;
     plan->n_sb = (uint32_t)gm.n_sb;
-    plan->n_flush = (uint32_t)((gm.n_sb + kFlushSb - 1) / kFlushSb);
-    plan->cpart_floats = (uint64_t)plan->n_flush * gm.P * 64 * 2 * 256;
+    // One strip per compute unit, the whole grid resident (8-bit arrival count): the single-read kernel.  Fewer strips
+    // than compute units: Q row teams per strip fill the chip (superblock k belongs to team k % Q).  More strips than
+    // compute units (N > 2048 x CUs): the tallies come from their own pass and the accumulation runs as an ordinary
+    // grid of P x Q independent workgroups, about four per compute unit for an even tail.
+    plan->given = two_pass || gm.P > (uint32_t)cus || gm.P > 255;
+    uint64_t q = plan->given ? std::max<uint64_t>(1, ((uint64_t)4 * cus + gm.P - 1) / gm.P) : (uint64_t)cus / gm.P;
+    q = std::max<uint64_t>(1, std::min<uint64_t>(q, gm.n_sb));
+    plan->Q = (uint32_t)q;
+    const uint64_t n_t = (gm.n_sb + q - 1) / q;  // superblocks of the longest team
+    plan->n_flush = (uint32_t)((n_t + kFlushSb - 1) / kFlushSb);
+    plan->cpart_floats = (uint64_t)plan->n_flush * q * gm.P * 64 * 2 * 256;
     plan->ok = true;
     return hipSuccess;
+}
+
+hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                           uint64_t n_samples, unsigned long long *d_tally) {
+    (void)n_samples;
+    (void)hipGetLastError();
+    const uint32_t groups = (plan.P + 15) / 16;
+    for (uint32_t s = 0; s < plan.n_sb; s += 1u << 30) {  // (grid.x holds 2^31 - 1 blocks)
+        const uint32_t k = std::min<uint32_t>(1u << 30, plan.n_sb - s);
+        hipLaunchKernelGGL(mx_tally_kernel, dim3(k, groups), dim3(256), 0, st, (const v4u *)d_units, n_sb_cohort,
+                           (uint32_t)sb0 + s, plan.P, plan.nu_last, d_tally + (uint64_t)s * 128);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
@@ -747,26 +821,23 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
     }
-    const void *fn = (const void *)fused_mx_kernel<0>;
+    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true> : (const void *)fused_mx_kernel<0, false>;
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
-    switch (dbg) {
-    case 1: fn = (const void *)fused_mx_kernel<1>; break;
-    case 2: fn = (const void *)fused_mx_kernel<2>; break;
-    case 3: fn = (const void *)fused_mx_kernel<3>; break;
-    case 4: fn = (const void *)fused_mx_kernel<4>; break;
-    case 12: fn = (const void *)fused_mx_kernel<12>; break;
-    case 15: fn = (const void *)fused_mx_kernel<15>; break;
-    case 31: fn = (const void *)fused_mx_kernel<31>; break;
-    default: break;
-    }
+    if (!plan.given) switch (dbg) {
+        case 1: fn = (const void *)fused_mx_kernel<1, false>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false>; break;
+        default: break;
+        }
 #endif
-    static const void *attr_set = nullptr;
-    if (attr_set != fn) {
+    static const void *attr_set[2] = {nullptr, nullptr};
+    if (attr_set[plan.given ? 1 : 0] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = fn;
+        attr_set[plan.given ? 1 : 0] = fn;
     }
     MxArgs a;
     a.units = (const v4u *)d_units;
@@ -777,6 +848,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.n_samples = n_samples;
     a.P = plan.P;
     a.nu_last = plan.nu_last;
+    a.Q = plan.Q;
     a.desc = d_desc;
     a.pre = (const MxPre *)d_pre;
     a.prm = prm;
@@ -789,8 +861,13 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.const_sum = d_const_sum;
     a.cpart = d_cpart;
     a.timeout = d_timeout;
+    const dim3 grid(plan.P * plan.Q);
+    if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
+        hipLaunchKernelGGL((fused_mx_kernel<0, true>), grid, dim3(512), kLdsBytes, st, a);
+        return hipGetLastError();
+    }
     void *args[] = {&a};
-    return hipLaunchCooperativeKernel(fn, dim3(plan.P), dim3(512), args, kLdsBytes, st);
+    return hipLaunchCooperativeKernel(fn, grid, dim3(512), args, kLdsBytes, st);
 }
 
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
@@ -799,7 +876,7 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
                           unsigned long long *d_status) {
     (void)hipGetLastError();
     const uint64_t blocks = std::max<uint64_t>(std::max<uint64_t>(1, (n_samples + 255) / 256), std::min<uint64_t>(4096, n_tally1 / 1024));
-    hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_flush, plan.P, n_samples,
+    hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_sb, plan.Q, plan.P, n_samples,
                        std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_tally1, n_tally1, d_timeout,
                        d_status);
     return hipGetLastError();

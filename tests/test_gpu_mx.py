@@ -75,9 +75,14 @@ def test_gt2x_fill_paths_agree(shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (33, 1), (100, 3), (1000, 64), (2047, 127), (2048, 128), (2049, 129),
-                                   (4096, 257), (20000, 1001), (16385, 47), (40000, 385), (70000, 33), (5, 900)])
+                                   (4096, 257), (20000, 1001), (16385, 47), (40000, 385), (70000, 33), (5, 900),
+                                   (70000, 2000), (3000, 40000), (250000, 700), (530000, 130), (1050000, 300)])
 def test_gt2x_resident_vs_oracle(shape):
-    """1 .. 35 strips (ragged last strip: 1 unit, 1 sample), 1 .. 8 superblocks (ragged last one), all decisions"""
+    """1 .. 513 strips (ragged last strip: 1 unit, 1 sample), 1 .. 313 superblocks (ragged last one), all decisions.
+    Fewer strips than compute units: row teams (70 000 x 2 000: 35 strips x 7 teams of 2-3 superblocks; 3 000 x
+    40 000: 2 strips x 128 teams; 250 000 x 700: 123 strips x 2 teams).  More strips than compute units (530 000 and
+    1 050 000 samples: 259 and 513 strips, beyond the 255 x 2 048 samples of one resident grid): NPS_MODE_AUTO takes
+    the tally pass + the accumulation with given tallies."""
     n, m = shape
     rng = np.random.default_rng(n + m)
     co = make_cohort(n, m, 4242, rng)
@@ -90,6 +95,43 @@ def test_gt2x_resident_vs_oracle(shape):
     assert nloci == ref_nloci
     assert_stats_equal(stats, [tuple(s) for s in ref_stats])
     check_scores(scores, ref_scores, co["beta"], nloci)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2049, 129), (20000, 1001), (70000, 2000), (3000, 5000)])
+def test_gt2x_two_pass_mode_vs_oracle(shape):
+    """NPS_MODE_TWOPASS on a strip cohort: the tally pass + the accumulation with given tallies (what shapes with more
+    strips than compute units get under NPS_MODE_AUTO), here on shapes the single-read kernel also takes: equal to the
+    oracle and bit-identical tallies; NPS_MODE_FUSED on a shape beyond the resident grid is refused, not mis-scored"""
+    n, m = shape
+    rng = np.random.default_rng(n * 3 + m)
+    co = make_cohort(n, m, 777, rng)
+    kw = PARAM_GRID[(n + m + 2) % len(PARAM_GRID)]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
+    scores, nloci, stats = score_gt2x(dev, n, kw, descs, 0.5, mode=capi.MODE_TWOPASS)
+    one, nloci1, stats1 = score_gt2x(dev, n, kw, descs, 0.5, mode=capi.MODE_FUSED)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.5)
+    assert nloci == ref_nloci == nloci1
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert_stats_equal(stats1, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+    # the same exact integer digit sums, folded in another grouping (teams): equal to a few ulps of the sum
+    both = ~np.isnan(one)
+    assert np.array_equal(np.isnan(one), np.isnan(scores))
+    assert np.allclose(one[both], scores[both], rtol=1e-12, atol=1e-15)
+
+
+def test_gt2x_fused_mode_refused_beyond_resident_grid():
+    n, m = 530000, 130
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    sc = capi.Scorer(n, capi.make_params())
+    with pytest.raises(capi.NpsError) as ei:
+        sc.score_cohort(dev, capi.row_descs(np.ones(m), 0.3 * np.ones(m)), 0, capi.MODE_FUSED)
+    assert ei.value.status == -6  # NPS_E_UNSUPPORTED
+    sc.close()
+    dev.close()
 
 
 @pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
@@ -305,8 +347,6 @@ def test_gt2x_refusals():
     d = capi.row_descs(np.zeros(10), np.full(10, 0.1))
     with pytest.raises(capi.NpsError):
         sc.score_cohort(dev, d, 5)                       # cohort_row0 not a multiple of 128
-    with pytest.raises(capi.NpsError):
-        sc.score_cohort(dev, d, 0, capi.MODE_TWOPASS)    # no two-pass kernels for this layout
     with pytest.raises(capi.NpsError):
         dev.upload(64, np.zeros((10, 7), np.uint32))     # row0 of an upload: whole superblocks
     sc.score_cohort(dev, d, 128)                         # refused calls left the context usable
