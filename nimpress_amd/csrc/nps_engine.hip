@@ -1315,7 +1315,16 @@ struct nps_scoredef {
     // NPS_FMT_GT2X runs: the largest |beta| (4 + max(2, 2 |eaf|)) over the PRESENT rows with finite numbers: the
     // fixed-point scale 2^F of fused_mx_kernel keeps every weight below 2^56
     double mx_bound = 0.0;
+    // ... and when the definition's weights span more than 2^30 (a sample that carries only its small-beta rows would see
+    // the quantisation of the largest one): magnitude bands of 2^30, each a copy of the PRESENT rows with beta = 0
+    // outside the band, scored one pass per band with the band's own scale (empty: one band, d_desc itself)
+    struct MxBand {
+        double bound = 0.0;
+        nps_row_desc *d_desc = nullptr;
+    };
+    std::vector<MxBand> mx_bands;
 };
+constexpr int kMxBandBits = 30, kMxMaxBands = 8;
 
 extern "C" int nps_scoredef_create(nps_scoredef **out, int device, const nps_row_desc *rows,
                                    uint64_t n_desc) {
@@ -1358,8 +1367,46 @@ extern "C" int nps_scoredef_create(nps_scoredef **out, int device, const nps_row
         hipError_t e = hipMalloc(&d->d_desc, sizeof(nps_row_desc) * d->m);
         if (e == hipSuccess)
             e = hipMemcpy(d->d_desc, data.data(), sizeof(nps_row_desc) * d->m, hipMemcpyHostToDevice);
+        // magnitude bands for the fixed-point kernel (north star: 1e-6 RELATIVE for every sample, also one whose only
+        // rows are the definition's smallest): band b holds the rows with bound 2^-30(b+1) < v <= bound 2^-30b
+        std::vector<int> band(d->m, 0);
+        int n_bands = 1;
+        if (e == hipSuccess && d->mx_bound > 0.0) {
+            for (uint64_t j = 0; j < d->m; ++j) {
+                const nps_row_desc &r = data[j];
+                if (!std::isfinite(r.beta) || r.beta == 0.0) continue;
+                const double ie = std::isfinite(r.eaf) ? std::max(2.0, 2.0 * std::fabs(r.eaf)) : 2.0;
+                int e_top = 0, e_v = 0;
+                (void)std::frexp(d->mx_bound, &e_top);
+                (void)std::frexp(std::fabs(r.beta) * (4.0 + ie), &e_v);
+                band[j] = std::min(kMxMaxBands - 1, std::max(0, (e_top - e_v) / kMxBandBits));
+                n_bands = std::max(n_bands, band[j] + 1);
+            }
+        }
+        if (e == hipSuccess && n_bands > 1) {
+            std::vector<nps_row_desc> copy(d->m);
+            for (int b = 0; b < n_bands && e == hipSuccess; ++b) {
+                nps_scoredef::MxBand mb;
+                bool any = b == 0;
+                for (uint64_t j = 0; j < d->m; ++j) {
+                    copy[j] = data[j];
+                    if (band[j] != b && std::isfinite(data[j].beta)) copy[j].beta = 0.0;
+                    if (band[j] == b && std::isfinite(data[j].beta) && data[j].beta != 0.0) {
+                        const double ie = std::isfinite(data[j].eaf) ? std::max(2.0, 2.0 * std::fabs(data[j].eaf)) : 2.0;
+                        mb.bound = std::max(mb.bound, std::fabs(data[j].beta) * (4.0 + ie));
+                        any = true;
+                    }
+                }
+                if (!any) continue;  // an empty band costs no pass
+                e = hipMalloc(&mb.d_desc, sizeof(nps_row_desc) * d->m);
+                if (e == hipSuccess)
+                    e = hipMemcpy(mb.d_desc, copy.data(), sizeof(nps_row_desc) * d->m, hipMemcpyHostToDevice);
+                d->mx_bands.push_back(mb);
+            }
+        }
         if (e != hipSuccess) {
             (void)hipFree(d->d_desc);
+            for (auto &mb : d->mx_bands) (void)hipFree(mb.d_desc);
             delete d;
             return fail(e == hipErrorOutOfMemory ? NPS_E_NOMEM : NPS_E_HIP,
                         "uploading the score definition failed: %s", hipGetErrorString(e));
@@ -1375,6 +1422,7 @@ extern "C" void nps_scoredef_destroy(nps_scoredef *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipFree(d->d_desc);
+    for (auto &mb : d->mx_bands) (void)hipFree(mb.d_desc);
     delete d;
 }
 
@@ -1612,13 +1660,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
 
     if (is_mx) {
         if (c->n == 0) return done();
-        // fixed-point scale: every weight of the definition below 2^56 (fourteen hexadecimal digits)
-        int F = 56;
-        if (def->mx_bound > 0.0) {
-            int e2 = 0;
-            (void)std::frexp(def->mx_bound, &e2);  // bound < 2^e2
-            F = std::min(1000, std::max(-1000, 56 - e2));
-        }
         // the reference's test `nmissing / N > --maxmis` (double division, nimpress.nim:565) is monotone in
         // nmissing: the largest count that is NOT over the rate, found with that very expression
         const double rate = c->params.max_missing_rate;
@@ -1634,36 +1675,56 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             }
             t_maxmis = (int64_t)lo;
         }
-        rc = tally_ready();
-        if (rc) return rc;
-        if (mxp.given) {
-            ProfScope ps(c, P_TALLY);
-            HIP_TRY(launch_mx_tally(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n,
-                                    c->d_rtally));
+        // one pass per magnitude band of the definition (normally one): band 0 counts nloci and writes the statistics
+        struct Run {
+            const nps_row_desc *d_desc;
+            double bound;
+        };
+        std::vector<Run> runs;
+        if (def->mx_bands.empty())
+            runs.push_back(Run{def->d_desc, def->mx_bound});
+        else
+            for (const auto &mb : def->mx_bands) runs.push_back(Run{mb.d_desc, mb.bound});
+        unsigned long long *scratch_nloci = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_mx_const) + 64);
+        for (size_t b = 0; b < runs.size(); ++b) {
+            // fixed-point scale: every weight of the band below 2^56 (fourteen hexadecimal digits)
+            int F = 56;
+            if (runs[b].bound > 0.0) {
+                int e2 = 0;
+                (void)std::frexp(runs[b].bound, &e2);  // bound < 2^e2
+                F = std::min(1000, std::max(-1000, 56 - e2));
+            }
+            rc = tally_ready();
+            if (rc) return rc;
+            if (mxp.given) {
+                ProfScope ps(c, P_TALLY);
+                HIP_TRY(launch_mx_tally(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n,
+                                        c->d_rtally));
+            }
+            hipError_t fe;
+            {
+                ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
+                fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                     runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
+                                     c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
+                                     c->d_mx_const, c->d_mx_cpart, c->d_timeout);
+            }
+            if (fe != hipSuccess) {
+                (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
+                c->rtally_clean = !mxp.given;
+                return fail(NPS_E_HIP, "NPS_FMT_GT2X kernel launch failed: %s", hipGetErrorString(fe));
+            }
+            guard.armed = true;
+            {
+                ProfScope ps(c, P_REDUCE);
+                HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, c->d_mx_const, c->d_part,
+                                       c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
+                                       (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1));
+                HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double), c->stream));
+            }
+            c->chunks_used = std::max(c->chunks_used, 1u);
+            c->rtally_clean = true;
         }
-        hipError_t fe;
-        {
-            ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
-            fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                 def->d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally, c->d_mx_tally1, c->d_rstats,
-                                 c->d_nloci,
-                                 c->d_mx_const, c->d_mx_cpart, c->d_timeout);
-        }
-        if (fe != hipSuccess) {
-            (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
-            c->rtally_clean = !mxp.given;
-            return fail(NPS_E_HIP, "NPS_FMT_GT2X kernel launch failed: %s", hipGetErrorString(fe));
-        }
-        guard.armed = true;
-        {
-            ProfScope ps(c, P_REDUCE);
-            HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, c->d_mx_const, c->d_part,
-                                   c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
-                                   (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1));
-            HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double), c->stream));
-        }
-        c->chunks_used = std::max(c->chunks_used, 1u);
-        c->rtally_clean = true;
         return done();
     }
 

@@ -341,6 +341,46 @@ def test_gt2x_every_row_of_a_65536_row_slice_recounted():
         assert np.array_equal(stats["reason"] == capi.REASON_MAXMIS, ms / n > 0.05)
 
 
+@pytest.mark.parametrize("mode", [capi.MODE_AUTO, capi.MODE_TWOPASS])
+def test_gt2x_beta_span_plain_relative_bar(mode):
+    """beta from 1e-9 to 10 in ONE definition, and samples that carry only its small-beta rows: the north star's bar --
+    1e-6 RELATIVE, plain, no absolute escape -- for every sample.  (56-bit fixed-point weights scaled to the largest
+    |beta| alone would leave such a sample 2^-56 x 10 / 1e-9 = 1.4e-7 per term at best and nothing below 1e-17; the
+    definition is scored in magnitude bands of 2^30, one pass each.)  All beta positive: no cancellation, the relative
+    bar means what it says."""
+    n, m = 6000, 512
+    rng = np.random.default_rng(4711)
+    mag = np.array([10.0, 1e-3, 1e-9, 3e-14])
+    beta = np.concatenate([rng.uniform(0.1, 1.0, m // 4) * k for k in mag])
+    eaf = np.round(rng.uniform(0.05, 0.5, m), 4)
+    # quarter q of the samples has genotypes (dosage 0/1/2, 2 % missing) only in the rows of magnitudes >= q
+    codes = np.zeros((m, (n + 15) // 16), np.uint32)
+    g = rng.integers(0, 3, size=(m, n)).astype(np.uint32)
+    g[g == 2] = 3                       # NPS_CODE_DOSAGE2
+    miss = rng.uniform(size=(m, n)) < 0.02
+    g[miss] = 2                         # NPS_CODE_MISSING
+    for q in range(4):
+        g[: q * (m // 4), q * (n // 4):(q + 1) * (n // 4)] = 0
+    for k in range(16):
+        cols = g[:, k::16]
+        codes[:, :cols.shape[1]] |= cols << np.uint32(2 * k)
+    co = dict(n=n, m=m, eaf=eaf, beta=beta, rie=np.zeros(m, np.int32), codes=codes)
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=100)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.upload(0, codes)
+    scores, nloci, stats = score_gt2x(dev, n, kw, capi.row_descs(beta, eaf), 0.0, mode=mode)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci == m
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    ref = np.asarray(ref_scores)
+    assert not np.isnan(ref).any() and (ref > 0).all()
+    rel = np.abs(np.asarray(scores) - ref) / ref
+    assert rel.max() <= 1e-6, (rel.max(), int(rel.argmax()), ref[rel.argmax()])
+    # the last quarter's scores are 1e-14 of the first quarter's
+    assert ref[-1] < 1e-12 * ref[0]
+
+
 def test_gt2x_refusals():
     dev = capi.Cohort(100, 300, fmt=capi.FMT_GT2X)
     sc = capi.Scorer(100, capi.make_params())

@@ -11,6 +11,7 @@ ap.add_argument("--variants", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--cases", default="bench")
 ap.add_argument("--fmt", type=int, default=3)
+ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 two reads (tally + accumulation), 2 single read")
 a = ap.parse_args()
 import torch
 from nimpress_amd import capi
@@ -54,14 +55,14 @@ for key in a.cases.split(","):
         sc.reset()
         sc.profile_enable(True)
         sc.profile_get(reset=True)
-        sc.score_cohort_def(co, sdef, 0, capi.MODE_FUSED)
+        sc.score_cohort_def(co, sdef, 0, a.mode)
         nloci = sc.finish_device(0.0, d.data_ptr())
         p = sc.profile_get(reset=True)
-        times.append((p.ms_fused, p.ms_reduce))
+        times.append((p.ms_fused + p.ms_tally + p.ms_accumulate, p.ms_reduce, p.ms_tally))
     alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
     best = min(t[0] for t in times[1:])
-    print("%-44s fmt %d: fused %s ms, reduce %.3f ms; best %.2f ms = %.1f %% of 8 TB/s; nloci %d, score[0] %.12g" % (
-        name, a.fmt, " ".join("%.2f" % t[0] for t in times), times[-1][1], best, alg / best / 8e9 * 100, nloci,
+    print("%-44s %d x %d fmt %d: kernels %s ms (tally pass %.2f), reduce %.3f ms; best %.2f ms = %.1f %% of 8 TB/s; nloci %d, score[0] %.12g" % (
+        name, n, m, a.fmt, " ".join("%.2f" % t[0] for t in times), times[-1][2], times[-1][1], best, alg / best / 8e9 * 100, nloci,
         float(d[0])), flush=True)
     sc.close(); sdef.close(); co.close()
     torch.cuda.empty_cache()
