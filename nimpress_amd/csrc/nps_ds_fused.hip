@@ -330,8 +330,8 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         const char *p = reinterpret_cast<const char *>(a.ds) + (in ? row : 0) * stride_bytes;
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, in ? row_bytes : 0u, 0x00020000);
-        const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-        const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 0);
+        const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);
+        const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 2);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             dst[r * 8 + s] = __uint_as_float(qa[s]);

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(T, 4) void fused_cw_kernel(const FusedArgs a) {
         for (int g = 0; g < 4; ++g) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char *>(p), 0, (uint32_t)g < ngroups ? row_bytes * 4u : 0u, 0x00020000);
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);
             dst[4 * g + 0] = q[0];
             dst[4 * g + 1] = q[1];
             dst[4 * g + 2] = q[2];
