@@ -213,7 +213,13 @@ void nps_destroy(nps_ctx *ctx);
 #define NPS_CODE_DOSAGE1 1u
 #define NPS_CODE_MISSING 2u
 #define NPS_CODE_DOSAGE2 3u
-#define NPS_FMT_DS32 1 /* float32 dosages, NaN = missing, variant-major / sample-minor */
+/* float32 dosages, NaN = missing, variant-major / sample-minor.  A dosage is 0 <= DS <= 2 (the FORMAT/DS convention
+ * for a diploid sample; the host readers refuse a file that breaks it).  The single-read kernel (NPS_MODE_FUSED, and
+ * NPS_MODE_AUTO where the shape allows it) relies on that range: it hands the slices' dosage sums over as fixed-point
+ * integers (order-independent, bit-reproducible).  A resident value outside [0, 2] makes nps_flush / nps_finish of
+ * that run return NPS_E_INVAL (sticky until nps_reset); NPS_MODE_TWOPASS and the streamed nps_push_ds rows take any
+ * finite value. */
+#define NPS_FMT_DS32 1
 /* 2-bit codes in the layout of the multi-score (matrix-core) path: superblocks of 128 rows x groups of 32
  * samples, 16 ROWS of one sample per 32-bit word; carries its whole-row tallies.  Filled by
  * nps_cohort_convert (from a NPS_FMT_GT2 cohort) or nps_cohort_synth[_rows]; scored by nps_score_cohort_multi. */

@@ -253,6 +253,12 @@ const float *Variant::dsRow(int eaidx, size_t n, std::vector<float> &tmp) const 
             float sum = 0.0f;
             for (int k = 0; k < ds_per_sample; ++k)
                 if (!isVectorEndFloat(p[k])) sum += p[k];
+            if (sum > 2.0f) {  // the ALT dosages of a diploid sample add up to at most 2 (rounding of printed values aside)
+                if (sum > 2.001f)
+                    throw std::runtime_error("FORMAT/DS: the ALT dosages of a sample add up to more than 2 at " + contig + ":" +
+                                             std::to_string(pos));
+                sum = 2.0f;
+            }
             tmp[i] = sum;
         }
     }
@@ -342,45 +348,70 @@ static bool parseRecordLine(const char *L, size_t len, size_t ns, const RegionMa
         if (di >= 0 && (gi < 0 || preferDS())) {  // FORMAT/DS: one float per ALT allele and sample, "." = missing
             v.has_gt = false;
             v.has_ds = true;
-            v.ds_per_sample = 1;
-            std::vector<std::vector<float>> rows(ns);
-            const char *s = col[9];
-            for (size_t i = 0; i < ns; ++i) {
-                const char *t = s;
+            // two sweeps over the sample columns, no allocation per genotype: the widest value list decides the
+            // stride (Number=1 or Number=A), then every value is parsed where it lies and checked against the
+            // range of a dosage, 0 <= DS <= 2 (what the single-read DS kernel's fixed-point tallies rely on)
+            const char *const s_first = col[9];
+            auto subfield = [&](const char *s0, const char *&g0, const char *&g1) -> const char * {
+                const char *t = s0;
                 while (t < end && *t != '\t') ++t;
-                const char *g0 = s;
+                g0 = s0;
                 for (int k = 0; k < di && g0 < t; ++k) {
                     while (g0 < t && *g0 != ':') ++g0;
                     if (g0 < t) ++g0;
                 }
-                const char *g1 = g0;
+                g1 = g0;
                 while (g1 < t && *g1 != ':') ++g1;
+                return t;
+            };
+            int width = 1;
+            {
+                const char *s = s_first;
+                for (size_t i = 0; i < ns; ++i) {
+                    const char *g0, *g1;
+                    const char *t = subfield(s, g0, g1);
+                    int k = 1;
+                    for (const char *q = g0; q < g1; ++q) k += *q == ',';
+                    width = std::max(width, k);
+                    if (t >= end && i + 1 < ns) throw std::runtime_error("VCF record with too few sample columns");
+                    s = t + 1;
+                }
+            }
+            v.ds_per_sample = width;
+            uint32_t eov_bits = 0x7F800002u;
+            float eov;
+            memcpy(&eov, &eov_bits, 4);
+            v.ds.assign(ns * (size_t)width, eov);
+            const char *s = s_first;
+            for (size_t i = 0; i < ns; ++i) {
+                const char *g0, *g1;
+                const char *t = subfield(s, g0, g1);
+                float *dst = &v.ds[i * (size_t)width];
                 const char *a = g0;  // comma separated values of [g0, g1)
-                while (true) {
+                for (int k = 0;; ++k) {
                     const char *b = a;
                     while (b < g1 && *b != ',') ++b;
                     if (b == a || (b - a == 1 && *a == '.')) {
-                        rows[i].push_back(missingFloat());
+                        dst[k] = missingFloat();
                     } else {
+                        char buf[64];
+                        const size_t len = (size_t)(b - a);
+                        if (len >= sizeof buf) throw std::runtime_error("bad FORMAT/DS value (too long)");
+                        memcpy(buf, a, len);
+                        buf[len] = 0;
                         char *ep = nullptr;
-                        const std::string tok(a, b - a);
-                        const float f = strtof(tok.c_str(), &ep);
-                        if (!ep || *ep) throw std::runtime_error("bad FORMAT/DS value '" + tok + "'");
-                        rows[i].push_back(f);
+                        const float f = strtof(buf, &ep);
+                        if (!ep || *ep) throw std::runtime_error(std::string("bad FORMAT/DS value '") + buf + "'");
+                        if (f == f && !(f >= 0.0f && f <= 2.0f))
+                            throw std::runtime_error(std::string("FORMAT/DS value ") + buf + " outside [0, 2] at " + v.contig +
+                                                     ":" + field(1));
+                        dst[k] = f;
                     }
                     if (b >= g1) break;
                     a = b + 1;
                 }
-                v.ds_per_sample = std::max(v.ds_per_sample, (int)rows[i].size());
-                if (t >= end && i + 1 < ns) throw std::runtime_error("VCF record with too few sample columns");
                 s = t + 1;
             }
-            uint32_t eov_bits = 0x7F800002u;
-            float eov;
-            memcpy(&eov, &eov_bits, 4);
-            v.ds.assign(ns * (size_t)v.ds_per_sample, eov);
-            for (size_t i = 0; i < ns; ++i)
-                for (size_t k = 0; k < rows[i].size(); ++k) v.ds[i * (size_t)v.ds_per_sample + k] = rows[i][k];
             return true;
         }
         const int cap = 8;
@@ -873,6 +904,10 @@ static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const u
     v.gts.clear();
     if (n_sample != h.samples.size()) throw std::runtime_error("BCF: record sample count differs from the header");
     BcfCursor f{indiv, indiv + l_indiv};
+    int ds_type = 0;
+    int64_t ds_len = 0;
+    const unsigned char *ds_ptr = nullptr;
+    size_t ds_bytes = 0;
     for (uint32_t k = 0; k < n_fmt; ++k) {
         const int32_t key = f.typedInt();
         int type;
@@ -888,12 +923,12 @@ static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const u
             v.gt_raw.assign(f.p, f.p + bytes);
             v.has_gt = true;
         } else if (key >= 0 && (size_t)key < h.ids.size() && h.ids[(size_t)key] == "DS") {
-            // typed float vector: len values per sample, missing 0x7F800001, end of vector 0x7F800002
-            if (type != 5) throw std::runtime_error("BCF: FORMAT/DS is not a float vector");
-            if (len < 1) throw std::runtime_error("BCF: empty FORMAT/DS vector");
-            v.ds_per_sample = (int)len;
-            v.ds.resize((size_t)len * n_sample);
-            memcpy(v.ds.data(), f.p, bytes);
+            // remembered only: whether the record is scored from GT or from DS is decided below, and a DS that is not
+            // used is neither validated nor copied (a file with an oddly typed DS next to its GT scores as before)
+            ds_type = type;
+            ds_len = len;
+            ds_ptr = f.p;
+            ds_bytes = bytes;
             v.has_ds = true;
         }
         f.p += bytes;
@@ -901,13 +936,21 @@ static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const u
     if (n_sample && !v.has_gt && !v.has_ds)
         throw std::runtime_error("BCF record without FORMAT/GT (or FORMAT/DS) at " + v.contig + ":" + std::to_string(v.pos));
     if (v.has_ds && (!v.has_gt || preferDS())) {  // the selection rule of nimpress_host.hpp: one of the two is kept
+        // typed float vector: len values per sample, missing 0x7F800001, end of vector 0x7F800002
+        if (ds_type != 5) throw std::runtime_error("BCF: FORMAT/DS is not a float vector");
+        if (ds_len < 1) throw std::runtime_error("BCF: empty FORMAT/DS vector");
+        v.ds_per_sample = (int)ds_len;
+        v.ds.resize((size_t)ds_len * n_sample);
+        memcpy(v.ds.data(), ds_ptr, ds_bytes);
+        for (const float x : v.ds)  // a dosage is 0 <= DS <= 2 (NaN patterns = missing / end of vector)
+            if (x == x && !(x >= 0.0f && x <= 2.0f))
+                throw std::runtime_error("FORMAT/DS value " + std::to_string(x) + " outside [0, 2] at " + v.contig + ":" +
+                                         std::to_string(v.pos));
         v.has_gt = false;
         v.gt_raw.clear();
         v.gt_raw.shrink_to_fit();
     } else {
         v.has_ds = false;
-        v.ds.clear();
-        v.ds.shrink_to_fit();
     }
     return true;
 }
@@ -1657,6 +1700,11 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                                     break;
                                 }
                         }
+                        if (v->has_ds && v->ds_per_sample == 1 && v->alt.size() > 1 && eaidx <= 1)
+                            rec.pre_warning += (rec.pre_warning.empty() ? "" : "\n") + std::string("Variant ") + e.contig + ":" +
+                                               std::to_string(e.pos) + " has one FORMAT/DS value per sample at a site with " +
+                                               std::to_string(v->alt.size()) + " ALT alleles; it is taken as the dosage of " +
+                                               "the first ALT allele.";
                         if (v->has_ds)  // FORMAT/DS row (build-defined; the seam of nim:381-391 for float dosages)
                             npsCheck(nps_push_ds(ctx, v->dsRow(eaidx, (size_t)nsamples, ds_tmp), rie, e.beta, e.eaf),
                                      "nps_push_ds");

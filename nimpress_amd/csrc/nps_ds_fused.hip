@@ -13,11 +13,16 @@
 //     reference's own order and operations (row after row, float64 `dosage * beta` then `+=`,
 //     not fused), tally batch k+5 (NaN count by wave ballot, dosage sum by a fixed-shape tree) and
 //     refill the ring.
-//   * control wave: combines the waves' partial tallies in fixed order, stores the workgroup's
-//     partial dosage sum to psum[row][slice] (sc1 store, drained) and then signals with one 64-bit
-//     agent-scope atomic (arrivals<<56 | nmissing); two phases after that it looks at the row's word until
-//     all P slices have arrived, adds the P partial sums (sc1 loads) in fixed order -- deterministic,
-//     and derives the row's parameters for the data waves.  One workgroup barrier per batch.
+//   * control wave: combines the waves' partial tallies in fixed order and hands the slice's tally over with
+//     two 64-bit agent-scope atomic adds on the row's pair of words, each carrying its own arrival count:
+//     word 0 = arrivals<<56 | high part of the dosage sum<<28 | nmissing, word 1 = arrivals<<56 | low part.
+//     The slice's dosage sum travels as a FIXED-POINT integer (2^F, F from the cohort size): integer adds
+//     commute, so the total does not depend on the order of arrival (bit-reproducible), nobody stores, drains
+//     or re-reads per-slice partial sums (rounds 1-3: an sc1 store, a drained queue, then the arrival, and P
+//     loads + a tree sum on the other side: 11 % of the pass).  Two phases later the control wave looks at the
+//     pair until both counts say P and derives the row's parameters.  One workgroup barrier per batch.
+//     Range: FORMAT/DS values are dosages, 0 <= DS <= 2 (validated on ingest; a value outside raises the
+//     context's NPS_STATUS_DS_RANGE bit and the pass fails -- the bound is what keeps the fields apart).
 //
 // Semantics are the build-defined DS extension of the oracle (ref_raw_dosages_ds): NaN = missing,
 // effect allele == REF -> dosage = 2 - DS.  The row's dosage sum is formed as sum(DS) and turned into
@@ -46,8 +51,8 @@ struct DsFusedArgs {
     uint32_t P, Q;
     const nps_row_desc *desc;
     DevParams prm;
-    unsigned long long *tally;  // [n_rows], zeroed: arrivals << 56 | nmissing
-    double *psum;               // [n_rows][P]: sum of the non-missing DS values of one slice
+    unsigned long long *tally;  // [n_rows][2], zeroed: arrivals << 56 | sum_hi << 28 | nmissing ; arrivals << 56 | sum_lo
+    double scale, inv_scale;    // 2^F, 2^-F: the slices' dosage sums travel as round(sum * 2^F)
     nps_locus_stat *stats;
     unsigned long long *nloci;
     double *part;  // [Q][part_team_stride]
@@ -66,11 +71,6 @@ struct __attribute__((aligned(16))) DsFusedLds {
     DsRowLds rowp[2][kDsRows];
 };
 
-static __device__ __forceinline__ double wave_tree_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // lane 0
-}
 // wave sum by DPP (row_shr 1,2,4,8, then row_bcast15 / row_bcast31): fixed order, total in lane 63.
 // Two v_mov_b32_dpp + one v_add_f64 per stage, ~100 cycles of dependent latency per row instead of
 // the ~1 500 of a ds_bpermute tree.
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         // of batch k+1 (whose arrival word matched a phase ago), the poll of batch k+2 and the
         // publication of batch k+3 are issued back to back and drained by one s_waitcnt.
         struct Polled {  // lanes < R: one row each
-            unsigned long long x;
+            unsigned long long x, y;  // the row's pair of words
             double beta, eaf;
             int rflags;
             bool valid, ok;
@@ -137,11 +137,12 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
             Polled q;
             const uint64_t row = batch_row0(kt) + lane;
             q.valid = lane < R && kt < n_local && row < a.n_rows;
-            q.x = 0;
+            q.x = q.y = 0;
             q.beta = q.eaf = 0.0;
             q.rflags = 0;
             if (q.valid) {
-                q.x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.x = __hip_atomic_load(&a.tally[2 * row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.y = __hip_atomic_load(&a.tally[2 * row + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q.beta = a.desc[row].beta;
                 q.eaf = a.desc[row].eaf;
                 q.rflags = a.desc[row].ref_is_effect;
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         };
         auto poll_finish = [&](uint32_t kt, Polled &q) {  // spins until all P slices have arrived
             const uint64_t row = batch_row0(kt) + lane;
-            q.ok = !q.valid || (uint32_t)(q.x >> 56) == a.P;
+            q.ok = !q.valid || ((uint32_t)(q.x >> 56) == a.P && (uint32_t)(q.y >> 56) == a.P);
             uint32_t spins = 0;
             while (!__all(q.ok) && !timed_out) {
                 __builtin_amdgcn_s_sleep(1);
                 if (!q.ok) {
-                    q.x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    q.ok = (uint32_t)(q.x >> 56) == a.P;
+                    q.x = __hip_atomic_load(&a.tally[2 * row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q.y = __hip_atomic_load(&a.tally[2 * row + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q.ok = (uint32_t)(q.x >> 56) == a.P && (uint32_t)(q.y >> 56) == a.P;
                 }
                 if ((++spins & 255u) == 0) {
                     const unsigned int t =
@@ -169,29 +171,9 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
                     }
                 }
             }
-            asm volatile("" ::: "memory");  // loads of the handed-off sums stay behind the matched poll
         };
 
-        // the P partial sums of each row of batch kt (poll matched): sc1 loads, lane i takes slices
-        // i, i+64, ...
-        auto psum_issue = [&](uint32_t kt, double(&v)[R]) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint64_t row_r = batch_row0(kt) + r;
-                v[r] = 0.0;
-                if (kt < n_local && row_r < a.n_rows && !timed_out)
-                    for (uint32_t i = lane; i < a.P; i += 64)
-                        v[r] += __longlong_as_double((long long)__hip_atomic_load(
-                            reinterpret_cast<unsigned long long *>(&a.psum[row_r * a.P + i]),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-        };
-
-        // partial tallies of batch k (its LDS sums are complete): sc1 store of the dosage sum, drained,
-        // then the arrival.  This is the fence-free hand-off MI355X_MICROARCH.md lists as measured
-        // valid on gfx950 (one lane signals for its own 8-byte sc1 store; the consumer's polling wave
-        // loads the bytes with sc1 loads after its poll matched); an agent-scope release/acquire pair
-        // instead costs 1.7-6.5 us per phase (buffer_wbl2 / buffer_inv).
+        // partial tallies of batch k (its LDS sums are complete): two atomic adds, nothing to drain, nothing stored
         auto publish = [&](uint32_t k) {
             double s = 0.0;
             uint32_t cnt = 0;
@@ -204,25 +186,22 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
                     s += lds.wsum[par][lane][w];
                     cnt += lds.wcnt[par][lane][w];
                 }
-                if (valid)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.psum[row * a.P + slice]),
-                                       (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED,
+            }
+            if (valid) {
+                const double x = s * a.scale;
+                // (a slice holds < 2^14 of dosage, F <= 46; anything else is a value outside [0, 2]: flagged by the data waves)
+                const unsigned long long S = x >= 0.0 && x < 9.0e18 ? (unsigned long long)__double2ll_rn(x) : 0ull;
+                __hip_atomic_fetch_add(&a.tally[2 * row], (1ull << 56) | ((S >> 32) << 28) | (unsigned long long)cnt,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&a.tally[2 * row + 1], (1ull << 56) | (S & 0xffffffffull), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also lands every load issued before
-            if (valid)
-                __hip_atomic_fetch_add(&a.tally[row], (1ull << 56) | (unsigned long long)cnt,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
 
-        // row parameters of batch kt from its complete tally words and partial sums
-        auto params = [&](uint32_t kt, const Polled &q, double(&v)[R]) {
-            double mysum = 0.0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double tot = uniform_f64(wave_tree_sum(v[r]));
-                if (lane == r) mysum = tot;
-            }
+        // row parameters of batch kt from its complete pair of words
+        auto params = [&](uint32_t kt, const Polled &q) {
+            const unsigned long long tot = (((q.x >> 28) & 0xfffffffull) << 32) + (q.y & ((1ull << 56) - 1));
+            const double mysum = (double)tot * a.inv_scale;
             int used = 0;
             if (lane < R) {
                 const uint64_t row = batch_row0(kt) + lane;
@@ -234,7 +213,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
                 if (q.valid && q.ok) {
                     const double beta = q.beta, eaf = q.eaf;
                     const bool rie = (q.rflags & 1) != 0;  // homref imputation value
-                    const uint64_t nmiss = q.x & ((1ull << 56) - 1);
+                    const uint64_t nmiss = q.x & 0xfffffffull;
                     const uint64_t ngen = a.n_samples - nmiss;
                     const double neff = rp.flip ? 2.0 * (double)ngen - mysum : mysum;
                     const double nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -281,7 +260,6 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
             nloci_local += (uint32_t)__popcll(__ballot(used != 0));
         };
 
-        double v[R];
         __syncthreads();  // #0
         publish(0);
         __syncthreads();  // #1
@@ -292,17 +270,15 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         publish(3);
         Polled cur = poll_issue(0);
         poll_finish(0, cur);
-        psum_issue(0, v);
-        params(0, cur, v);
+        params(0, cur);
         cur = poll_issue(1);
         poll_finish(1, cur);
         __syncthreads();  // #4
         for (uint32_t k = 0; k < n_steps; ++k) {
-            psum_issue(k + 1, v);             // batch k+1: arrival word matched a phase ago
             Polled nxt = poll_issue(k + 2);   // batch k+2: published by every slice TWO phases ago: complete unless a slice lags
-            publish(k + 4);                   // drains the loads above with its own store
+            publish(k + 4);
             poll_finish(k + 2, nxt);
-            params(k + 1, cur, v);
+            params(k + 1, cur);
             cur = nxt;
             __syncthreads();  // #(k+5)
         }
@@ -350,6 +326,14 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         for (int r = 0; r < R; ++r) {
             uint32_t cnt = 0;
             double s = 0.0;
+            // a dosage is 0 <= DS <= 2 (maxNum / minNum skip the NaNs): anything else fails the pass
+            const float hi = fmaxf(fmaxf(fmaxf(src[r * 8], src[r * 8 + 1]), fmaxf(src[r * 8 + 2], src[r * 8 + 3])),
+                                   fmaxf(fmaxf(src[r * 8 + 4], src[r * 8 + 5]), fmaxf(src[r * 8 + 6], src[r * 8 + 7])));
+            const float lo = fminf(fminf(fminf(src[r * 8], src[r * 8 + 1]), fminf(src[r * 8 + 2], src[r * 8 + 3])),
+                                   fminf(fminf(src[r * 8 + 4], src[r * 8 + 5]), fminf(src[r * 8 + 6], src[r * 8 + 7])));
+            if (__any(hi > 2.0f || lo < 0.0f)) {
+                if (lane == 0) __hip_atomic_store(a.timeout + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
             for (int e = 0; e < kDsPerThread; ++e) {
                 const float v = src[r * 8 + e];
@@ -464,7 +448,7 @@ static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, i
 hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want, int max_q,
                          FusedPlan *plan) {
     *plan = FusedPlan{};
-    if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 30)) return hipSuccess;
+    if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;  // 28-bit tally fields
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return e;
@@ -488,7 +472,7 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int wa
 
 hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
-                           DevParams prm, unsigned long long *d_tally, double *d_psum,
+                           DevParams prm, unsigned long long *d_tally,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout) {
     DsFusedArgs a;
@@ -502,7 +486,12 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
     a.desc = d_desc;
     a.prm = prm;
     a.tally = d_tally;
-    a.psum = d_psum;
+    // total < 2 N 2^F must leave its high part (>> 32) inside 28 bits, a slice's sum (< 2^14) inside 63
+    int lg = 0;
+    while ((1ull << lg) < n_samples) ++lg;
+    const int F = std::min(46, 58 - lg);
+    a.scale = std::ldexp(1.0, F);
+    a.inv_scale = std::ldexp(1.0, -F);
     a.stats = d_stats;
     a.nloci = d_nloci;
     a.part = d_part;

@@ -123,8 +123,6 @@ struct nps_ctx {
     uint64_t res_ds_cap = 0;
     DsTally *d_rds_tally = nullptr;
     DsRowP *d_rds_rowp = nullptr;
-    double *d_rds_psum = nullptr;  // fused DS kernel: per (row, slice) partial dosage sums
-    uint64_t psum_cap = 0;
 
     // raw GT staging for ploidy > 2: a ring of two pinned host buffers (grown on demand), read by the kernel
     size_t poly_cap = 0;
@@ -306,7 +304,6 @@ static void free_ctx(nps_ctx *c) {
         if (c->ev_ds_raw[k]) (void)hipEventDestroy(c->ev_ds_raw[k]);
     (void)hipFree(c->d_rds_tally);
     (void)hipFree(c->d_rds_rowp);
-    (void)hipFree(c->d_rds_psum);
     (void)hipFree(c->d_part_fused);
     (void)hipFree(c->d_timeout);
     (void)hipFree(c->d_mx_cpart);
@@ -834,6 +831,10 @@ static int check_status(nps_ctx *c) {
     if (c->h_result[1] & 1ull)
         return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
                                    "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
+    if (c->h_result[1] & 2ull)
+        return fail(NPS_E_INVAL, "a FORMAT/DS value of the resident cohort lies outside [0, 2]: the single-read DS "
+                                 "kernel hands dosage sums over in fixed point and needs that range; the scores of "
+                                 "this context are invalid (nps_reset; NPS_MODE_TWOPASS takes any value)");
     return NPS_OK;
 }
 
@@ -1594,9 +1595,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
 
     // buffers (a failed allocation leaves the context usable: nothing has been queued yet)
     const uint64_t m_pad = is_mx ? (m + 127) / 128 * 128 : (m + 15) / 16 * 16;
-    rc = ensure_resident_buffers(c, m_pad);
-    if (rc) return rc;
     const bool fused = plan.ok && c->n;
+    // (the single-read DS kernel keeps a PAIR of tally words per row)
+    const uint64_t n_tally = is_ds && fused ? 2 * m_pad : m_pad;
+    rc = ensure_resident_buffers(c, n_tally);
+    if (rc) return rc;
     if (is_mx && c->n) {
         rc = grow(c, (void **)&c->d_mx_cpart, &c->mx_cpart_cap, mxp.cpart_floats, sizeof(float));
         if (rc) return rc;
@@ -1624,10 +1627,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             c->res_ds_cap = std::min(cap_a, cap_b);
             if (rc) return rc;
         }
-        if (fused) {
-            rc = grow(c, (void **)&c->d_rds_psum, &c->psum_cap, m * plan.P, sizeof(double));
-            if (rc) return rc;
-        }
     }
 
     // ---- launches.  From here on an error leaves queued work behind: the context is marked broken.
@@ -1651,7 +1650,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     auto epilogue = [&]() -> int {
         ProfScope ps(c, P_REDUCE);
         HIP_TRY(launch_fold(c->stream, c->d_part_fused, plan.Q, plan.part_team_stride, c->n, c->d_part,
-                            c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_timeout,
+                            c->chunks_used == 0 ? 1 : 0, c->d_rtally, n_tally, c->d_timeout,
                             c->d_nloci + 1));
         c->chunks_used = std::max(c->chunks_used, 1u);
         c->rtally_clean = true;  // all words were zero before the run, [0, m_pad) are zero again
@@ -1734,16 +1733,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         if (fused) {
             rc = tally_ready();
             if (rc) return rc;
-#ifdef NPS_DIAGNOSTICS
-            // soak / test builds: a consumer that read a partial sum before it was stored would see
-            // NaNs instead of the previous pass's (identical) bits
-            HIP_TRY(hipMemsetAsync(c->d_rds_psum, 0xFF, sizeof(double) * m * plan.P, c->stream));
-#endif
             hipError_t fe;
             {
                 ProfScope ps(c, P_FUSED);
                 fe = launch_ds_fused(c->stream, plan, ds, stride_f, c->n, m, def->d_desc,
-                                     dev_params(c->params), c->d_rtally, c->d_rds_psum, c->d_rstats,
+                                     dev_params(c->params), c->d_rtally, c->d_rstats,
                                      c->d_nloci, c->d_part_fused, c->d_timeout);
             }
             if (fe == hipSuccess) {

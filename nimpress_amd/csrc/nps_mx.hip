@@ -828,7 +828,12 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     if (!plan.given) switch (dbg) {
         case 1: fn = (const void *)fused_mx_kernel<1, false>; break;
         case 2: fn = (const void *)fused_mx_kernel<2, false>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false>; break;
         case 4: fn = (const void *)fused_mx_kernel<4, false>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false>; break;
         case 31: fn = (const void *)fused_mx_kernel<31, false>; break;
         default: break;
         }

@@ -702,6 +702,54 @@ def test_ds_fused_all_imputation_modes(pk):
     assert rel_err(scores, ref_scores, sub["beta"], max(nloci, 1)) <= REL_TOL
 
 
+def test_ds_fused_range_and_small_sums():
+    """The single-read DS kernel hands the slices' dosage sums over as fixed-point integers and needs 0 <= DS <= 2 (the
+    FORMAT/DS convention): a value outside fails the pass with NPS_E_INVAL (sticky until nps_reset) instead of
+    corrupting the tally fields; NPS_MODE_TWOPASS takes any value.  Rows whose whole dosage sum is tiny (one sample
+    at 0.001, the rest 0; all samples at 2^-20) keep their sum to 1e-9 relative."""
+    n, m = 20000, 8
+    rng = np.random.default_rng(5)
+    ds = np.round(rng.uniform(0.0, 2.0, size=(m, n)), 3).astype(np.float32)
+    ds[rng.uniform(size=(m, n)) < 0.02] = np.nan
+    ds[1, :] = 0.0
+    ds[1, 777] = 0.001
+    ds[2, :] = np.float32(2.0 ** -20)
+    ds[3, :] = 2.0
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    eaf = np.full(m, 0.25)
+    rie = np.zeros(m, np.int32)
+    kw = dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=100)
+    co = dict(n=n, m=m, ds=ds, beta=beta, eaf=eaf, rie=rie)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_DS32)
+    dev.upload(0, ds)
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_FUSED)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    ref_scores, ref_stats, ref_nloci = oracle_ds(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert_ds_stats(stats, ref_stats)
+    assert rel_err(scores, ref_scores, beta, max(nloci, 1)) <= REL_TOL
+    # one value out of range
+    bad = ds.copy()
+    bad[5, 12345] = 2.5
+    dev.upload(0, bad)
+    sc.reset()
+    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_FUSED)
+    with pytest.raises(capi.NpsError) as ei:
+        sc.finish(0.0)
+    assert ei.value.status == -1 and "[0, 2]" in str(ei.value)
+    sc.reset()                                          # the bit is sticky until nps_reset
+    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_TWOPASS)
+    two, nloci2 = sc.finish(0.0)
+    co_bad = dict(co, ds=bad)
+    ref_bad, _, ref_nloci_bad = oracle_ds(co_bad, kw, 0.0)
+    assert nloci2 == ref_nloci_bad
+    assert rel_err(two, ref_bad, beta, max(nloci2, 1)) <= REL_TOL
+    sc.close()
+    dev.close()
+
+
 def test_ds_large_fused_equals_twopass_and_scaling():
     """BASELINE.json configs[4] shape (200 000 samples, FORMAT/DS float32, missing rate U(0,0.10) so about
     half the rows exceed --maxmis) on 65 536 rows (52 GB): the single-read fused DS kernel and the

@@ -226,6 +226,37 @@ def test_format_ds_rows_match_oracle(host, tmp_path, monkeypatch, prefer, kind):
         host.nh_vcf_close(h)
 
 
+@pytest.mark.parametrize("kind", ["text", "bcf"])
+def test_format_ds_outside_the_dosage_range_is_refused(host, tmp_path, kind):
+    """a dosage is 0 <= DS <= 2 (the single-read DS kernel's fixed-point tallies rely on it): a record that is scored
+    from DS and holds a value outside is refused when it is read, naming the record; the same value in a DS that is
+    NOT used (the record has GT, NIMPRESS_FORMAT unset) is not even looked at"""
+    import bcfwriter
+    bad = DS_VCF.replace("0.25\t.\t2\t1.5", "0.25\t.\t2.5\t1.5")             # the DS-only record 1:200
+    unused = DS_VCF.replace("0/1:1.004", "0/1:7.5")                              # 1:100 has GT: its DS is not used
+    for name, text, ok in (("bad", bad, False), ("unused", unused, True)):
+        vpath = str(tmp_path / (name + ".vcf"))
+        open(vpath, "w").write(text)
+        path = vpath
+        if kind == "bcf":
+            # (the oracle's reader is the fixture writer's source here; it does not police the range)
+            rd, rg = refcpu.read_vcf(vpath, prefer_ds=True), refcpu.read_vcf(vpath, prefer_ds=False)
+            recs = [dict(contig=a.contig, pos=a.pos, id=".", ref=a.ref, alts=a.alts,
+                         filters=[] if a.filt == "." else a.filt.split(";"),
+                         gts=None if b.gts is None else np.asarray(b.gts).reshape(4, b.ploidy), ds=a.ds)
+                    for a, b in zip(rd.records, rg.records)]
+            path = str(tmp_path / (name + ".bcf"))
+            bcfwriter.write_bcf(path, ["1"], ["A", "B", "C", "D"], recs, gt_dtype=np.int8)
+        h = host.nh_vcf_open(path.encode(), None)
+        if ok:
+            assert h, host.nh_last_error()
+            host.nh_vcf_close(h)
+        else:
+            assert not h
+            msg = host.nh_last_error().decode()
+            assert "outside [0, 2]" in msg and "1:200" in msg, msg
+
+
 def test_vcf_reader_plain_text_phased_haploid(host, tmp_path):
     p = tmp_path / "t.vcf"
     p.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\n"
