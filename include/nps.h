@@ -216,9 +216,9 @@ void nps_destroy(nps_ctx *ctx);
 /* float32 dosages, NaN = missing, variant-major / sample-minor.  A dosage is 0 <= DS <= 2 (the FORMAT/DS convention
  * for a diploid sample; the host readers refuse a file that breaks it).  The single-read kernel (NPS_MODE_FUSED, and
  * NPS_MODE_AUTO where the shape allows it) relies on that range: it hands the slices' dosage sums over as fixed-point
- * integers (order-independent, bit-reproducible).  A resident value outside [0, 2] makes nps_flush / nps_finish of
- * that run return NPS_E_INVAL (sticky until nps_reset); NPS_MODE_TWOPASS and the streamed nps_push_ds rows take any
- * finite value. */
+ * integers (order-independent, bit-reproducible).  nps_cohort_upload checks the rows it receives; while a cohort
+ * holds a value outside [0, 2], NPS_MODE_AUTO scores it with the two-pass kernels and NPS_MODE_FUSED returns
+ * NPS_E_INVAL.  NPS_MODE_TWOPASS and the streamed nps_push_ds rows take any finite value. */
 #define NPS_FMT_DS32 1
 /* 2-bit codes in the layout of the multi-score (matrix-core) path: superblocks of 128 rows x groups of 32
  * samples, 16 ROWS of one sample per 32-bit word; carries its whole-row tallies.  Filled by

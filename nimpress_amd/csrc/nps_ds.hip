@@ -292,6 +292,30 @@ hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stri
     return hipGetLastError();
 }
 
+// one workgroup per row: does the row hold a value that is neither missing (NaN) nor a dosage (0 <= DS <= 2)?
+__global__ __launch_bounds__(256) void ds_range_kernel(const float *__restrict__ ds, uint64_t stride_f, uint64_t n,
+                                                       unsigned char *__restrict__ bad) {
+    const float *row = ds + (uint64_t)blockIdx.x * stride_f;
+    bool b = false;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = row[i];
+        b |= v == v && !(v >= 0.0f && v <= 2.0f);
+    }
+    const int any = __syncthreads_or(b ? 1 : 0);
+    if (threadIdx.x == 0) bad[blockIdx.x] = any ? 1 : 0;
+}
+
+hipError_t launch_ds_range_check(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n, uint64_t n_rows,
+                                 unsigned char *d_bad) {
+    if (n_rows == 0) return hipSuccess;
+    (void)hipGetLastError();
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += 1u << 30) {
+        const uint64_t k = std::min<uint64_t>(1u << 30, n_rows - r0);
+        hipLaunchKernelGGL(ds_range_kernel, dim3((uint32_t)k), dim3(256), 0, st, d_ds + r0 * stride_f, stride_f, n, d_bad + r0);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
                            uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss) {

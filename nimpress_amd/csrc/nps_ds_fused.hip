@@ -21,8 +21,10 @@
 //     or re-reads per-slice partial sums (rounds 1-3: an sc1 store, a drained queue, then the arrival, and P
 //     loads + a tree sum on the other side: 11 % of the pass).  Two phases later the control wave looks at the
 //     pair until both counts say P and derives the row's parameters.  One workgroup barrier per batch.
-//     Range: FORMAT/DS values are dosages, 0 <= DS <= 2 (validated on ingest; a value outside raises the
-//     context's NPS_STATUS_DS_RANGE bit and the pass fails -- the bound is what keeps the fields apart).
+//     Range: FORMAT/DS values are dosages, 0 <= DS <= 2: the bound is what keeps the fields of the words apart.  It is
+//     checked where a cohort is filled (nps_cohort_upload: ds_range_kernel; the generator clips), never in this loop
+//     (a check on the data waves cost 15 % of the pass): a cohort that holds a value outside is scored by the
+//     two-pass kernels.
 //
 // Semantics are the build-defined DS extension of the oracle (ref_raw_dosages_ds): NaN = missing,
 // effect allele == REF -> dosage = 2 - DS.  The row's dosage sum is formed as sum(DS) and turned into
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
             }
             if (valid) {
                 const double x = s * a.scale;
-                // (a slice holds < 2^14 of dosage, F <= 46; anything else is a value outside [0, 2]: flagged by the data waves)
+                // (a slice holds < 2^14 of dosage, F <= 46; cohorts with values outside [0, 2] never get here)
                 const unsigned long long S = x >= 0.0 && x < 9.0e18 ? (unsigned long long)__double2ll_rn(x) : 0ull;
                 __hip_atomic_fetch_add(&a.tally[2 * row], (1ull << 56) | ((S >> 32) << 28) | (unsigned long long)cnt,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -326,14 +328,6 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         for (int r = 0; r < R; ++r) {
             uint32_t cnt = 0;
             double s = 0.0;
-            // a dosage is 0 <= DS <= 2 (maxNum / minNum skip the NaNs): anything else fails the pass
-            const float hi = fmaxf(fmaxf(fmaxf(src[r * 8], src[r * 8 + 1]), fmaxf(src[r * 8 + 2], src[r * 8 + 3])),
-                                   fmaxf(fmaxf(src[r * 8 + 4], src[r * 8 + 5]), fmaxf(src[r * 8 + 6], src[r * 8 + 7])));
-            const float lo = fminf(fminf(fminf(src[r * 8], src[r * 8 + 1]), fminf(src[r * 8 + 2], src[r * 8 + 3])),
-                                   fminf(fminf(src[r * 8 + 4], src[r * 8 + 5]), fminf(src[r * 8 + 6], src[r * 8 + 7])));
-            if (__any(hi > 2.0f || lo < 0.0f)) {
-                if (lane == 0) __hip_atomic_store(a.timeout + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
 #pragma unroll
             for (int e = 0; e < kDsPerThread; ++e) {
                 const float v = src[r * 8 + e];

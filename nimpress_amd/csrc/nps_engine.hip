@@ -69,6 +69,10 @@ struct nps_cohort {
     size_t push_cap = 0;
     int push_next = 0;
     unsigned long long *d_push_tally = nullptr;  // scratch word for the decode kernel's tally (a GT2 cohort keeps none)
+    // NPS_FMT_DS32: rows that hold a value outside [0, 2] (checked when rows are uploaded; the generator clips): while
+    // there is one, the cohort is scored by the two-pass kernels (the single-read kernel's fixed-point tallies need the range)
+    std::vector<unsigned char> ds_row_bad;
+    uint64_t ds_bad_rows = 0;
 };
 
 static int cohort_quiesce(const nps_cohort *c) {
@@ -831,10 +835,6 @@ static int check_status(nps_ctx *c) {
     if (c->h_result[1] & 1ull)
         return fail(NPS_E_TIMEOUT, "fused kernel: a bounded inter-workgroup wait expired; the scores "
                                    "of this context are invalid (nps_reset and retry in NPS_MODE_TWOPASS)");
-    if (c->h_result[1] & 2ull)
-        return fail(NPS_E_INVAL, "a FORMAT/DS value of the resident cohort lies outside [0, 2]: the single-read DS "
-                                 "kernel hands dosage sums over in fixed point and needs that range; the scores of "
-                                 "this context are invalid (nps_reset; NPS_MODE_TWOPASS takes any value)");
     return NPS_OK;
 }
 
@@ -1237,6 +1237,20 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (c->format == NPS_FMT_GT2X) return gt2x_transfer(c, row0, nrows, const_cast<void *>(host_rows), host_stride, true);
     HIP_TRY(hipMemcpy2D((char *)c->d_data + row0 * c->stride_bytes, c->stride_bytes, host_rows,
                         host_stride, width, nrows, hipMemcpyHostToDevice));
+    // the range of a dosage, row by row, where the rows now lie (one read at upload time, none when scoring)
+    unsigned char *d_bad = nullptr;
+    HIP_TRY(hipMalloc(&d_bad, nrows));
+    std::vector<unsigned char> bad(nrows);
+    hipError_t e = launch_ds_range_check(nullptr, (const float *)c->d_data + row0 * (c->stride_bytes / 4), c->stride_bytes / 4,
+                                         c->n_samples, nrows, d_bad);
+    if (e == hipSuccess) e = hipMemcpy(bad.data(), d_bad, nrows, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "range check of the uploaded dosages failed: %s", hipGetErrorString(e));
+    if (c->ds_row_bad.size() != c->n_rows) c->ds_row_bad.assign(c->n_rows, 0);
+    for (uint64_t r = 0; r < nrows; ++r) {
+        c->ds_bad_rows += (uint64_t)bad[r] - (uint64_t)c->ds_row_bad[row0 + r];
+        c->ds_row_bad[row0 + r] = bad[r];
+    }
     return NPS_OK;
 }
 
@@ -1565,6 +1579,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             c->plan_valid = true;
         }
         if (env_u64("NPS_DISABLE_FUSED", 0) == 1 && mode == NPS_MODE_AUTO) plan.ok = false;
+        if (is_ds && co->ds_bad_rows) {  // a dosage outside [0, 2] somewhere in the cohort: the two-pass kernels take any value
+            if (mode == NPS_MODE_FUSED)
+                return fail(NPS_E_INVAL, "%llu row(s) of the cohort hold FORMAT/DS values outside [0, 2]: the single-read DS "
+                            "kernel hands dosage sums over in fixed point and needs that range (NPS_MODE_AUTO / "
+                            "NPS_MODE_TWOPASS score such a cohort in two reads)", (unsigned long long)co->ds_bad_rows);
+            plan.ok = false;
+        }
         if (!plan.ok && mode == NPS_MODE_FUSED)
             return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the fused "
                         "persistent grid", (unsigned long long)c->n, (unsigned long long)m);

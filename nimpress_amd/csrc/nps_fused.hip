@@ -468,9 +468,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ pa
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
     for (uint64_t j = i; j < n_tally; j += nthreads) tally[j] = 0ull;
     if (i == 0 && timeout) {
-        if (timeout[0]) atomicOr(status, 1ull);
-        if (timeout[1]) atomicOr(status, 2ull);  // ds_fused_kernel: a dosage outside [0, 2]
-        timeout[0] = timeout[1] = 0u;
+        if (*timeout) atomicOr(status, 1ull);
+        *timeout = 0u;
     }
     if (i >= n) return;
     double s = 0.0;

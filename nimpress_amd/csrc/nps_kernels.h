@@ -193,7 +193,10 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
                            DevParams prm, unsigned long long *d_tally /* [n_rows][2], zero */,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
-                           unsigned int *d_timeout /* [0] bounded wait expired, [1] a dosage outside [0, 2] */);
+                           unsigned int *d_timeout);
+// per row of a float32 dosage matrix: d_bad[r] = 1 when a value that is not NaN lies outside [0, 2]
+hipError_t launch_ds_range_check(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n, uint64_t n_rows,
+                                 unsigned char *d_bad);
 hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_bytes, uint64_t n,
                                   int ploidy, int eaidx, float *d_out);
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,

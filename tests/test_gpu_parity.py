@@ -704,9 +704,10 @@ def test_ds_fused_all_imputation_modes(pk):
 
 def test_ds_fused_range_and_small_sums():
     """The single-read DS kernel hands the slices' dosage sums over as fixed-point integers and needs 0 <= DS <= 2 (the
-    FORMAT/DS convention): a value outside fails the pass with NPS_E_INVAL (sticky until nps_reset) instead of
-    corrupting the tally fields; NPS_MODE_TWOPASS takes any value.  Rows whose whole dosage sum is tiny (one sample
-    at 0.001, the rest 0; all samples at 2^-20) keep their sum to 1e-9 relative."""
+    FORMAT/DS convention).  nps_cohort_upload checks the rows it receives: while the cohort holds a value outside,
+    NPS_MODE_FUSED is refused (NPS_E_INVAL) and NPS_MODE_AUTO / NPS_MODE_TWOPASS score it with the two-pass kernels,
+    which take any value; uploading the row again with good values lifts the mark.  Rows whose whole dosage sum is
+    tiny (one sample at 0.001, the rest 0; all samples at 2^-20) keep their sum to 1e-9 relative."""
     n, m = 20000, 8
     rng = np.random.default_rng(5)
     ds = np.round(rng.uniform(0.0, 2.0, size=(m, n)), 3).astype(np.float32)
@@ -735,17 +736,22 @@ def test_ds_fused_range_and_small_sums():
     bad[5, 12345] = 2.5
     dev.upload(0, bad)
     sc.reset()
-    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_FUSED)
     with pytest.raises(capi.NpsError) as ei:
-        sc.finish(0.0)
+        sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_FUSED)
     assert ei.value.status == -1 and "[0, 2]" in str(ei.value)
-    sc.reset()                                          # the bit is sticky until nps_reset
-    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_TWOPASS)
-    two, nloci2 = sc.finish(0.0)
     co_bad = dict(co, ds=bad)
     ref_bad, _, ref_nloci_bad = oracle_ds(co_bad, kw, 0.0)
-    assert nloci2 == ref_nloci_bad
-    assert rel_err(two, ref_bad, beta, max(nloci2, 1)) <= REL_TOL
+    for mode in (capi.MODE_AUTO, capi.MODE_TWOPASS):    # the refused call left the context usable
+        sc.reset()
+        sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, mode)
+        two, nloci2 = sc.finish(0.0)
+        assert nloci2 == ref_nloci_bad
+        assert rel_err(two, ref_bad, beta, max(nloci2, 1)) <= REL_TOL
+    dev.upload(5, ds[5:6])                              # the row again, in range: single read again
+    sc.reset()
+    sc.score_cohort(dev, capi.row_descs(beta, eaf, None, rie), 0, capi.MODE_FUSED)
+    again, nloci3 = sc.finish(0.0)
+    assert nloci3 == ref_nloci and np.array_equal(again, scores, equal_nan=True)
     sc.close()
     dev.close()
 
