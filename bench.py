@@ -76,56 +76,14 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run
 def spawn_ranks(n, timeout_s):
-    """Start the N rank processes (this process never touches a GPU), wait for them, pass on the
-    highest exit code.  Rank 0 inherits stdout, so its JSON line is this command's JSON line.  Every rank's
-    stderr is kept (rank 0: inherited; the others: a file each, replayed with a rank prefix when a rank fails or
-    the run times out).  A run that exceeds `timeout_s` is killed as a whole and exits with status 124."""
-    import tempfile
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs, errs = [], []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        ef = None if r == 0 else tempfile.TemporaryFile(mode="w+")
-        errs.append(ef)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=ef))
-    rc = 0
-    deadline = time.monotonic() + timeout_s
-    try:
-        pending = list(procs)
-        while pending:
-            for p in list(pending):
-                code = p.poll()
-                if code is None:
-                    continue
-                pending.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:  # a rank died: the others would wait in a collective for ever
-                        q.terminate()
-            if pending and time.monotonic() > deadline:
-                sys.stderr.write("bench.py: %d rank(s) still running after %.0f s: killing the run\n" % (len(pending), timeout_s))
-                rc = rc or 124
-                for q in pending:
-                    q.kill()
-                break
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        if rc:
-            for r, ef in enumerate(errs):
-                if ef is not None:
-                    ef.seek(0)
-                    tail = ef.read()[-4000:]
-                    if tail.strip():
-                        sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in tail.splitlines()))
-    sys.exit(rc)
+    """Start the N rank processes (this process never touches a GPU), wait for them with a deadline, pass on the highest
+    exit code (nimpress_amd/launch.py; importing it loads no GPU library)."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nps_launch", os.path.join(ROOT, "nimpress_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    launch.spawn_ranks(__file__, sys.argv[1:], n, timeout_s, name="bench.py")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -631,17 +589,61 @@ def config2_e2e(tmpdir):
     cli = os.path.join(ROOT, "nimpress_amd", "nimpress")
     wood = os.path.join(ROOT, "tests", "golden", "scores", "wood-25282103-height.scores")
     path, n_rec, n = config2.write_cohort(tmpdir, wood, level=1)[:3]
-    best = None
+    best, breakdown = None, None
     for _ in range(2):
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "--afmisp=0", wood, path], capture_output=True, text=True)
+        r = subprocess.run([cli, "--afmisp=0", wood, path], capture_output=True, text=True,
+                           env=dict(os.environ, NIMPRESS_TIMINGS="1"))
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": r.stderr[-300:]}
-        best = dt if best is None else min(best, dt)
-    return {"config2_e2e_s": best, "genotypes_per_s": n_rec * n / best, "records": n_rec, "samples": n,
-            "workload": "nimpress --afmisp=0 wood-25282103-height.scores cohort.bcf (100 000 samples, "
-                        "int8 GT, CSI random access), process start to exit, best of 2"}
+        if best is None or dt < best:
+            best, breakdown = dt, timings_line(r.stderr, "nimpress_timings")
+    gt_bytes = 2 * n_rec * n                                   # int8 FORMAT/GT bytes of the records scored
+    out = {"config2_e2e_s": best, "genotypes_per_s": n_rec * n / best, "records": n_rec, "samples": n,
+           "workload": "nimpress --afmisp=0 wood-25282103-height.scores cohort.bcf (100 000 samples, "
+                       "int8 GT, CSI random access), process start to exit, best of 2"}
+    if breakdown:
+        # the HIP context comes up on its own thread beside open + inflate + parse: hip_init_s is its duration,
+        # hip_init_wait_s what of it the run had to wait for; process_start_s = what the process spent outside the listed stages
+        listed = sum(breakdown[k] for k in ("hip_init_wait_s", "open_s", "inflate_parse_s", "push_s", "kernel_s",
+                                            "warnings_s", "write_s"))
+        breakdown["process_start_and_exit_s"] = best - listed
+        out["breakdown"] = breakdown
+        stage = breakdown["inflate_parse_s"] + breakdown["push_s"]
+        out["ingest_stage_GBps"] = gt_bytes / stage / 1e9 if stage > 0 else None
+    return out
+
+
+def timings_line(stderr_text, key):
+    """the one-line JSON object {key: {...}} a run printed on stderr (NIMPRESS_TIMINGS=1 / score_many.py --timings)"""
+    for line in stderr_text.splitlines():
+        if line.startswith("{") and key in line:
+            try:
+                return json.loads(line)[key]
+            except ValueError:
+                pass
+    return None
+
+
+def matrices_equal(path_a, path_b, rel=1e-6):
+    """two samples x scores TSVs: same sample names, same NaN positions, values within `rel` relative (floored at 1e-12
+    of the column's mean magnitude): (ok, max relative difference)"""
+    a = [l.split("\t") for l in open(path_a).read().split("\n") if l]
+    b = [l.split("\t") for l in open(path_b).read().split("\n") if l]
+    if len(a) != len(b) or any(x[0] != y[0] or len(x) != len(y) for x, y in zip(a, b)):
+        return False, float("inf")
+    va = np.array([[float(v) for v in x[1:]] for x in a])
+    vb = np.array([[float(v) for v in x[1:]] for x in b])
+    if not np.array_equal(np.isnan(va), np.isnan(vb)):
+        return False, float("inf")
+    ok = ~np.isnan(va)
+    if not ok.any():
+        return True, 0.0
+    floor = 1e-12 * np.nanmean(np.abs(va), axis=0, keepdims=True)
+    d = np.abs(va - vb) / np.maximum(np.abs(va), np.maximum(floor, 1e-300))
+    worst = float(np.nanmax(np.where(ok, d, 0.0)))
+    return bool(worst <= rel), worst
 
 
 def config4_e2e(tmpdir, n=500_000):
@@ -658,25 +660,36 @@ def config4_e2e(tmpdir, n=500_000):
     out = {"workload": "tools/score_many.py --gpus 1 --afmisp=0 <8 score files> union.bcf (%d samples, %d records, "
                        "int8 GT, CSI random access), process start to the samples x scores matrix written" % (n, len(recs)),
            "score_files": len(files), "records": len(recs), "samples": n}
-    res = {}
+    res, brk = {}, {}
     for label, extra in (("per_file", []), ("one_pass", ["--one-pass"])):
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1", "--afmisp=0",
-                                "--out", os.path.join(tmpdir, label + ".tsv")] + extra + files + [path],
+                                "--timings", "--out", os.path.join(tmpdir, label + ".tsv")] + extra + files + [path],
                                capture_output=True, text=True)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
-            best = dt if best is None else min(best, dt)
+            if best is None or dt < best:
+                best, brk[label] = dt, timings_line(r.stderr, "score_many_timings")
         res[label] = best
-    a = open(os.path.join(tmpdir, "per_file.tsv")).read().split("\n")
-    b = open(os.path.join(tmpdir, "one_pass.tsv")).read().split("\n")
-    same_rows = len(a) == len(b) and all(x.split("\t")[0] == y.split("\t")[0] for x, y in zip(a, b))
+    # the two matrices, value by value (1e-6 relative: the one-pass weights are 49-bit fixed point)
+    same, worst = matrices_equal(os.path.join(tmpdir, "per_file.tsv"), os.path.join(tmpdir, "one_pass.tsv"))
     out.update({"e2e_s": res["one_pass"], "per_file_e2e_s": res["per_file"],
                 "one_pass_vs_per_file": res["per_file"] / res["one_pass"],
-                "ingest_GBps": gt_bytes / res["one_pass"] / 1e9, "outputs_have_the_same_samples": bool(same_rows)})
+                "ingest_GBps_end_to_end": gt_bytes / res["one_pass"] / 1e9,
+                "outputs_equal_within_1e-6_relative": bool(same), "outputs_max_relative_difference": worst})
+    b = brk.get("one_pass")
+    if b:
+        # python_start_s: interpreter start until score_many's first line; hip_init_s runs on a thread of its own beside
+        # open + inflate + parse, hip_init_wait_s is what of it the run waited for
+        b["python_start_and_exit_s"] = res["one_pass"] - b["total_in_process_s"]
+        out["breakdown"] = b
+        stage = b["inflate_parse_s"] + b["push_s"]
+        out["ingest_stage_GBps"] = gt_bytes / stage / 1e9 if stage > 0 else None
+    if not same:
+        out["error"] = "the one-pass matrix differs from the file-by-file matrix (max relative difference %g)" % worst
     return out
 
 

@@ -131,6 +131,11 @@ int nps_abi_version(void);
 const char *nps_last_error(void);
 /* number of HIP devices visible (0 when there is none; never initialises a device) */
 int nps_device_count(void);
+/* Create the HIP context of `device` and load the library's code object now rather than inside the first call that
+ * needs them (half a second of a cold process).  Thread-safe; meant to be called from a thread of its own while the
+ * caller opens, inflates and parses its input files (the host layer does: DESIGN.md section 9, f1).  Has no effect
+ * on results; NPS_E_NODEVICE without a GPU. */
+int nps_warmup(int device);
 
 /* ---- streaming scorer: one call per score row, in score-file order --------------------- */
 

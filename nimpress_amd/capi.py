@@ -49,7 +49,7 @@ ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
 
 # every symbol include/nps.h declares (tests/test_capi_symbols.py checks the two lists agree)
 SYMBOLS = [
-    "nps_abi_version", "nps_last_error", "nps_device_count", "nps_create", "nps_push_gt",
+    "nps_abi_version", "nps_last_error", "nps_device_count", "nps_warmup", "nps_create", "nps_push_gt",
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
     "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",

@@ -1,6 +1,7 @@
 // main.cpp -- the `nimpress` command line (reference: src/nimpress.nim:652-757, docopt-driven).
 // Same usage text, options, defaults, version string, exit codes and output format; the work is
 // done by computePolygenicScores (nimpress_host.cpp) on top of libnps (HIP, MI355X).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +143,15 @@ int cliMain(int argc, char **argv) {
         return 1;
     }
 
+    int device = 0;
+    if (const char *d = getenv("NIMPRESS_DEVICE")) device = atoi(d);
+    // the HIP context and libnps's code object come up on a thread of their own while the files are opened, inflated
+    // and parsed (joined inside computePolygenicScores, before its first libnps call, and here on every other way out)
+    warmupStart(device);
+    struct Join {
+        ~Join() { warmupJoin(); }
+    } join_on_exit;
+    const auto t_start = std::chrono::steady_clock::now();
     try {
         ScoreFile scoreFile;
         const bool score_ok = scoreFile.open(positional[0]);
@@ -175,12 +185,22 @@ int cliMain(int argc, char **argv) {
                 log.fatal("Could not open coverage BED file " + opt["--cov"]);
         }
         std::vector<double> scores;
-        int device = 0;
-        if (const char *d = getenv("NIMPRESS_DEVICE")) device = atoi(d);
+        const double t_open = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         computePolygenicScores(scores, scoreFile, vcf, restrict, cov, iml, imm, ims, maxMissingRate,
                                afMismatchPthresh, mincs, ignorefilt, log, device);
+        const auto t_write0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < scores.size(); ++i)  // nim:752-753
             printf("%s\t%s\n", vcf.samples[i].c_str(), formatFloat(scores[i]).c_str());
+        if (getenv("NIMPRESS_TIMINGS")) {  // where the run's time went, one JSON line on stderr (bench.py reads it)
+            fflush(stdout);
+            const Timings &t = timings();
+            fprintf(stderr,
+                    "{\"nimpress_timings\": {\"hip_init_s\": %.4f, \"hip_init_wait_s\": %.4f, \"open_s\": %.4f, "
+                    "\"inflate_parse_s\": %.4f, \"push_s\": %.4f, \"kernel_s\": %.4f, \"warnings_s\": %.4f, "
+                    "\"write_s\": %.4f}}\n",
+                    t.hip_init, t.hip_init_wait, t_open - t.inflate_parse, t.inflate_parse, t.push, t.kernels, t.warnings,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_write0).count());
+        }
     } catch (const std::exception &ex) {
         fprintf(stderr, "Error: unhandled exception: %s\n", ex.what());
         return 1;

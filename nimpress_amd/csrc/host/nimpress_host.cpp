@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,37 @@
 #include "../../../include/nps.h"
 
 namespace nimpress {
+
+// ---- where the time goes, and the HIP context on a thread of its own ------------------------------------
+static Timings g_timings;
+Timings &timings() { return g_timings; }
+void timingsReset() { g_timings = Timings(); }
+static double nowSeconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct Tick {  // adds the scope's wall time to one of the Timings fields
+    double &acc;
+    double t0;
+    explicit Tick(double &a) : acc(a), t0(nowSeconds()) {}
+    ~Tick() { acc += nowSeconds() - t0; }
+};
+static std::thread g_warm_thread;
+static double g_warm_seconds = 0.0;
+void warmupStart(int device) {
+    if (g_warm_thread.joinable()) return;
+    g_warm_seconds = 0.0;
+    g_warm_thread = std::thread([device]() {
+        const double t0 = nowSeconds();
+        (void)nps_warmup(device);  // (an error shows up again, with its message, in the run's first libnps call)
+        g_warm_seconds = nowSeconds() - t0;
+    });
+}
+void warmupJoin() {
+    if (!g_warm_thread.joinable()) return;
+    Tick t(g_timings.hip_init_wait);
+    g_warm_thread.join();
+    g_timings.hip_init += g_warm_seconds;
+}
 
 // ------------------------------------------------------------------------------------------
 // small text helpers with Nim stdlib semantics
@@ -1155,6 +1187,7 @@ static void fetchRange(const IndexedSource &src, const ScoreEntry *first, size_t
 }
 
 static std::vector<Variant> fetchParallel(const IndexedSource &src, const ScoreEntry *first, size_t count) {
+    Tick tick(g_timings.inflate_parse);
     const unsigned nt = hostThreads(count);
     std::vector<std::map<uint64_t, Variant>> parts(nt);
     if (nt <= 1) {
@@ -1632,8 +1665,9 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                             ImputeMethodMissing imputeMethodMissing,
                             ImputeMethodSample imputeMethodSample, double maxMissingRate,
                             double afMismatchPthresh, int64_t minGtForInternalImput,
-                            bool ignoreFilterField, Log &log, int device, uint64_t *nloci_out) {
+                            bool ignoreFilterField, Log &log, int device, uint64_t *nloci_out, double *d_scores_out) {
     const int64_t nsamples = genotypeVcf.n_samples();
+    warmupJoin();
     nps_params p;
     p.imp_locus = (int32_t)imputeMethodLocus;
     p.imp_missing = (int32_t)imputeMethodMissing;
@@ -1674,6 +1708,7 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                 fetched = genotypeVcf.fetch(entries.data() + w0, w1 - w0);
                 index.build(fetched);
             }
+            Tick tick_push(g_timings.push);  // (locating the records is in here too: a hash lookup per row)
             for (size_t j = w0; j < w1; ++j) {
                 const ScoreEntry &e = entries[j];
                 const int rie = e.refseq == e.easeq ? 1 : 0;
@@ -1772,7 +1807,14 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
         }
         scores.assign((size_t)nsamples, 0.0);
         uint64_t nloci = 0;
-        npsCheck(nps_finish(ctx, scoreFile.offset, scores.data(), &nloci), "nps_finish");
+        {
+            Tick tick(g_timings.kernels);
+            if (d_scores_out)  // the scores stay on the device (a multi-GPU gather reads them there)
+                npsCheck(nps_finish_device(ctx, scoreFile.offset, d_scores_out, &nloci), "nps_finish_device");
+            else
+                npsCheck(nps_finish(ctx, scoreFile.offset, scores.data(), &nloci), "nps_finish");
+        }
+        if (d_scores_out) scores.clear();
         if (nloci_out) *nloci_out = nloci;
     } catch (...) {
         nps_destroy(ctx);
@@ -1786,8 +1828,9 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                                  ImputeMethodLocus imputeMethodLocus, ImputeMethodMissing imputeMethodMissing,
                                  ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
                                  int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs, int device,
-                                 std::vector<uint64_t> *nloci_out, int shard, int n_shards, bool partial) {
+                                 std::vector<uint64_t> *nloci_out, int shard, int n_shards, bool partial, double *d_out) {
     if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("computePolygenicScoresMulti: bad shard");
+    warmupJoin();
     const size_t S = scoreFiles.size();
     const int64_t nsamples = genotypeVcf.n_samples();
     scores.assign(S, std::vector<double>());
@@ -1887,6 +1930,7 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                             break;
                         }
                 }
+                Tick tick(g_timings.push);
                 if (v->is_bed)
                     npsCheck(nps_cohort_push_bed(gt2, j, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0), "nps_cohort_push_bed");
                 else
@@ -1895,6 +1939,7 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             }
         }
         fetched.clear();
+        double t_kernels0 = nowSeconds();
         npsCheck(nps_cohort_create(&gt2m, device, (uint64_t)nsamples, (uint64_t)U, NPS_FMT_GT2M), "nps_cohort_create");
         npsCheck(nps_cohort_convert(gt2m, gt2), "nps_cohort_convert");
         nps_cohort_destroy(gt2);
@@ -1933,13 +1978,19 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             std::vector<double> offs(ns), flat(ns * (size_t)std::max<int64_t>(nsamples, 1));
             std::vector<uint64_t> nl(ns, 0);
             for (size_t s = 0; s < ns; ++s) offs[s] = scoreFiles[s0 + s]->offset;
-            if (partial)
+            double *d_dst = d_out ? d_out + s0 * (size_t)nsamples : nullptr;  // [S][nsamples] on the device
+            if (d_dst && partial)
+                npsCheck(nps_multi_partial_device(msc, d_dst, nl.data()), "nps_multi_partial_device");
+            else if (d_dst)
+                npsCheck(nps_multi_finish_device(msc, offs.data(), d_dst, nl.data()), "nps_multi_finish_device");
+            else if (partial)
                 npsCheck(nps_multi_partial(msc, flat.data(), nl.data()), "nps_multi_partial");
             else
                 npsCheck(nps_multi_finish(msc, offs.data(), flat.data(), nl.data()), "nps_multi_finish");
             for (size_t s = 0; s < ns; ++s) {
-                scores[s0 + s].assign(flat.begin() + (ptrdiff_t)(s * (size_t)nsamples),
-                                      flat.begin() + (ptrdiff_t)((s + 1) * (size_t)nsamples));
+                if (!d_dst)
+                    scores[s0 + s].assign(flat.begin() + (ptrdiff_t)(s * (size_t)nsamples),
+                                          flat.begin() + (ptrdiff_t)((s + 1) * (size_t)nsamples));
                 if (nloci_out) (*nloci_out)[s0 + s] = nl[s];
             }
             nps_multi_destroy(msc);
@@ -1948,7 +1999,9 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
             mdef = nullptr;
         }
 
+        g_timings.kernels += nowSeconds() - t_kernels0;
         // ---- the reference's warnings, per file in its own row order (nim:527-579), from the rows' tallies
+        Tick tick_warn(g_timings.warnings);
         for (size_t s = 0; s < S; ++s) {
             Log &log = logs[s];
             const ScoreFile &sf = *scoreFiles[s];
@@ -2181,21 +2234,65 @@ long nh_vcf_find_ds(void *h, const char *contig, long pos, const char *ref, cons
 // whole run (needs a GPU): the reference's main() minus printing.  Returns the number of samples,
 // or < 0 on error (nh_last_error).  scores_out has room for cap doubles; warnings (newline separated)
 // go to log_out.
-long nh_compute(const char *score_path, const char *vcf_path, const char *bed_path_or_null,
-                int imp_locus, int imp_missing, int imp_sample, double maxmis, double afmisp,
-                long mincs, int ignorefilt, int device, double *scores_out, long cap,
-                unsigned long long *nloci_out, char *log_out, long log_cap) {
+// the complete log text of the last nh_compute* call of this thread (the caller's log_out buffer may have been too
+// small for it: it then ends at a line end followed by "... log truncated"), and the time breakdown of that call
+static thread_local std::string g_nh_log;
+long nh_last_log_size() { return (long)g_nh_log.size(); }
+long nh_last_log(char *out, long cap) {
+    if (!out || cap <= 0) return -1;
+    const size_t n = std::min(g_nh_log.size(), (size_t)cap - 1);
+    memcpy(out, g_nh_log.data(), n);
+    out[n] = 0;
+    return (long)n;
+}
+static void copyLog(const std::string &all, char *log_out, long log_cap) {
+    g_nh_log = all;
+    if (!log_out || log_cap <= 0) return;
+    if ((long)all.size() < log_cap) {
+        memcpy(log_out, all.c_str(), all.size() + 1);
+        return;
+    }
+    // too small: whole lines only, and say so (nh_last_log has the full text)
+    static const char kMark[] = "... log truncated\n";
+    size_t room = (size_t)log_cap - 1 > sizeof kMark - 1 ? (size_t)log_cap - 1 - (sizeof kMark - 1) : 0;
+    size_t cut = all.rfind('\n', room ? room - 1 : 0);
+    cut = cut == std::string::npos || room == 0 ? 0 : cut + 1;
+    memcpy(log_out, all.data(), cut);
+    const size_t m = std::min(sizeof kMark - 1, (size_t)log_cap - 1 - cut);
+    memcpy(log_out + cut, kMark, m);
+    log_out[cut + m] = 0;
+}
+// out[0..6] = hip_init, hip_init_wait, open, inflate_parse, push, kernels, warnings (seconds) of the last nh_compute* call
+void nh_last_timings(double *out7) {
+    const Timings &t = timings();
+    out7[0] = t.hip_init, out7[1] = t.hip_init_wait, out7[2] = t.open, out7[3] = t.inflate_parse, out7[4] = t.push,
+    out7[5] = t.kernels, out7[6] = t.warnings;
+}
+
+static long nh_compute_impl(const char *score_path, const char *vcf_path, const char *bed_path_or_null,
+                            int imp_locus, int imp_missing, int imp_sample, double maxmis, double afmisp,
+                            long mincs, int ignorefilt, int device, double *scores_out, long cap, double *d_scores_out,
+                            unsigned long long *nloci_out, char *log_out, long log_cap) {
     try {
+        timingsReset();
+        warmupStart(device);  // the HIP context comes up while the files are opened, inflated and parsed
+        struct Join {
+            ~Join() { warmupJoin(); }
+        } join_on_exit;
         ScoreFile sf;
-        if (!sf.open(score_path)) {
-            g_nh_error = std::string("Could not open polygenic score file ") + score_path;
-            return -1;
-        }
         VCF vcf;
-        const bool stream = getenv("NIMPRESS_STREAM") != nullptr;  // the command line always streams
-        if (!((stream && vcf.openStreaming(vcf_path)) || vcf.open(vcf_path, &sf.entries))) {
-            g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
-            return -1;
+        {
+            const double t0 = nowSeconds(), ip0 = timings().inflate_parse;
+            if (!sf.open(score_path)) {
+                g_nh_error = std::string("Could not open polygenic score file ") + score_path;
+                return -1;
+            }
+            const bool stream = getenv("NIMPRESS_STREAM") != nullptr;  // the command line always streams
+            if (!((stream && vcf.openStreaming(vcf_path)) || vcf.open(vcf_path, &sf.entries))) {
+                g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
+                return -1;
+            }
+            timings().open += nowSeconds() - t0 - (timings().inflate_parse - ip0);
         }
         GenomeIntervals cov;
         const bool restrict = bed_path_or_null != nullptr;
@@ -2207,20 +2304,38 @@ long nh_compute(const char *score_path, const char *vcf_path, const char *bed_pa
         uint64_t nloci = 0;
         computePolygenicScores(scores, sf, vcf, restrict, cov, (ImputeMethodLocus)imp_locus,
                                (ImputeMethodMissing)imp_missing, (ImputeMethodSample)imp_sample, maxmis,
-                               afmisp, mincs, ignorefilt != 0, log, device, &nloci);
+                               afmisp, mincs, ignorefilt != 0, log, device, &nloci, d_scores_out);
         if (nloci_out) *nloci_out = nloci;
         for (size_t i = 0; i < scores.size() && (long)i < cap; ++i) scores_out[i] = scores[i];
-        if (log_out && log_cap > 0) {
-            std::string all;
-            for (const std::string &l : log.lines) all += l + "\n";
-            strncpy(log_out, all.c_str(), (size_t)log_cap - 1);
-            log_out[log_cap - 1] = 0;
-        }
-        return (long)scores.size();
+        std::string all;
+        for (const std::string &l : log.lines) all += l + "\n";
+        copyLog(all, log_out, log_cap);
+        return (long)vcf.n_samples();
     } catch (const std::exception &ex) {
         g_nh_error = ex.what();
         return -2;
     }
+}
+
+long nh_compute(const char *score_path, const char *vcf_path, const char *bed_path_or_null,
+                int imp_locus, int imp_missing, int imp_sample, double maxmis, double afmisp,
+                long mincs, int ignorefilt, int device, double *scores_out, long cap,
+                unsigned long long *nloci_out, char *log_out, long log_cap) {
+    return nh_compute_impl(score_path, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp, mincs,
+                           ignorefilt, device, scores_out, cap, nullptr, nloci_out, log_out, log_cap);
+}
+// the same with the n_samples scores left in DEVICE memory (d_scores_out; nps_finish_device): no host bounce before a
+// multi-GPU gather
+long nh_compute_dev(const char *score_path, const char *vcf_path, const char *bed_path_or_null,
+                    int imp_locus, int imp_missing, int imp_sample, double maxmis, double afmisp,
+                    long mincs, int ignorefilt, int device, void *d_scores_out,
+                    unsigned long long *nloci_out, char *log_out, long log_cap) {
+    if (!d_scores_out) {
+        g_nh_error = "nh_compute_dev: d_scores_out is NULL";
+        return -1;
+    }
+    return nh_compute_impl(score_path, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp, mincs,
+                           ignorefilt, device, nullptr, 0, (double *)d_scores_out, nloci_out, log_out, log_cap);
 }
 
 // S score files on one genotype file in ONE pass over the genotypes (computePolygenicScoresMulti).  score_paths:
@@ -2229,8 +2344,15 @@ long nh_compute(const char *score_path, const char *vcf_path, const char *bed_pa
 static long nh_compute_multi_impl(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
                                   int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
                                   int device, int shard, int n_shards, bool partial, double *scores_out, long cap,
-                                  unsigned long long *nloci_out, double *offsets_out, char *log_out, long log_cap) {
+                                  unsigned long long *nloci_out, double *offsets_out, char *log_out, long log_cap,
+                                  double *d_out = nullptr) {
     try {
+        timingsReset();
+        warmupStart(device);  // the HIP context comes up while the files are opened, inflated and parsed
+        struct Join {
+            ~Join() { warmupJoin(); }
+        } join_on_exit;
+        const double t_open0 = nowSeconds();
         std::vector<std::string> paths = splitChar(score_paths, '\n');
         std::vector<ScoreFile> files(paths.size());
         std::vector<const ScoreFile *> ptrs;
@@ -2252,6 +2374,7 @@ static long nh_compute_multi_impl(const char *score_paths, const char *vcf_path,
             g_nh_error = std::string("Could not open input VCF file ") + vcf_path;
             return -1;
         }
+        timings().open += nowSeconds() - t_open0 - timings().inflate_parse;
         GenomeIntervals cov;
         const bool restrict = bed_path_or_null != nullptr;
         std::vector<Log> logs;
@@ -2262,20 +2385,17 @@ static long nh_compute_multi_impl(const char *score_paths, const char *vcf_path,
         std::vector<uint64_t> nloci;
         computePolygenicScoresMulti(scores, ptrs, vcf, restrict, cov, (ImputeMethodLocus)imp_locus,
                                     (ImputeMethodMissing)imp_missing, (ImputeMethodSample)imp_sample, maxmis, afmisp, mincs,
-                                    ignorefilt != 0, logs, device, &nloci, shard, n_shards, partial);
+                                    ignorefilt != 0, logs, device, &nloci, shard, n_shards, partial, d_out);
         for (size_t s = 0; s < scores.size(); ++s) {
             for (size_t i = 0; i < scores[s].size() && (long)i < cap; ++i) scores_out[s * (size_t)cap + i] = scores[s][i];
             if (nloci_out) nloci_out[s] = nloci[s];
         }
-        if (log_out && log_cap > 0) {
-            std::string allt;
-            for (size_t s = 0; s < logs.size(); ++s) {
-                if (!pre.empty()) allt += std::to_string(s) + "\t" + pre + "\n";
-                for (const std::string &l : logs[s].lines) allt += std::to_string(s) + "\t" + l + "\n";
-            }
-            strncpy(log_out, allt.c_str(), (size_t)log_cap - 1);
-            log_out[log_cap - 1] = 0;
+        std::string allt;
+        for (size_t s = 0; s < logs.size(); ++s) {
+            if (!pre.empty()) allt += std::to_string(s) + "\t" + pre + "\n";
+            for (const std::string &l : logs[s].lines) allt += std::to_string(s) + "\t" + l + "\n";
         }
+        copyLog(allt, log_out, log_cap);  // (every line carries its file index: a cut at a line end keeps them apart)
         return (long)vcf.n_samples();
     } catch (const std::exception &ex) {
         g_nh_error = ex.what();
@@ -2303,6 +2423,21 @@ long nh_compute_multi_partial(const char *score_paths, const char *vcf_path, con
     return nh_compute_multi_impl(score_paths, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp,
                                  mincs, ignorefilt, device, shard, n_shards, true, sums_out, cap, nloci_out, offsets_out,
                                  log_out, log_cap);
+}
+
+// the two above with the results left in DEVICE memory: d_out = [S][n_samples] doubles (scores, or with n_shards > 1
+// the block's un-normalised sums for the all-reduce): nps_multi_finish_device / nps_multi_partial_device
+long nh_compute_multi_dev(const char *score_paths, const char *vcf_path, const char *bed_path_or_null, int imp_locus,
+                          int imp_missing, int imp_sample, double maxmis, double afmisp, long mincs, int ignorefilt,
+                          int device, int shard, int n_shards, int partial, void *d_out, unsigned long long *nloci_out,
+                          double *offsets_out, char *log_out, long log_cap) {
+    if (!d_out) {
+        g_nh_error = "nh_compute_multi_dev: d_out is NULL";
+        return -1;
+    }
+    return nh_compute_multi_impl(score_paths, vcf_path, bed_path_or_null, imp_locus, imp_missing, imp_sample, maxmis, afmisp,
+                                 mincs, ignorefilt, device, shard, n_shards, partial != 0, nullptr, 0, nloci_out, offsets_out,
+                                 log_out, log_cap, (double *)d_out);
 }
 
 double nh_dbinom(long x, long n, double p) { return dbinom(x, n, p); }
@@ -2336,23 +2471,30 @@ long nh_write_matrix_tsv(const char *path, const char *names_nl, long n, const d
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const long n_thr = std::max<long>(1, std::min<long>({16, (long)hw, n / 2048 + 1}));
         std::vector<std::string> parts((size_t)n_thr);
+        std::vector<std::exception_ptr> err((size_t)n_thr);  // (an exception must not leave a worker thread: std::terminate)
         auto work = [&](long t) {
-            const long a = n * t / n_thr, b = n * (t + 1) / n_thr;
-            std::string &o = parts[(size_t)t];
-            o.reserve((size_t)(b - a) * (size_t)(16 + 24 * n_scores));
-            for (long i = a; i < b; ++i) {
-                o.append(names[(size_t)i].first, names[(size_t)i].second);
-                for (long k = 0; k < n_scores; ++k) {
-                    o.push_back('\t');
-                    o += formatFloat(scores[k * row_stride + i]);
+            try {
+                const long a = n * t / n_thr, b = n * (t + 1) / n_thr;
+                std::string &o = parts[(size_t)t];
+                o.reserve((size_t)(b - a) * (size_t)(16 + 24 * n_scores));
+                for (long i = a; i < b; ++i) {
+                    o.append(names[(size_t)i].first, names[(size_t)i].second);
+                    for (long k = 0; k < n_scores; ++k) {
+                        o.push_back('\t');
+                        o += formatFloat(scores[k * row_stride + i]);
+                    }
+                    o.push_back('\n');
                 }
-                o.push_back('\n');
+            } catch (...) {
+                err[(size_t)t] = std::current_exception();
             }
         };
         std::vector<std::thread> thr;
         for (long t = 1; t < n_thr; ++t) thr.emplace_back(work, t);
         work(0);
         for (auto &t : thr) t.join();
+        for (const std::exception_ptr &e : err)
+            if (e) std::rethrow_exception(e);  // the first worker's error, after every thread has been joined
         FILE *f = strcmp(path, "-") == 0 ? stdout : fopen(path, "w");
         if (!f) throw std::runtime_error(std::string("cannot open ") + path + ": " + strerror(errno));
         bool ok = true;

@@ -139,6 +139,24 @@ double binomTestFast(int64_t x, int64_t n, double p);  // same value by bisectio
 // Nim's `$float` as the reference prints it: "%.16g" plus ".0" when no '.', 'e', 'n', 'i' appears.
 std::string formatFloat(double x);
 
+// Where a run's wall time went (seconds; what is not listed is process start and output, which the caller sees).
+// Filled by computePolygenicScores[Multi] and by the C hooks around them; reset by timingsReset().
+struct Timings {
+    double hip_init = 0;       // nps_warmup on its own thread: HIP context + code object
+    double hip_init_wait = 0;  // ... of which the run had to wait for (the rest overlapped open + inflate + parse)
+    double open = 0;           // score files, genotype file header, index
+    double inflate_parse = 0;  // BGZF inflate + record parsing (all fetch threads, wall)
+    double push = 0;           // nps_push_* / nps_cohort_push_* calls: pinned copy, PCIe, decode launches
+    double kernels = 0;        // convert + score definitions + scoring + finish, until the scores are there
+    double warnings = 0;       // the reference's per-row warnings (binomial tests) and log text
+};
+Timings &timings();
+void timingsReset();
+// the HIP context and libnps's code object on a thread of their own, while the caller opens and parses its files:
+// start it before the first file is touched, join it (warmupJoin) before the first libnps call
+void warmupStart(int device);
+void warmupJoin();
+
 struct Log {
     std::vector<std::string> lines;  // "WARN ..." / "FATAL ..." in emission order
     bool echo = true;                // also print to stdout like Nim's ConsoleLogger
@@ -155,7 +173,9 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                             ImputeMethodSample imputeMethodSample, double maxMissingRate,
                             double afMismatchPthresh, int64_t minGtForInternalImput,
                             bool ignoreFilterField, Log &log, int device = 0,
-                            uint64_t *nloci_out = nullptr);
+                            uint64_t *nloci_out = nullptr, double *d_scores_out = nullptr);
+// d_scores_out (optional, device memory, n_samples doubles): the scores are left on the device (nps_finish_device)
+// and `scores` comes back empty -- what a multi-GPU gather wants (no host bounce).
 
 // S score files against ONE genotype file in one pass over the genotypes (the reference runs
 // its loop nim:634-641 once per file): the union of the files' loci is located once (findVariant), every located
@@ -170,7 +190,8 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                                  ImputeMethodSample imputeMethodSample, double maxMissingRate, double afMismatchPthresh,
                                  int64_t minGtForInternalImput, bool ignoreFilterField, std::vector<Log> &logs,
                                  int device = 0, std::vector<uint64_t> *nloci_out = nullptr, int shard = 0,
-                                 int n_shards = 1, bool partial = false);
+                                 int n_shards = 1, bool partial = false, double *d_out = nullptr);
+// d_out (optional, device memory, [files][n_samples] doubles): results stay on the device, `scores` stays empty.
 // shard / n_shards / partial: the rows-sharded x all-scores layout over several GPUs.  The
 // union's rows are cut into n_shards contiguous blocks; this call locates, decodes and scores block `shard` only
 // (1 / n_shards of the ingest and of the cohort) for ALL files, and with partial = true returns the state of the

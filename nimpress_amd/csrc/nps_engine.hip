@@ -255,6 +255,21 @@ extern "C" int nps_device_count(void) {
     return n;
 }
 
+static int select_device(int device);
+__global__ void warmup_kernel(unsigned int *p) {
+    if (p) *p = 1u;
+}
+extern "C" int nps_warmup(int device) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipFree(nullptr));  // the primary context
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(warmup_kernel, dim3(1), dim3(1), 0, nullptr, (unsigned int *)nullptr);  // the code object
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return NPS_OK;
+}
+
 static int select_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

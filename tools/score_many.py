@@ -13,11 +13,12 @@ in the reference's float format (nimpress.nim:752-753).  With --gpus N > 1 and n
 (torch.distributed.run) this process starts the N ranks itself, before anything touches a GPU.
 """
 import argparse
+import json
 import os
-import socket
-import subprocess
 import sys
 import time
+
+T_START = time.perf_counter()   # (the interpreter's own start-up is before this: bench.py measures from outside)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,6 +38,11 @@ def parse_args(argv=None):
                          "sum all-reduce of the [files, samples] sums and the per-file locus counts follows (implies "
                          "--one-pass; inputs that path does not cover are an error)")
     ap.add_argument("--out", default="-", help="output TSV (default: stdout)")
+    ap.add_argument("--timings", action="store_true",
+                    help="rank 0 prints one JSON line on stderr saying where the run's time went (imports, HIP context, "
+                         "file open, inflate + parse, push, kernels, warnings, gather, output)")
+    ap.add_argument("--rank-timeout", type=float, default=1800.0,
+                    help="seconds after which a self-started multi-rank run is killed as a whole (exit status 124)")
     ap.add_argument("--cov", default=None)
     ap.add_argument("--imp-locus", default="ps", choices=["ps", "homref", "fail", "ignore"])
     ap.add_argument("--imp-missing", default="homref", choices=["homref", "ignore"])
@@ -52,55 +58,36 @@ def parse_args(argv=None):
     return a
 
 
-def spawn_ranks(n):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    pending = list(procs)
-    try:
-        while pending:
-            for p in list(pending):
-                code = p.poll()
-                if code is None:
-                    continue
-                pending.remove(p)
-                if code != 0:
-                    rc = rc or code
-                    for q in pending:
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    sys.exit(rc)
+def spawn_ranks(n, timeout_s):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nps_launch", os.path.join(ROOT, "nimpress_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    launch.spawn_ranks(__file__, sys.argv[1:], n, timeout_s, name="score_many.py")   # does not return
 
 
 def main(argv=None):
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        spawn_ranks(args.gpus)
+        spawn_ranks(args.gpus, args.rank_timeout)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import numpy as np
     from nimpress_amd import capi, host
     capi.load()
-    if capi.device_count() < 1:
-        sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
+    stamp = {"imports_s": time.perf_counter() - T_START}
     torch = dist = multi = device = None
     # (ranks that share a GPU exist only in tests: NIMPRESS_DIST_BACKEND=gloo, the exchange on CPU tensors)
     backend = os.environ.get("NIMPRESS_DIST_BACKEND", "nccl")
-    local_rank %= capi.device_count()
     if world > 1:   # (one process, one GPU: no exchange, and torch's import is a fifth of such a run)
+        ndev = capi.device_count()
+        if ndev < 1:
+            sys.exit("score_many.py needs an MI355X: libnps has no CPU path")
+        if backend == "nccl" and local_rank >= ndev:
+            sys.exit("score_many.py: LOCAL_RANK %d but only %d GPU(s) visible: one RCCL rank per GPU (start at most %d "
+                     "ranks per node)" % (local_rank, ndev, ndev))
+        local_rank %= ndev   # (only ever wraps for the GPU-sharing test backend)
         import torch
         import torch.distributed as dist
         from nimpress_amd import multi
@@ -111,75 +98,103 @@ def main(argv=None):
         else:
             device = torch.device("cpu")
             dist.init_process_group(backend)
+    # results stay in device memory between the scoring and the exchange when the exchange runs on the GPU (RCCL)
+    on_gpu = world > 1 and backend == "nccl"
     score_files, cohort = args.files[:-1], args.files[-1]
     names = host.sample_names(cohort)
     n = len(names)
+    S = len(score_files)
     logs = {}
+    tim = {k: 0.0 for k in host.TIMING_KEYS}
 
-    def score_file(i):
-        s, nloci, log = host.compute_polygenic_scores(
-            score_files[i], cohort, cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing,
-            imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp,
-            ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1))
+    def took():
+        for k, v in host.last_timings().items():
+            tim[k] += v
+
+    kw = dict(cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing, imp_sample=args.imp_sample,
+              maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp, ignorefilt=args.ignorefilt, device=local_rank,
+              max_samples=max(n, 1))
+
+    def score_file(i, d_out=None):
+        sc, nloci, log = host.compute_polygenic_scores(score_files[i], cohort, d_out=d_out, **kw)
+        took()
         logs[i] = log
-        return s
+        return sc
 
     one_pass_used = False
     t0 = time.perf_counter()
-    cache = {}
+    t_gather = 0.0
     mat = None
     if args.shard == "rows":
         # rows sharded over the GPUs x all files on every GPU: one partial pass, one all-reduce, the normalisation
+        d_sums = torch.zeros((S, n), dtype=torch.float64, device=device) if on_gpu else None
         sums, nl, offs, lg = host.compute_polygenic_scores_multi_partial(
-            score_files, cohort, rank, world, cov=args.cov, imp_locus=args.imp_locus, imp_missing=args.imp_missing,
-            imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs, afmisp=args.afmisp,
-            ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1))
+            score_files, cohort, rank, world, d_out=d_sums.data_ptr() if on_gpu else None, **kw)
+        took()
         for i, lines in enumerate(lg):
             logs[i] = lines
         one_pass_used = True
         if world > 1:
-            t, cnt = multi.all_reduce_partial_matrix(torch.from_numpy(sums).to(device), nl)
+            tg = time.perf_counter()
+            t, cnt = multi.all_reduce_partial_matrix(d_sums if on_gpu else torch.from_numpy(sums).to(device), nl)
             mat = multi.normalize_matrix(t, cnt, offs).cpu().numpy()
+            t_gather = time.perf_counter() - tg
         else:
             with np.errstate(divide="ignore", invalid="ignore"):
                 mat = sums / (nl.astype(np.float64) * 2.0)[:, None] + offs[:, None]
-    elif args.one_pass:
-        mine = list(range(rank, len(score_files), world))
-        try:
-            sc, _nl, lg = host.compute_polygenic_scores_multi(
-                [score_files[i] for i in mine], cohort, cov=args.cov, imp_locus=args.imp_locus,
-                imp_missing=args.imp_missing, imp_sample=args.imp_sample, maxmis=args.maxmis, mincs=args.mincs,
-                afmisp=args.afmisp, ignorefilt=args.ignorefilt, device=local_rank, max_samples=max(n, 1)) if mine else (None, None, [])
-            cache = {i: sc[k] for k, i in enumerate(mine)}
-            for k, i in enumerate(mine):
-                logs[i] = lg[k]
-            one_pass_used = True
-        except capi.NpsError as e:
-            sys.stderr.write("score_many: one-pass path not applicable (%s); scoring file by file\n" % e)
-
-    def row(i):  # scores of file i (from the one pass, if there was one)
-        return cache[i] if i in cache else score_file(i)
-
-    if mat is not None:
-        pass
-    elif world == 1:
-        mat = np.empty((len(score_files), n), dtype=np.float64)
-        for i in range(len(score_files)):
-            mat[i] = row(i)
     else:
-        full = multi.evaluate_sharded(len(score_files), n,
-                                      lambda i, out_row: out_row.copy_(torch.from_numpy(row(i)).to(out_row.device)), device)
-        mat = full.cpu().numpy()
+        mine = list(range(rank, S, world))
+        # this rank's rows of the matrix, in shard order: on the GPU when the gather runs there
+        local = None if world == 1 else torch.empty((len(mine), n), dtype=torch.float64, device=device)
+        done = set()
+        if args.one_pass and mine:
+            try:
+                sc, _nl, lg = host.compute_polygenic_scores_multi(
+                    [score_files[i] for i in mine], cohort, d_out=local.data_ptr() if on_gpu else None, **kw)
+                took()
+                for k, i in enumerate(mine):
+                    logs[i] = lg[k]
+                    if local is not None and not on_gpu:
+                        local[k].copy_(torch.from_numpy(sc[k]))
+                done = set(mine)
+                one_pass_used = True
+                if world == 1:
+                    mat = sc
+            except capi.NpsError as e:
+                sys.stderr.write("score_many: one-pass path not applicable (%s); scoring file by file\n" % e)
+        if mat is None and world == 1:
+            mat = np.empty((S, n), dtype=np.float64)
+            for i in range(S):
+                mat[i] = score_file(i)
+        elif world > 1:
+            for k, i in enumerate(mine):
+                if i in done:
+                    continue
+                if on_gpu:
+                    score_file(i, d_out=local[k].data_ptr())   # nps_finish_device writes the gather's send buffer
+                else:
+                    local[k].copy_(torch.from_numpy(score_file(i)))
+            tg = time.perf_counter()
+            mat = multi.gather_scores(local, S).cpu().numpy()
+            t_gather = time.perf_counter() - tg
     elapsed = time.perf_counter() - t0
     for i in sorted(logs):
         for line in logs[i]:
             sys.stderr.write("[%s] %s\n" % (os.path.basename(score_files[i]), line))
     if rank == 0:
+        tw = time.perf_counter()
         host.write_matrix_tsv(args.out, names, mat)   # the reference's float format, 16 threads in C++
+        t_write = time.perf_counter() - tw
         sys.stderr.write("score_many: %d score files x %d samples on %d GPU(s) in %.2f s%s\n"
-                         % (len(score_files), n, world, elapsed,
+                         % (S, n, world, elapsed,
                             " (rows sharded over the GPUs, all files per GPU in one pass)" if args.shard == "rows" else
                             " (one pass over the genotypes)" if one_pass_used else ""))
+        if args.timings:
+            out = {"imports_s": stamp["imports_s"], "sample_names_s": t0 - T_START - stamp["imports_s"]}
+            out.update(tim)
+            out.update({"gather_s": t_gather, "write_s": t_write, "total_in_process_s": time.perf_counter() - T_START,
+                        "ranks": world, "exchange_on": "gpu (RCCL)" if on_gpu else ("cpu (%s)" % backend if world > 1 else "none")})
+            sys.stderr.write(json.dumps({"score_many_timings": out}) + "\n")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
