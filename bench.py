@@ -66,6 +66,13 @@ def parse_args():
     ap.add_argument("--no-optimize", action="store_true",
                     help="skip nps_cohort_optimize (the parity layout of the high-bit planes: the table lookups "
                          "spread over twice as many LDS banks)")
+    ap.add_argument("--no-multi-legs", action="store_true",
+                    help="N > 1: skip the two strong-scaling legs that follow the headline (one GT score with its rows "
+                         "sharded over the GPUs = configs[2] at N GPUs; the FORMAT/DS score of configs[4] likewise)")
+    ap.add_argument("--ds-samples", type=int, default=200_000, help="cohort size of the N > 1 FORMAT/DS leg (configs[4])")
+    ap.add_argument("--ds-variants", type=int, default=2_000_000, help="score rows of the N > 1 FORMAT/DS leg (configs[4])")
+    ap.add_argument("--ds-chunk-rows", type=int, default=300_000,
+                    help="resident chunk of the N > 1 FORMAT/DS leg (rows; 300 000 x 200 000 float32 = 240 GB)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20250103)
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
@@ -236,6 +243,83 @@ def score_delta(stats, got, nloci, fmt, beta, eaf, seed, n, m, th, tm, tmi, geom
                        "rows scored by oracle/refcpu.c (ref_score_subset); whole-row tallies of %d random "
                        "rows recounted over all %d samples" % (samples.size, n_cols, n_slices, slices, teams,
                                                                m, rows.size, n)}
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1: the other two north-star curves, measured by ALL ranks right after the headline (none of them is `value`)
+def strong_scaling_leg(torch, dist, multi, capi, args, rank, world, device, fmt, n, m, seed, chunk_rows, steps,
+                       cohort=None):
+    """ONE score whose rows are sharded over the GPUs (second layout): rank r holds all samples of its
+    block of rows, so tallies stay local and exact; the one exchange is the RCCL sum all-reduce of the partial sums and
+    of nloci, then nimpress.nim:643-649 in place.  fmt = NPS_FMT_GT2X (configs[2] at N GPUs; `cohort` = the
+    headline's resident matrix, of which the rank scores its 128-aligned block where it lies) or NPS_FMT_DS32
+    (configs[4]: the block is generated chunk by chunk on the device, outside the timed segments).  Time = the slowest
+    rank's timed segments (scoring + exchange + normalisation) per pass; value = n m / that."""
+    is_ds = fmt == capi.FMT_DS32
+    beta, eaf, miss = synth_score(m, seed, "ds" if is_ds else "gt")
+    th, tm, tmi = hwe_thresholds(eaf, miss)
+    r0, r1 = multi.shard_rows(m, world, rank, align=128)
+    own = cohort is None
+    chunk = max(1, min(chunk_rows if chunk_rows > 0 else (r1 - r0), max(r1 - r0, 1)))
+    chunks = [(a, min(r1, a + chunk)) for a in range(r0, r1, chunk)]
+    if own:
+        cohort = capi.Cohort(n, chunk, fmt=fmt, device=device)
+    sdefs = [capi.ScoreDef(capi.row_descs(beta[a:b], eaf[a:b]), device=device) for a, b in chunks]
+    sc = capi.Scorer(n, capi.make_params(imp_locus="ps") if is_ds else capi.make_params(), device=device)
+    d = torch.empty(n, dtype=torch.float64, device="cuda")
+    regenerate = own and len(chunks) > 1   # (a block that fits is generated once, before the timed passes)
+
+    def fill(a, b):
+        for x in range(a, b, 1 << 15):
+            y = min(b, x + (1 << 15))
+            cohort.synth_at(x - a, x, seed, th[x:y], tm[x:y], tmi[x:y])
+
+    if own and chunks and not regenerate:
+        fill(*chunks[0])
+
+    def one_pass():
+        sc.reset()
+        seg = 0.0
+        for (a, b), sdef in zip(chunks, sdefs):
+            if regenerate:
+                fill(a, b)
+            sc.sync()
+            t0 = time.perf_counter()
+            sc.score_cohort_def(cohort, sdef, 0 if own else a, capi.MODE_AUTO)
+            sc.sync()
+            seg += time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        nl = sc.partial_device(d.data_ptr())
+        _, nl = multi.all_reduce_partial(d, nl)
+        sc.normalize_device(d.data_ptr(), nl, 0.0)
+        torch.cuda.synchronize()
+        return seg, time.perf_counter() - t0, nl
+
+    if not regenerate:
+        one_pass()   # warm-up (a block that has to be regenerated chunk by chunk is scored once: 1.6 TB of generation per pass)
+    seg = exch = 0.0
+    for _ in range(steps):
+        a_, b_, nloci = one_pass()
+        seg += a_
+        exch += b_
+    t = torch.tensor([seg, exch], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    seg, exch = (float(x) for x in t.tolist())
+    sc.close()
+    for sd in sdefs:
+        sd.close()
+    if own:
+        cohort.close()
+    torch.cuda.empty_cache()
+    per = (seg + exch) / max(steps, 1)
+    return {"workload": "one %s score of %d rows on %d samples, rows sharded x%d (blocks of %d rows, %d resident chunk(s) "
+                        "per GPU) + RCCL all-reduce of sums and nloci" % ("FORMAT/DS" if is_ds else "2-bit GT", m, n, world,
+                                                                          r1 - r0, len(chunks)),
+            "scaling": "strong", "n_gpus": world, "value": float(n) * float(m) / per if per > 0 else 0.0,
+            "unit": "genotype-dosage accumulations/s", "ms_per_pass": per * 1e3, "scoring_ms": seg / max(steps, 1) * 1e3,
+            "exchange_ms": exch / max(steps, 1) * 1e3, "nloci": int(nloci), "passes": steps}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -816,6 +900,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: the two strong-scaling curves of the north star, by all ranks, in this order on every rank
+    multi_legs = None
+    if world > 1 and not args.no_multi_legs and not strong and not is_ds and resident:
+        multi_legs = {"configs2_gt_rows_sharded": strong_scaling_leg(
+            torch, dist, multi, capi, args, rank, world, local_rank, fmt, n, m, args.seed, 0, max(1, min(args.steps, 5)),
+            cohort=cohort)}
+        sc.close()
+        for sd in sdefs:
+            sd.close()
+        cohort.close()      # the DS chunk needs the room
+        torch.cuda.empty_cache()
+        multi_legs["configs4_ds_rows_sharded"] = strong_scaling_leg(
+            torch, dist, multi, capi, args, rank, world, local_rank, capi.FMT_DS32, args.ds_samples, args.ds_variants,
+            20250105, args.ds_chunk_rows, 1)
+
     failed = []   # secondary measurements that raised (rank 0): the line is printed, the exit status is 1
     if rank == 0:
         steps = max(args.steps, 1)
@@ -937,6 +1036,8 @@ def main():
 
             leg("config4", config4_leg)
             out["secondary"] = secondary
+        if multi_legs is not None:
+            out["multi_gpu"] = multi_legs
         print(json.dumps(out), flush=True)
         failed += ["parity:" + p for p in parity_failures(out)]
     if world > 1:

@@ -11,12 +11,13 @@ import tempfile
 import time
 
 
-def spawn_ranks(script, argv, n, timeout_s, name=None):
+def spawn_ranks(script, argv, n, timeout_s, name=None, inherit_stderr=False):
     """Start ranks 0..n-1 of `script argv` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
     the environment), wait for them, exit with the highest exit code.  Rank 0 inherits stdout and stderr, so its
     output is this command's output.  The other ranks' stderr goes to a file each, replayed with a rank prefix when a
     rank fails or the run times out.  A rank that dies takes the others with it (they would wait in a collective for
-    ever); a run that exceeds `timeout_s` is killed as a whole and exits with status 124."""
+    ever); a run that exceeds `timeout_s` is killed as a whole and exits with status 124.  inherit_stderr: every
+    rank writes to this command's stderr (a tool whose ranks each report on their own share of the work)."""
     name = name or os.path.basename(script)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -26,7 +27,7 @@ def spawn_ranks(script, argv, n, timeout_s, name=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        ef = None if r == 0 else tempfile.TemporaryFile(mode="w+")
+        ef = None if r == 0 or inherit_stderr else tempfile.TemporaryFile(mode="w+")
         errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL, stderr=ef))

@@ -45,7 +45,8 @@ def _rehearse(world, extra):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rehearse_bench.py"), "--gpus",
                                        str(world), "--steps", "2", "--warmup", "1", "--samples", "4000", "--variants",
-                                       "640", "--no-extras", "--no-cpu-baseline"] + extra,
+                                       "640", "--no-extras", "--no-cpu-baseline", "--ds-samples", "3000", "--ds-variants",
+                                       "1000", "--ds-chunk-rows", "256"] + extra,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -61,6 +62,15 @@ def test_bench_two_ranks_weak_scaling_rehearsal():
     assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["ms_per_step"] > 0
     assert d["config"]["parallelism"].startswith("score-sharded x2") and d["config"]["nloci"] == 640
     assert "cpu_baseline" not in d and "secondary" not in d and d["vs_baseline"] is None
+    # the two strong-scaling legs that follow the headline on N > 1 (the other two north-star curves, same command):
+    # configs[2] with the rows of one GT score sharded over the GPUs, configs[4] (FORMAT/DS) likewise, in chunks
+    legs = d["multi_gpu"]
+    gt, ds = legs["configs2_gt_rows_sharded"], legs["configs4_ds_rows_sharded"]
+    assert gt["scaling"] == ds["scaling"] == "strong" and gt["n_gpus"] == ds["n_gpus"] == 2
+    assert gt["nloci"] == 640 and ds["nloci"] == 1000 and gt["value"] > 0 and ds["value"] > 0
+    assert "2 resident chunk(s)" in ds["workload"] and "blocks of 512 rows" in ds["workload"]
+    # every rank contributed partial sums of 1.0: 2.0 / (2 x nloci) after the all-reduce and the normalisation
+    assert abs(d["rehearsal_normalised"][0] - 2.0 / 2000.0) < 1e-15 and d["rehearsal_normalised"][1] == 1000
 
 
 def test_bench_three_ranks_strong_scaling_rehearsal():

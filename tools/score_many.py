@@ -63,7 +63,8 @@ def spawn_ranks(n, timeout_s):
     spec = importlib.util.spec_from_file_location("nps_launch", os.path.join(ROOT, "nimpress_amd", "launch.py"))
     launch = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(launch)
-    launch.spawn_ranks(__file__, sys.argv[1:], n, timeout_s, name="score_many.py")   # does not return
+    # (every rank's warnings -- with --shard rows those of its own block of rows -- go to this command's stderr)
+    launch.spawn_ranks(__file__, sys.argv[1:], n, timeout_s, name="score_many.py", inherit_stderr=True)   # does not return
 
 
 def main(argv=None):
@@ -76,7 +77,7 @@ def main(argv=None):
     import numpy as np
     from nimpress_amd import capi, host
     capi.load()
-    stamp = {"imports_s": time.perf_counter() - T_START}
+    stamp = {"imports_s": time.perf_counter() - T_START}   # numpy, ctypes, dlopen of libnps + the HIP runtime
     torch = dist = multi = device = None
     # (ranks that share a GPU exist only in tests: NIMPRESS_DIST_BACKEND=gloo, the exchange on CPU tensors)
     backend = os.environ.get("NIMPRESS_DIST_BACKEND", "nccl")
