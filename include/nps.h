@@ -166,7 +166,15 @@ int nps_push_gt_raw(nps_ctx *ctx, const void *gt, int elem_bytes, int ploidy, in
  * samples per byte, sample 0 in the low bits, values 0 = hom A1, 1 = missing, 2 = het, 3 = hom A2.
  * effect_is_a1 selects the allele the score row counts (.bim column 5 or 6).  The row is already
  * 2-bit and sample-minor: it is moved as it is and recoded on the device (build-defined extension;
- * the reference reads VCF/BCF only). */
+ * the reference reads VCF/BCF only).
+ * The argument is the row's CODE MAP (NPS_MAP_*): 0 / 1 are the two .bed maps; a fixed-width hard-call record of a
+ * PLINK 2 .pgen file (storage mode 0x02: same packing, the code is the number of ALT alleles, 3 = missing) goes
+ * through the same entry points with NPS_MAP_PGEN_ALT (the score row counts ALT) or NPS_MAP_PGEN_REF (it counts REF:
+ * dosage = 2 - ALT count).  Also the per-row flags of nps_cohort_upload_bed and the flag of nps_cohort_push_bed. */
+#define NPS_MAP_BED_A2 0
+#define NPS_MAP_BED_A1 1
+#define NPS_MAP_PGEN_ALT 2
+#define NPS_MAP_PGEN_REF 3
 int nps_push_bed(nps_ctx *ctx, const uint8_t *bed_row, int effect_is_a1, int ref_is_effect, double beta,
                  double eaf);
 

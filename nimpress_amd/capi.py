@@ -341,7 +341,8 @@ class Scorer:
         bed_row = np.ascontiguousarray(bed_row, dtype=np.uint8)
         if bed_row.size != (self.n + 3) // 4:
             raise ValueError("bed row has %d bytes, expected %d" % (bed_row.size, (self.n + 3) // 4))
-        _check(load().nps_push_bed(self._h, bed_row.ctypes.data, int(bool(effect_is_a1)),
+        # effect_is_a1 is the row's code map (NPS_MAP_*: 0 / 1 .bed effect A2 / A1, 2 / 3 .pgen effect ALT / REF)
+        _check(load().nps_push_bed(self._h, bed_row.ctypes.data, int(effect_is_a1),
                                    int(bool(ref_is_effect)), float(beta), float(eaf)))
 
     def push_ds(self, ds: np.ndarray, ref_is_effect, beta: float, eaf: float):

@@ -1301,12 +1301,41 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
                 FILE *f;
                 ~Closer() { fclose(f); }
             } closer{f};
-            if (magic[2] != 1) throw std::runtime_error("sample-major .bed files are not supported");
+            // byte 3 = storage mode: 0x01 PLINK 1 .bed (variant-major), 0x02 PLINK 2 .pgen with fixed-width hard-call
+            // records (12-byte header: magic, mode, uint32 variants, uint32 samples, one flag byte; then
+            // ceil(N/4) bytes per variant, the 2-bit code = number of ALT alleles, 3 = missing).  Nothing else of
+            // the .pgen family is read (variable-width records, dosages, multi-allelic hard calls).
+            // PARITY UNPINNED: neither plink2 nor the format's specification is in this image; the layout is written
+            // from the published description and pinned only by the build's own writer (tests/pgenwriter.py).
+            const bool pgen = magic[2] == 2;
+            if (magic[2] == 0) throw std::runtime_error("sample-major .bed files are not supported");
+            if (magic[2] != 1 && !pgen)
+                throw std::runtime_error("PLINK 2 .pgen storage mode 0x" + std::string(1, "0123456789abcdef"[magic[2] >> 4]) +
+                                         std::string(1, "0123456789abcdef"[magic[2] & 15]) +
+                                         " is not supported (only 0x02: fixed-width hard calls; plink2 --make-pgen fixed-width, "
+                                         "or convert with --make-bed)");
             std::string prefix = path;
-            if (prefix.size() > 4 && prefix.compare(prefix.size() - 4, 4, ".bed") == 0) prefix.resize(prefix.size() - 4);
+            if (prefix.size() > 4 && (prefix.compare(prefix.size() - 4, 4, ".bed") == 0)) prefix.resize(prefix.size() - 4);
+            if (prefix.size() > 5 && (prefix.compare(prefix.size() - 5, 5, ".pgen") == 0)) prefix.resize(prefix.size() - 5);
             std::string fam, bim;
-            if (!readFile(prefix + ".fam", fam) || !readFile(prefix + ".bim", bim))
+            bool pvar = false, psam = false;
+            if (pgen) {  // .pvar / .psam, or the PLINK 1 .bim / .fam next to the .pgen
+                pvar = readFile(prefix + ".pvar", bim);
+                psam = readFile(prefix + ".psam", fam);
+                if ((!pvar && !readFile(prefix + ".bim", bim)) || (!psam && !readFile(prefix + ".fam", fam)))
+                    throw std::runtime_error("cannot open " + prefix + ".pvar / .psam (or .bim / .fam) next to the .pgen file");
+            } else if (!readFile(prefix + ".fam", fam) || !readFile(prefix + ".bim", bim)) {
                 throw std::runtime_error("cannot open " + prefix + ".fam / .bim next to the .bed file");
+            }
+            size_t header_bytes = 3;
+            uint32_t pgen_m = 0, pgen_n = 0;
+            if (pgen) {
+                unsigned char h[9];
+                if (fread(h, 1, 9, f) != 9) throw std::runtime_error("truncated .pgen header");
+                memcpy(&pgen_m, h, 4);
+                memcpy(&pgen_n, h + 4, 4);
+                header_bytes = 12;
+            }
             auto fields = [](const std::string &line) {
                 std::vector<std::string> out;
                 size_t i = 0;
@@ -1319,26 +1348,59 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
                 }
                 return out;
             };
+            size_t iid_col = 1;  // .fam: FID IID ...; .psam: the column its header line calls IID
             for (const std::string &ln : splitChar(fam, '\n')) {
                 const std::vector<std::string> c = fields(ln);
                 if (c.empty()) continue;
-                if (c.size() < 2) throw std::runtime_error("bad .fam line");
-                samples.push_back(c[1]);  // IID
+                if (psam && c[0][0] == '#') {
+                    if (c[0] == "#IID") iid_col = 0;
+                    else if (c[0] == "#FID") iid_col = 1;
+                    else continue;  // other comment lines
+                    if (iid_col >= c.size() || (iid_col == 1 && c[1] != "IID")) throw std::runtime_error("bad .psam header line");
+                    continue;
+                }
+                if (c.size() <= iid_col) throw std::runtime_error(psam ? "bad .psam line" : "bad .fam line");
+                samples.push_back(c[iid_col]);  // IID
             }
+            if (pgen && pgen_n != samples.size())
+                throw std::runtime_error(".pgen header says " + std::to_string(pgen_n) + " samples, the sample file lists " +
+                                         std::to_string(samples.size()));
             const size_t row_bytes = (samples.size() + 3) / 4;
             size_t row = 0;
+            // .pvar: '##' meta lines, then '#CHROM POS ID REF ALT ...' naming the columns; without that line the file
+            // has the .bim layout (chrom, id, cM, pos, ALT = A1, REF = A2)
+            int col_chrom = 0, col_id = 1, col_pos = 3, col_alt = 4, col_ref = 5;
+            size_t min_cols = 6;
             for (const std::string &ln : splitChar(bim, '\n')) {
                 const std::vector<std::string> c = fields(ln);
                 if (c.empty()) continue;
-                if (c.size() < 6) throw std::runtime_error("bad .bim line");
+                if (pvar && c[0].size() >= 2 && c[0][0] == '#' && c[0][1] == '#') continue;
+                if (pvar && c[0] == "#CHROM") {
+                    col_chrom = 0;
+                    col_id = col_pos = col_alt = col_ref = -1;
+                    for (size_t k = 1; k < c.size(); ++k) {
+                        if (c[k] == "POS") col_pos = (int)k;
+                        if (c[k] == "ID") col_id = (int)k;
+                        if (c[k] == "REF") col_ref = (int)k;
+                        if (c[k] == "ALT") col_alt = (int)k;
+                    }
+                    if (col_pos < 0 || col_ref < 0 || col_alt < 0) throw std::runtime_error(".pvar header line lacks POS / REF / ALT");
+                    min_cols = (size_t)std::max(std::max(col_pos, col_ref), std::max(col_alt, col_id)) + 1;
+                    continue;
+                }
+                if (c.size() < min_cols) throw std::runtime_error(pgen ? "bad .pvar / .bim line" : "bad .bim line");
                 Variant v;
-                v.contig = c[0];
-                v.id = c[1];
-                v.pos = parseIntNim(c[3]);
-                v.ref = c[5];           // A2
-                v.alt.push_back(c[4]);  // A1
+                v.contig = c[(size_t)col_chrom];
+                v.id = col_id >= 0 ? c[(size_t)col_id] : ".";
+                v.pos = parseIntNim(c[(size_t)col_pos]);
+                v.ref = c[(size_t)col_ref];           // .bed: A2; .pgen: REF
+                v.alt.push_back(c[(size_t)col_alt]);  // .bed: A1; .pgen: ALT
+                if (pgen && v.alt[0].find(',') != std::string::npos)
+                    throw std::runtime_error("multi-allelic .pvar record at " + v.contig + ":" + std::to_string(v.pos) +
+                                             ": not representable in fixed-width hard-call records");
                 v.filter = ".";
-                v.is_bed = true;
+                v.is_bed = !pgen;
+                v.is_pgen = pgen;
                 v.gt_bytes = 0;
                 v.ploidy = 2;
                 bool want = !keep;
@@ -1356,9 +1418,9 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
                 if (want) {
                     v.gt_raw.resize(row_bytes);
                     if (row_bytes &&
-                        (fseeko(f, (off_t)(3 + row * row_bytes), SEEK_SET) != 0 ||
+                        (fseeko(f, (off_t)(header_bytes + row * row_bytes), SEEK_SET) != 0 ||
                          fread(v.gt_raw.data(), 1, row_bytes, f) != row_bytes))
-                        throw std::runtime_error("truncated .bed file");
+                        throw std::runtime_error(pgen ? "truncated .pgen file" : "truncated .bed file");
                     records.push_back(std::move(v));
                 }
                 ++row;
@@ -1442,6 +1504,11 @@ int32_t Variant::gtValue(size_t i) const {
         if (code == 1) return 0;                       // missing
         const int n_a1 = code == 0 ? 2 : (code == 2 ? 1 : 0);
         return ((int)(i & 1) < n_a1 ? 2 : 1) << 1;     // (allele + 1) << 1
+    }
+    if (is_pgen) {  // (diploid; the code is the number of ALT alleles, 3 = missing)
+        const unsigned code = (gt_raw[(i / 2) >> 2] >> (((i / 2) & 3) * 2)) & 3u;
+        if (code == 3) return 0;
+        return ((unsigned)(i & 1) < code ? 2 : 1) << 1;
     }
     if (gt_raw.empty()) return gts[i];
     switch (gt_bytes) {
@@ -1744,7 +1811,11 @@ void computePolygenicScores(std::vector<double> &scores, const ScoreFile &scoreF
                             npsCheck(nps_push_ds(ctx, v->dsRow(eaidx, (size_t)nsamples, ds_tmp), rie, e.beta, e.eaf),
                                      "nps_push_ds");
                         else if (v->is_bed)  // the .bed bytes as they stand in the file: recoded on the device
-                            npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0, rie,
+                            npsCheck(nps_push_bed(ctx, v->gt_raw.data(), e.easeq == v->alt[0] ? NPS_MAP_BED_A1 : NPS_MAP_BED_A2,
+                                                  rie, e.beta, e.eaf),
+                                     "nps_push_bed");
+                        else if (v->is_pgen)  // a fixed-width .pgen record: the same bytes, another code map
+                            npsCheck(nps_push_bed(ctx, v->gt_raw.data(), rie ? NPS_MAP_PGEN_REF : NPS_MAP_PGEN_ALT, rie,
                                                   e.beta, e.eaf),
                                      "nps_push_bed");
                         else if (v->gt_bytes == 4 && v->gt_raw.empty())
@@ -1932,7 +2003,11 @@ void computePolygenicScoresMulti(std::vector<std::vector<double>> &scores, const
                 }
                 Tick tick(g_timings.push);
                 if (v->is_bed)
-                    npsCheck(nps_cohort_push_bed(gt2, j, v->gt_raw.data(), e.easeq == v->alt[0] ? 1 : 0), "nps_cohort_push_bed");
+                    npsCheck(nps_cohort_push_bed(gt2, j, v->gt_raw.data(), e.easeq == v->alt[0] ? NPS_MAP_BED_A1 : NPS_MAP_BED_A2),
+                             "nps_cohort_push_bed");
+                else if (v->is_pgen)
+                    npsCheck(nps_cohort_push_bed(gt2, j, v->gt_raw.data(), eaidx == 0 ? NPS_MAP_PGEN_REF : NPS_MAP_PGEN_ALT),
+                             "nps_cohort_push_bed");
                 else
                     npsCheck(nps_cohort_push_gt_raw(gt2, j, v->gtData(), v->gt_raw.empty() ? 4 : v->gt_bytes, v->ploidy, eaidx),
                              "nps_cohort_push_gt_raw");
@@ -2205,7 +2280,7 @@ long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const c
         strncpy(filter, v->filter.c_str(), (size_t)filter_cap - 1);
         filter[filter_cap - 1] = 0;
     }
-    const size_t nval = v->is_bed ? 2 * vcf.samples.size()
+    const size_t nval = v->is_bed || v->is_pgen ? 2 * vcf.samples.size()
                         : v->gt_raw.empty() ? v->gts.size() : v->gt_raw.size() / (size_t)v->gt_bytes;
     for (size_t i = 0; i < nval && (long)i < gts_cap; ++i) gts[i] = v->gtValue(i);
     return (long)(v - vcf.records.data());

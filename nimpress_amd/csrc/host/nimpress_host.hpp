@@ -83,6 +83,10 @@ struct Variant {
     // ref = A2 and alt = {A1} of the .bim line.  A .bim has no notion of REF, so findVariant also
     // accepts a score row whose ref is A1.
     bool is_bed = false;
+    // PLINK 2 .pgen source, storage mode 0x02 only (fixed-width hard calls; build-defined extension, PARITY UNPINNED:
+    // pinned by the build's own writer alone): gt_raw holds the variant's ceil(N/4) record bytes (2-bit code = number
+    // of ALT alleles, 3 = missing), ref / alt = REF / ALT of the .pvar line; findVariant applies the VCF rule.
+    bool is_pgen = false;
     const void *gtData() const { return gt_raw.empty() ? (const void *)gts.data() : (const void *)gt_raw.data(); }
     int32_t gtValue(size_t i) const;  // element i widened like bcf_get_genotypes does
 };

@@ -735,6 +735,7 @@ extern "C" int nps_push_bed(nps_ctx *c, const uint8_t *bed_row, int effect_is_a1
                             double beta, double eaf) {
     if (int urc = check_usable(c)) return urc;
     if (c->n && !bed_row) return fail(NPS_E_INVAL, "bed_row is NULL");
+    if (effect_is_a1 < 0 || effect_is_a1 > NPS_MAP_PGEN_REF) return fail(NPS_E_INVAL, "bad code map %d", effect_is_a1);
     HIP_TRY(hipSetDevice(c->device));
     uint32_t slot;
     int rc = begin_data_row(c, ref_is_effect, beta, eaf, &slot);
@@ -749,7 +750,7 @@ extern "C" int nps_push_bed(nps_ctx *c, const uint8_t *bed_row, int effect_is_a1
         {
             ProfScope ps(c, P_TALLY);
             HIP_TRY(launch_tally_scatter_row(c->stream, reinterpret_cast<const uint32_t *>(c->h_raw[k]), c->n,
-                                             effect_is_a1 ? 1 : 0,
+                                             effect_is_a1,
                                              c->d_codes + (uint64_t)(slot >> 2) * c->stride_words * 4,
                                              slot & 3, c->d_tally + slot));
         }
@@ -1149,6 +1150,8 @@ extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!bed_rows || !effect_is_a1 || row_stride_bytes < width)
         return fail(NPS_E_INVAL, "bad .bed buffer / stride / flags");
+    for (uint64_t r = 0; r < nrows; ++r)
+        if (effect_is_a1[r] > NPS_MAP_PGEN_REF) return fail(NPS_E_INVAL, "row %llu: bad code map %d", (unsigned long long)r, (int)effect_is_a1[r]);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     rc = cohort_unoptimize(c);
@@ -1217,6 +1220,7 @@ extern "C" int nps_cohort_push_gt_raw(nps_cohort *c, uint64_t row, const void *g
 
 extern "C" int nps_cohort_push_bed(nps_cohort *c, uint64_t row, const uint8_t *bed_row, int effect_is_a1) {
     if (c && c->n_samples && !bed_row) return fail(NPS_E_INVAL, "bed_row is NULL");
+    if (effect_is_a1 < 0 || effect_is_a1 > NPS_MAP_PGEN_REF) return fail(NPS_E_INVAL, "bad code map %d", effect_is_a1);
     const size_t bytes = c ? (size_t)((c->n_samples + 3) / 4) : 0;
     int k = 0;
     int rc = cohort_push_prepare(c, row, std::max<size_t>((bytes + 3) / 4 * 4 + 16, 16), &k);
@@ -1226,7 +1230,7 @@ extern "C" int nps_cohort_push_bed(nps_cohort *c, uint64_t row, const uint8_t *b
     memcpy(c->h_push[k], bed_row, bytes);
     const uint64_t sw = c->stride_bytes / 4;
     HIP_TRY(launch_tally_scatter_row(c->push_stream, reinterpret_cast<const uint32_t *>(c->h_push[k]), c->n_samples,
-                                     effect_is_a1 ? 1 : 0, (uint32_t *)c->d_data + (row >> 2) * sw * 4, (int)(row & 3),
+                                     effect_is_a1, (uint32_t *)c->d_data + (row >> 2) * sw * 4, (int)(row & 3),
                                      c->d_push_tally));
     HIP_TRY(hipEventRecord(c->ev_push[k], c->push_stream));
     return NPS_OK;

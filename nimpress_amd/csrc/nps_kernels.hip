@@ -210,7 +210,7 @@ hipError_t launch_tally_packed(hipStream_t st, const uint32_t *d_codes, uint64_t
 // whose effect allele is A2 / A1 (bed_recode below).  grid = chunks of 2048 words; every block adds its part
 // with one 64-bit atomic (`tally` is zero before the first row of a batch slot is pushed, as for the decode
 // kernel)
-static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, bool effect_a1, uint32_t c,
+static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, int map, uint32_t c,
                                                        uint32_t n_words, uint32_t tail_mask);
 
 __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *__restrict__ row,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void tally_scatter_row_kernel(const uint32_t *
         const uint32_t c = c0 + u * 256 + threadIdx.x;
         if (c < n_words) {
             uint32_t x = row[c];  // the staging row is in the C-ABI's bit order
-            if (bed_mode >= 0) x = bed_recode(x, bed_mode != 0, c, n_words, tail_mask);
+            if (bed_mode >= 0) x = bed_recode(x, bed_mode, c, n_words, tail_mask);
             const uint32_t w = word_to_planes(x);
             tally_word(w, cw, cm);
             out_group[(uint64_t)c * 4 + row_in_group] = w;
@@ -257,10 +257,22 @@ hipError_t launch_tally_scatter_row(hipStream_t st, const uint32_t *row, uint64_
 // permutation per code, chosen by which allele the score row counts:
 //   effect = A1:  0->3 (dosage 2)  2->1  3->0  1->2 (missing)   = bitwise NOT
 //   effect = A2:  0->0  2->1  3->3 (dosage 2)  1->2 (missing)   = swap the two bits of every code
-// Bits past the last sample are cleared (the .bed pads the last byte with zeros = hom A1).
-static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, bool effect_a1, uint32_t c,
+// PLINK 2 .pgen fixed-width hard-call records have the same packing with the code = number of ALT alleles
+// (0, 1, 2; 3 = missing):
+//   effect = ALT: 0->0  1->1  2->3 (dosage 2)  3->2 (missing)   = flip the low bit where the high bit is set
+//   effect = REF: 0->3 (dosage 2)  1->1  2->0  3->2 (missing)   = (xnor(h, l), not h)
+// map: NPS_MAP_* (0 .bed A2, 1 .bed A1, 2 .pgen ALT, 3 .pgen REF).  Bits past the last sample are cleared (the
+// files pad the last byte with zeros).
+static __device__ __forceinline__ uint32_t bed_recode(uint32_t w, int map, uint32_t c,
                                                        uint32_t n_words, uint32_t tail_mask) {
-    const uint32_t x = effect_a1 ? ~w : (((w >> 1) & 0x55555555u) | ((w & 0x55555555u) << 1));
+    const uint32_t h = (w >> 1) & 0x55555555u, l = w & 0x55555555u;
+    uint32_t x;
+    switch (map) {
+    case 1: x = ~w; break;
+    case 2: x = w ^ h; break;
+    case 3: x = ((~(h ^ l) & 0x55555555u) << 1) | (~h & 0x55555555u); break;
+    default: x = h | (l << 1); break;
+    }
     return c + 1 == n_words ? (x & tail_mask) : x;
 }
 
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const uint32_t *__
         uint32_t w = 0;
         if (row < k) {
             w = src[row * src_stride_words + c];
-            w = mode ? bed_recode(w, mode[row] != 0, c, n_words, tail_mask)
+            w = mode ? bed_recode(w, (int)mode[row], c, n_words, tail_mask)
                      : (c + 1 == n_words ? (w & tail_mask) : w);
         }
         q[r] = word_to_planes(w);

@@ -108,7 +108,7 @@ def test_cli_defaults_and_warnings():
 
 
 @pytest.mark.parametrize("gt_dtype", [np.int8, np.int16])
-def test_cli_on_bcf_equals_cli_on_vcf(tmp_path, gt_dtype):
+def test_cli_on_bcf_equals_cli_on_vcf_bcf_parity_unpinned(tmp_path, gt_dtype):
     """the fixture re-written as BCF2 (+CSI) by tests/bcfwriter.py: the typed GT vectors go to the
     device as they stand in the file (nps_push_gt_raw); output text identical to the vcf.gz run"""
     import sys
@@ -128,14 +128,18 @@ def test_cli_on_bcf_equals_cli_on_vcf(tmp_path, gt_dtype):
         assert a.stdout == b.stdout
 
 
-def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
-    """the same biallelic calls as text VCF and as a PLINK 1 fileset (.bed/.bim/.fam, A1 = ALT,
-    A2 = REF, and for every third variant the other way round): identical output"""
+def test_cli_on_plink_filesets_equals_cli_on_vcf_pgen_parity_unpinned(tmp_path):
+    """the same biallelic calls as text VCF, as a PLINK 1 fileset (.bed/.bim/.fam, A1 = ALT, A2 = REF, and for every
+    third variant the other way round) and as a PLINK 2 fixed-width .pgen (+ .pvar with and without header line,
+    .psam with and without FID): identical output.  The .pgen reader's conformance is PARITY UNPINNED (see below)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     rng = np.random.default_rng(4)
     n, m = 203, 57
     names = ["I%03d" % i for i in range(n)]
     vcf = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
     bim, bed = [], bytearray(b"\x6c\x1b\x01")
+    pvars, alt_counts, missing = [], [], []
     score = ["t", "", "", "x", "0.05"]
     pos = 100
     for j in range(m):
@@ -153,6 +157,9 @@ def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
         code = np.concatenate([code, np.zeros((-n) % 4, dtype=code.dtype)]).reshape(-1, 4)
         bed += bytes((code[:, 0] | (code[:, 1] << 2) | (code[:, 2] << 4) | (code[:, 3] << 6)).astype(np.uint8))
         bim.append("%s\trs%d\t0\t%d\t%s\t%s" % (contig, j, pos, a1, a2))
+        pvars.append((contig, pos, "rs%d" % j, ref, alt))
+        alt_counts.append(nalt)
+        missing.append(miss)
         if j % 4 != 3:                         # every 4th variant is not in the score
             ea = alt if j % 2 else ref         # effect allele = ALT or REF
             score.append("%s\t%d\t%s\t%s\t%.4f\t%.4f" % (contig, pos, ref, ea, rng.normal(0, 0.1),
@@ -163,6 +170,13 @@ def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
     (tmp_path / "c.bim").write_text("\n".join(bim) + "\n")
     (tmp_path / "c.fam").write_text("".join("F%d %s 0 0 0 -9\n" % (i, nm) for i, nm in enumerate(names)))
     (tmp_path / "s.score").write_text("\n".join(score))
+    # ... and as a PLINK 2 .pgen (storage mode 0x02, fixed-width hard calls) + .pvar + .psam.  PARITY UNPINNED: the
+    # reader is pinned by the build's own writer (tests/pgenwriter.py) alone -- no plink2, no specification and no
+    # .pgen fixture of the reference's exist in this image; what this shows is that the three inputs agree.
+    import pgenwriter
+    pgenwriter.write_pgen(str(tmp_path / "p"), names, pvars, np.array(alt_counts), np.array(missing))
+    pgenwriter.write_pgen(str(tmp_path / "q"), names, pvars, np.array(alt_counts), np.array(missing), pvar_header=False,
+                          psam_fid=True)
     for flags in ([], ["--imp-locus=homref", "--imp-sample=int_fail", "--maxmis=0.1", "--mincs=10"],
                   ["--imp-locus=ignore", "--imp-missing=ignore", "--imp-sample=ps"]):
         a = subprocess.run([CLI, *flags, str(tmp_path / "s.score"), str(tmp_path / "c.bed")],
@@ -172,6 +186,10 @@ def test_cli_on_plink_fileset_equals_cli_on_vcf(tmp_path):
         assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
         assert a.stdout == b.stdout
         assert len(a.stdout.splitlines()) >= n
+        for pg in ("p.pgen", "q.pgen"):
+            c = subprocess.run([CLI, *flags, str(tmp_path / "s.score"), str(tmp_path / pg)], capture_output=True, text=True)
+            assert c.returncode == 0, c.stderr
+            assert c.stdout == b.stdout, pg
 
 
 def test_config2_wood_height_on_100k_sample_bcf(tmp_path):

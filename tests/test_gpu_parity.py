@@ -973,6 +973,46 @@ def codes_to_bed(codes_row, n, effect_is_a1):
     return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
 
 
+def codes_to_pgen(codes_row, n, effect_is_ref):
+    """native 2-bit codes (dosage of the effect allele) -> fixed-width .pgen record bytes (code = ALT count, 3 = missing)"""
+    c = (codes_row[np.arange(n) >> 4] >> ((np.arange(n) & 15) * 2)) & 3     # 0 d0, 1 d1, 3 d2, 2 missing
+    d = np.select([c == 0, c == 1, c == 3], [0, 1, 2], -1)
+    v = np.where(d < 0, 3, (2 - d) if effect_is_ref else d)
+    v = np.concatenate([v, np.zeros((-n) % 4, dtype=v.dtype)]).reshape(-1, 4)
+    return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [1, 7, 16, 1001, 4097])
+def test_pgen_code_maps_streamed_and_resident(n):
+    """NPS_MAP_PGEN_ALT / NPS_MAP_PGEN_REF through nps_push_bed and nps_cohort_upload_bed: a fixed-width .pgen record
+    (2-bit code = number of ALT alleles, 3 = missing) is the .bed path with another code map; rows come back as the
+    native codes they encode and score like them"""
+    m = 23
+    rng = np.random.default_rng(n + 77)
+    co = make_cohort(n, m, 556, rng)
+    is_ref = rng.integers(0, 2, m).astype(np.uint8)
+    rows = np.stack([codes_to_pgen(co["codes"][j], n, is_ref[j]) for j in range(m)])
+    maps = (2 + is_ref).astype(np.uint8)                  # NPS_MAP_PGEN_ALT = 2, NPS_MAP_PGEN_REF = 3
+    kw = PARAM_GRID[0]
+    ref_scores, ref_stats, ref_nloci = refcpu.score_packed(
+        co["codes"], n, np.zeros(m, np.int32), co["rie"], co["beta"], co["eaf"], refcpu.make_params(**kw), 0.5)
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    for j in range(m):
+        sc.push_bed(rows[j], int(maps[j]), co["rie"][j], co["beta"][j], co["eaf"][j])
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.5)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+    dev = capi.Cohort(n, m)
+    dev.upload_bed(0, rows, maps)
+    assert np.array_equal(dev.download(0, m), co["codes"][:, : (n + 15) // 16])
+    with pytest.raises(capi.NpsError):
+        sc.push_bed(rows[0], 4, 0, 0.1, 0.2)              # not a code map
+    sc.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("n", [1, 7, 16, 1001, 4097])
 def test_plink_bed_rows_streamed_and_resident(n):
     m = 23

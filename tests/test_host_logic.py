@@ -534,7 +534,7 @@ def test_fast_binom_test_equals_enumeration(host):
 
 # ---- BCF2 + CSI (fixtures written by tests/bcfwriter.py; no htslib here: parity unpinned) -------------
 @pytest.mark.parametrize("gt_dtype", [np.int8, np.int16, np.int32])
-def test_bcf_reader_matches_vcf_reader_on_set1(host, tmp_path, gt_dtype):
+def test_bcf_reader_matches_vcf_reader_on_set1_bcf_parity_unpinned(host, tmp_path, gt_dtype):
     """the reference's own fixture re-written as BCF: same samples, records, FILTER strings, alleles
     and (widened) GT values as the text reader gives; with the CSI index and by whole-file scan"""
     import bcfwriter
@@ -571,7 +571,7 @@ def test_bcf_reader_matches_vcf_reader_on_set1(host, tmp_path, gt_dtype):
             os.environ.pop("NIMPRESS_NO_INDEX", None)
 
 
-def test_bcf_random_access_multi_block(host, tmp_path):
+def test_bcf_random_access_multi_block_csi_parity_unpinned(host, tmp_path):
     """records larger than a BGZF block, three contigs, IDX= in the header, a long allele (length
     descriptor 15), multi-filter records: CSI access == whole-file scan"""
     import bcfwriter
@@ -765,3 +765,50 @@ def test_ingest_under_sanitizers(tmp_path, san):
         outs.append(out)
     # BCF (int16 vectors) and text VCF give the same widened GT values
     assert outs[0] == outs[1]
+
+
+def test_pgen_fixed_width_reader_vs_writer_parity_unpinned(host, tmp_path):
+    """PLINK 2 .pgen, storage mode 0x02 (fixed-width hard calls) + .pvar + .psam: samples, records and every genotype
+    come back as written (tests/pgenwriter.py); findVariant applies the VCF rule (REF must match, effect allele = REF
+    or ALT); other storage modes and multi-allelic .pvar records are refused with a message.  PARITY UNPINNED: reader
+    and writer are both the build's own (no plink2 / specification / reference fixture in this image)."""
+    import pgenwriter
+    rng = np.random.default_rng(12)
+    n, m = 37, 9
+    names = ["S%02d" % i for i in range(n)]
+    variants = [("2", 100 + 10 * j, "v%d" % j, "AC"[j % 2], "GT"[j % 2]) for j in range(m)]
+    alt = rng.integers(0, 3, size=(m, n))
+    miss = rng.uniform(size=(m, n)) < 0.1
+    for header, fid in ((True, False), (False, True)):
+        prefix = str(tmp_path / ("g%d" % header))
+        pgenwriter.write_pgen(prefix, names, variants, alt, miss, pvar_header=header, psam_fid=fid)
+        h = host.nh_vcf_open((prefix + ".pgen").encode(), None)
+        assert h, host.nh_last_error()
+        assert host.nh_vcf_n_samples(h) == n and host.nh_vcf_n_records(h) == m
+        pos, ploidy = C.c_long(), C.c_int()
+        filt = C.create_string_buffer(16)
+        gts = np.zeros(2 * n, np.int32)
+        for j, (c, p, _, r, a) in enumerate(variants):
+            for ea in (a, r):
+                idx = host.nh_vcf_find(h, c.encode(), p, r.encode(), ea.encode(), C.byref(pos), C.byref(ploidy), filt, 16,
+                                       gts.ctypes.data, 2 * n)
+                assert idx == j and ploidy.value == 2 and filt.value == b"."
+                want = np.zeros((n, 2), np.int32)               # bcf_get_genotypes layout: (allele + 1) << 1, 0 = missing
+                for i in range(n):
+                    if not miss[j, i]:
+                        want[i] = [4 if k < alt[j, i] else 2 for k in range(2)]
+                assert gts.reshape(n, 2).tolist() == want.tolist(), (j, ea)
+            assert host.nh_vcf_find(h, c.encode(), p, a.encode(), r.encode(), None, None, None, 0, None, 0) == -1  # REF differs
+        host.nh_vcf_close(h)
+    # a storage mode the reader does not know
+    raw = bytearray(open(str(tmp_path / "g1.pgen"), "rb").read())
+    raw[2] = 0x10
+    (tmp_path / "x.pgen").write_bytes(bytes(raw))
+    for ext in (".pvar", ".psam"):
+        (tmp_path / ("x" + ext)).write_bytes(open(str(tmp_path / ("g1" + ext)), "rb").read())
+    assert not host.nh_vcf_open(str(tmp_path / "x.pgen").encode(), None)
+    assert "storage mode 0x10" in host.nh_last_error().decode()
+    # a multi-allelic .pvar line
+    pgenwriter.write_pgen(str(tmp_path / "m"), names, [("2", 5, "a", "A", "C,G")], alt[:1], miss[:1])
+    assert not host.nh_vcf_open(str(tmp_path / "m.pgen").encode(), None)
+    assert "multi-allelic" in host.nh_last_error().decode()
