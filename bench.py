@@ -374,8 +374,13 @@ def size_sweep(capi, device, args, seed, steps=3):
             torch.cuda.empty_cache()
             row[label] = r
         sdef.close()
+        auto = capi.Cohort(n, 128, fmt=capi.FMT_GT_AUTO, device=device)   # what nps_cohort_create picks for this size
+        row["NPS_FMT_GT_AUTO_picks"] = "strip_layout_matrix_cores" if auto.fmt == capi.FMT_GT2X else "row_layout_table_lookups"
+        auto.close()
+        row["auto_layout_frac_of_8TBps"] = row[row["NPS_FMT_GT_AUTO_picks"]]["frac_of_8TBps"]
         out.append(row)
-    return {"cases": out, "strip_layout_worst_frac": min(r["strip_layout_matrix_cores"]["frac_of_8TBps"] for r in out)}
+    return {"cases": out, "strip_layout_worst_frac": min(r["strip_layout_matrix_cores"]["frac_of_8TBps"] for r in out),
+            "auto_layout_worst_frac": min(r["auto_layout_frac_of_8TBps"] for r in out)}
 
 
 def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=20250105):

@@ -251,12 +251,19 @@ void nps_destroy(nps_ctx *ctx);
  * are scored in two reads (a tally pass, then the same accumulation with the tallies given); NPS_MODE_FUSED
  * insists on the single read and returns NPS_E_UNSUPPORTED where it cannot be had. */
 #define NPS_FMT_GT2X 3
+/* nps_cohort_create only: a 2-bit cohort in whichever of the two resident layouts is scored in ONE read of the matrix
+ * at this cohort size on this device -- NPS_FMT_GT2X while there is a compute unit per 2048-sample strip (N <= 522 240
+ * on an MI355X), NPS_FMT_GT2 beyond (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
+ * it became; use row offsets that are multiples of 128 (what NPS_FMT_GT2X asks for) and both behave alike towards the
+ * caller (plain rows of NPS_CODE_* codes in and out). */
+#define NPS_FMT_GT_AUTO 4
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
                       int format);
 /* row stride in bytes of the device layout (rows are padded to 256 B) */
 uint64_t nps_cohort_row_stride(const nps_cohort *c);
 uint64_t nps_cohort_n_rows(const nps_cohort *c);
+int nps_cohort_format(const nps_cohort *c); /* NPS_FMT_* (never NPS_FMT_GT_AUTO) */
 /* copy rows [row0,row0+nrows) from host memory laid out with host_stride bytes per row */
 int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
                       size_t host_stride);

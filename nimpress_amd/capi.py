@@ -20,7 +20,7 @@ MISSING = {"homref": 0, "ignore": 1}
 SAMPLE = {"ps": 0, "homref": 1, "fail": 2, "int_ps": 3, "int_fail": 4}
 ROW_PRESENT, ROW_UNCOVERED, ROW_ABSENT, ROW_FILTERED = 0, 1, 2, 3
 REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMIS = range(5)
-FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X = 0, 1, 2, 3
+FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X, FMT_GT_AUTO = 0, 1, 2, 3, 4
 ROW_NOT_IN_SCORE = 4
 MULTI_MAX_SCORES = 8
 MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
@@ -53,7 +53,7 @@ SYMBOLS = [
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
     "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
-    "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows",
+    "nps_destroy", "nps_cohort_create", "nps_cohort_row_stride", "nps_cohort_n_rows", "nps_cohort_format",
     "nps_cohort_upload", "nps_cohort_download", "nps_cohort_synth", "nps_cohort_synth_rows",
     "nps_cohort_optimize",
     "nps_cohort_destroy",
@@ -154,6 +154,8 @@ def load():
     L.nps_cohort_create.argtypes = [C.POINTER(vp), i32, u64, u64, i32]
     L.nps_cohort_row_stride.argtypes = [vp]
     L.nps_cohort_row_stride.restype = u64
+    L.nps_cohort_format.argtypes = [vp]
+    L.nps_cohort_format.restype = C.c_int
     L.nps_cohort_n_rows.argtypes = [vp]
     L.nps_cohort_n_rows.restype = u64
     L.nps_cohort_upload.argtypes = [vp, u64, u64, vp, C.c_size_t]
@@ -214,6 +216,7 @@ class Cohort:
         self._h = C.c_void_p()
         self.n_samples, self.n_rows, self.device, self.fmt = int(n_samples), int(n_rows), device, fmt
         _check(load().nps_cohort_create(C.byref(self._h), device, self.n_samples, self.n_rows, fmt))
+        self.fmt = int(load().nps_cohort_format(self._h))   # (FMT_GT_AUTO has become FMT_GT2X or FMT_GT2)
 
     @property
     def row_stride(self) -> int:

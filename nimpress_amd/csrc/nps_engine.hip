@@ -946,11 +946,20 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
                                  int format) {
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
-    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M && format != NPS_FMT_GT2X)
+    if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M && format != NPS_FMT_GT2X &&
+        format != NPS_FMT_GT_AUTO)
         return fail(NPS_E_INVAL, "unknown cohort format %d", format);
     if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
     int rc = select_device(device);
     if (rc) return rc;
+    if (format == NPS_FMT_GT_AUTO) {
+        // whichever 2-bit layout is scored in ONE read at this cohort size: strips (matrix cores, time independent of the
+        // genotypes) while there is a compute unit per 2048-sample strip, row groups (table lookups; 14 336 samples per
+        // compute unit) beyond that -- on an MI355X up to 522 240 samples and up to about 3.6 million samples
+        MxPlan mp;
+        HIP_TRY(mx_plan(device, n_samples, std::max<uint64_t>(n_rows, 1), false, &mp));
+        format = (n_samples == 0 || (mp.ok && !mp.given)) ? NPS_FMT_GT2X : NPS_FMT_GT2;
+    }
     nps_cohort *c = new (std::nothrow) nps_cohort;
     if (!c) return fail(NPS_E_NOMEM, "out of host memory");
     c->device = device;
@@ -995,6 +1004,7 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
 
 extern "C" uint64_t nps_cohort_row_stride(const nps_cohort *c) { return c ? c->stride_bytes : 0; }
 extern "C" uint64_t nps_cohort_n_rows(const nps_cohort *c) { return c ? c->n_rows : 0; }
+extern "C" int nps_cohort_format(const nps_cohort *c) { return c ? c->format : -1; }
 
 extern "C" void nps_cohort_destroy(nps_cohort *c) {
     if (!c) return;

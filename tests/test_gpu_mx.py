@@ -381,6 +381,32 @@ def test_gt2x_beta_span_plain_relative_bar(mode):
     assert ref[-1] < 1e-12 * ref[0]
 
 
+@pytest.mark.parametrize("n,want", [(3000, capi.FMT_GT2X), (522240, capi.FMT_GT2X), (530000, capi.FMT_GT2)])
+def test_gt_auto_layout_is_the_single_read_one(n, want):
+    """NPS_FMT_GT_AUTO: strips while there is a compute unit per 2048-sample strip, row groups beyond -- either way
+    NPS_MODE_FUSED (one read of the matrix) is accepted and equals the oracle"""
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the expected layouts are those of a 256-CU part")
+    m = 140
+    rng = np.random.default_rng(n)
+    co = make_cohort(n, m, 99, rng)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT_AUTO)
+    assert dev.fmt == want
+    dev.upload(0, co["codes"])
+    kw = PARAM_GRID[0]
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, capi.MODE_FUSED)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.0)
+    sc.close()
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+
+
 def test_gt2x_refusals():
     dev = capi.Cohort(100, 300, fmt=capi.FMT_GT2X)
     sc = capi.Scorer(100, capi.make_params())
