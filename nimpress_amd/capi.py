@@ -110,15 +110,18 @@ def _preload_torch_hip_runtime():
         return
 
 
-def load():
-    """dlopen libnps.so (raises if it has not been built -- there is no fallback)."""
+def load(with_torch: bool = True):
+    """dlopen libnps.so (raises if it has not been built -- there is no fallback).  with_torch=False: the process
+    will never import torch (a one-GPU tool run), so the half second its import takes is not spent on keeping the
+    two libraries on one HIP runtime; loading torch afterwards is then an error of the caller's."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise NpsError(-2, "libnps.so not built (%s); run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` -- the HIP library is the only compute path" % LIB_PATH)
-    _preload_torch_hip_runtime()
+    if with_torch:
+        _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     rts = _hip_runtimes_mapped()
     if len(rts) > 1:

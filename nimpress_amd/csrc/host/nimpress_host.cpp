@@ -2260,6 +2260,24 @@ long nh_vcf_n_samples(void *h) { return (long)((nh_vcf *)h)->vcf.samples.size();
 int nh_vcf_indexed(void *h) { return ((nh_vcf *)h)->vcf.indexed ? 1 : 0; }
 long nh_vcf_n_records(void *h) { return (long)((nh_vcf *)h)->vcf.records.size(); }
 const char *nh_vcf_sample(void *h, long i) { return ((nh_vcf *)h)->vcf.samples[(size_t)i].c_str(); }
+// all sample names, '\n'-separated, in one call (half a million ctypes calls cost a tenth of a second): returns the
+// number of bytes needed (without the terminator); copies when cap is large enough
+long nh_vcf_samples_joined(void *h, char *out, long cap) {
+    const std::vector<std::string> &s = ((nh_vcf *)h)->vcf.samples;
+    size_t need = 0;
+    for (const std::string &x : s) need += x.size() + 1;
+    if (need) --need;
+    if (out && (long)need < cap) {
+        char *p = out;
+        for (size_t i = 0; i < s.size(); ++i) {
+            if (i) *p++ = '\n';
+            memcpy(p, s[i].data(), s[i].size());
+            p += s[i].size();
+        }
+        *p = 0;
+    }
+    return (long)need;
+}
 // returns record index or -1; fills pos, ploidy, filter (copied), gts (cap int32)
 long nh_vcf_find(void *h, const char *contig, long pos, const char *ref, const char *ea, long *rec_pos,
                  int *ploidy, char *filter, long filter_cap, int *gts, long gts_cap) {

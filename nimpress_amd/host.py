@@ -56,6 +56,8 @@ def load():
         L.nh_vcf_open_header.argtypes = [C.c_char_p]
         L.nh_vcf_sample.restype = C.c_char_p
         L.nh_vcf_sample.argtypes = [C.c_void_p, C.c_long]
+        L.nh_vcf_samples_joined.restype = C.c_long
+        L.nh_vcf_samples_joined.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.nh_format_float.restype = None
         L.nh_format_float.argtypes = [C.c_double, C.c_char_p, C.c_long]
         L.nh_write_matrix_tsv.restype = C.c_long
@@ -212,7 +214,12 @@ def sample_names(vcf_path: str) -> List[str]:
     if not h:
         raise capi.NpsError(-1, "cannot open %s: %s" % (vcf_path, L.nh_last_error().decode("utf-8", "replace")))
     try:
-        return [L.nh_vcf_sample(h, i).decode() for i in range(L.nh_vcf_n_samples(h))]
+        if L.nh_vcf_n_samples(h) == 0:
+            return []
+        need = L.nh_vcf_samples_joined(h, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        L.nh_vcf_samples_joined(h, buf, need + 1)
+        return buf.raw[:need].decode().split("\n")
     finally:
         L.nh_vcf_close(h)
 

@@ -76,7 +76,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import numpy as np
     from nimpress_amd import capi, host
-    capi.load()
+    capi.load(with_torch=world > 1)   # (one process, one GPU: torch is never imported -- its import is a third of such a run)
     stamp = {"imports_s": time.perf_counter() - T_START}   # numpy, ctypes, dlopen of libnps + the HIP runtime
     torch = dist = multi = device = None
     # (ranks that share a GPU exist only in tests: NIMPRESS_DIST_BACKEND=gloo, the exchange on CPU tensors)
