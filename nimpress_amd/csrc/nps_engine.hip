@@ -158,7 +158,8 @@ struct nps_ctx {
     unsigned int *d_timeout = nullptr;      // bounded-wait flag of the fused kernels (cleared by fold_kernel)
     float *d_mx_cpart = nullptr;            // NPS_FMT_GT2X runs: digit sums handed from fused_mx_kernel to mx_fold_kernel
     uint64_t mx_cpart_cap = 0;              // floats
-    double *d_mx_const = nullptr;           // ... and the locus constants of rows over --maxmis (zero between passes)
+    double *d_mx_const = nullptr;           // ... and the locus constants of rows over --maxmis: [8 scratch][2 Q slots], zero between passes
+    uint64_t mx_const_cap = 0;
     unsigned long long *d_mx_tally1 = nullptr;  // first-stage tally words (groups of 16 strips), zero between passes
     uint64_t mx_tally1_cap = 0;
     bool mx_plan_valid = false, mx_plan_two_pass = false;
@@ -1653,9 +1654,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (is_mx && c->n) {
         rc = grow(c, (void **)&c->d_mx_cpart, &c->mx_cpart_cap, mxp.cpart_floats, sizeof(float));
         if (rc) return rc;
-        if (!c->d_mx_const) {
-            HIP_TRY(hipMalloc(&c->d_mx_const, 256));
-            HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, 256, c->stream));
+        if (8 + 2ull * mxp.Q > c->mx_const_cap) {
+            rc = grow(c, (void **)&c->d_mx_const, &c->mx_const_cap, 8 + 2ull * mxp.Q, sizeof(double));
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double) * c->mx_const_cap, c->stream));
         }
         const uint64_t need1 = (uint64_t)((mxp.P + 15) / 16) * m_pad;
         if (need1 > c->mx_tally1_cap) {
@@ -1734,7 +1736,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             runs.push_back(Run{def->d_desc, def->mx_bound});
         else
             for (const auto &mb : def->mx_bands) runs.push_back(Run{mb.d_desc, mb.bound});
-        unsigned long long *scratch_nloci = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(c->d_mx_const) + 64);
+        unsigned long long *scratch_nloci = reinterpret_cast<unsigned long long *>(c->d_mx_const);  // (the 8 scratch doubles)
+        double *const_slots = c->d_mx_const + 8;
         for (size_t b = 0; b < runs.size(); ++b) {
             // fixed-point scale: every weight of the band below 2^56 (fourteen hexadecimal digits)
             int F = 56;
@@ -1756,7 +1759,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                      runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
                                      c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
-                                     c->d_mx_const, c->d_mx_cpart, c->d_timeout);
+                                     const_slots, c->d_mx_cpart, c->d_timeout);
             }
             if (fe != hipSuccess) {
                 (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
@@ -1766,10 +1769,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             guard.armed = true;
             {
                 ProfScope ps(c, P_REDUCE);
-                HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, c->d_mx_const, c->d_part,
+                HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, const_slots, c->d_part,
                                        c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
                                        (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1));
-                HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double), c->stream));
+                HIP_TRY(hipMemsetAsync(const_slots, 0, sizeof(double) * 2 * mxp.Q, c->stream));
             }
             c->chunks_used = std::max(c->chunks_used, 1u);
             c->rtally_clean = true;

@@ -275,7 +275,7 @@ struct MxPlan {
 };
 // two_pass: plan the tally + accumulate pair whatever the shape (NPS_MODE_TWOPASS)
 hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pass, MxPlan *plan);
-// d_tally: [n_sb*128] zeroed; d_tally1: [ceil(P/16)][n_sb*128] zeroed (both are zero again after launch_mx_fold); d_cpart: [plan.cpart_floats]; d_const_sum: one double, zero on entry; d_pre: 32 bytes
+// d_tally: [n_sb*128] zeroed; d_tally1: [ceil(P/16)][n_sb*128] zeroed (both are zero again after launch_mx_fold); d_cpart: [plan.cpart_floats]; d_const_sum: 2 * plan.Q doubles, zero on entry (the caller zeroes them again after launch_mx_fold); d_pre: 32 bytes
 // per row (scratch, written by the pass's first launch);
 // t_maxmis: largest nmissing with !((double)nmissing / (double)N > --maxmis); F: fixed-point scale 2^F with
 // |beta| (4 + max(2, 2 |eaf|)) 2^F < 2^56 for every row

@@ -69,7 +69,9 @@ struct MxArgs {
     unsigned long long *tally1;  // [groups of 16 strips][n_sb * 128], zero on entry: first stage of the hand-over
     nps_locus_stat *stats;
     unsigned long long *nloci;
-    double *const_sum;       // += the locus constants of rows over --maxmis (added to every sample by mx_fold_kernel)
+    double *const_sum;       // [2 Q], zero on entry: slot 2 team + control wave = the locus constants of that wave's rows over
+                             // --maxmis (plain stores; mx_fold_kernel adds the slots in fixed order: bit-reproducible whatever
+                             // order the teams finish in, which a float atomicAdd per team was not)
     float *cpart;            // [n_flush][Q][P][64][2][256]
     unsigned int *timeout;
 };
@@ -513,7 +515,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
         if (lane == 0) {
             if (nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
-            if (cst_local != 0.0) atomicAdd(a.const_sum, cst_local);  // (NaN != 0 is true)
+            if (cst_local != 0.0) a.const_sum[2 * team + (wave - 6)] = cst_local;  // (NaN != 0 is true)
         }
     }
 }
@@ -549,6 +551,13 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
         if (*timeout) atomicOr(status, 1ull);
         *timeout = 0u;
     }
+    __shared__ double s_const;
+    if (threadIdx.x == 0) {  // the teams' locus constants, in slot order (the host zeroes the slots after this launch)
+        double c = 0.0;
+        for (uint32_t q = 0; q < 2 * Q; ++q) c += const_sum[q];
+        s_const = c;
+    }
+    __syncthreads();
     if (i >= n) return;
     const uint64_t strip = i >> 11;
     const uint32_t unit = (uint32_t)(i >> 5) & 63u, s = (uint32_t)i & 31u;
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
             isnan_ = isnan_ || t[15 * 4] != 0.f;
         }
     }
-    double r = total * inv_scale + *const_sum;
+    double r = total * inv_scale + s_const;
     if (isnan_) r = __longlong_as_double(0x7ff8000000000000ll);
     part0[i] = overwrite ? r : part0[i] + r;
 }

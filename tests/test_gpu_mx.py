@@ -123,6 +123,34 @@ def test_gt2x_two_pass_mode_vs_oracle(shape):
     assert np.allclose(one[both], scores[both], rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.parametrize("shape,mode", [((70000, 4000), capi.MODE_FUSED), ((3000, 60000), capi.MODE_FUSED),
+                                        ((70000, 4000), capi.MODE_TWOPASS)])
+def test_gt2x_row_teams_bit_reproducible(shape, mode):
+    """several row teams per strip, many rows over --maxmis in every team (their locus constants are float64 sums): 30
+    passes give the same bits -- the teams' constants are added in slot order, not in the order the teams finish
+    (a float atomicAdd per team was not reproducible: found by tools/soak.py in round 4)"""
+    n, m = shape
+    rng = np.random.default_rng(5 + n)
+    co = make_cohort(n, m, 4243, rng)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    sdef = capi.ScoreDef(capi.row_descs(co["beta"], co["eaf"], None, co["rie"]))
+    sc = capi.Scorer(n, capi.make_params(**PARAM_GRID[0]))
+    first = None
+    for k in range(30):
+        sc.reset()
+        sc.score_cohort_def(dev, sdef, 0, mode)
+        scores, nloci = sc.finish(0.25)
+        if first is None:
+            first = scores.copy()
+            assert np.isfinite(first).all() and nloci == m
+        else:
+            assert np.array_equal(scores.view(np.int64), first.view(np.int64)), "pass %d differs" % k
+    sc.close()
+    sdef.close()
+    dev.close()
+
+
 def test_gt2x_fused_mode_refused_beyond_resident_grid():
     n, m = 530000, 130
     dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)

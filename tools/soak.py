@@ -26,6 +26,7 @@ ap.add_argument("--format", default="gt")
 ap.add_argument("--samples", type=int, default=500_000)
 ap.add_argument("--variants", type=int, default=200_000)
 ap.add_argument("--passes", type=int, default=1000)
+ap.add_argument("--mode", type=int, default=2, help="mode of the soaked passes: 2 single read (default), 0 auto, 1 two reads")
 a = ap.parse_args()
 n, m = a.samples, a.variants
 _, eaf, miss = bench.synth_score(m, 7)
@@ -106,7 +107,7 @@ if is_strip:
 for k in range(a.passes):
     j = k & 1
     sc.reset()
-    sc.score_cohort_def(co, defs[j], 0, capi.MODE_FUSED)
+    sc.score_cohort_def(co, defs[j], 0, a.mode)
     nloci = sc.finish_device(0.0, d.data_ptr())     # raises on NPS_E_TIMEOUT
     cur = d.clone()
     twopass, ref_nloci, first = refs[j]
