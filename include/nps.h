@@ -251,9 +251,10 @@ void nps_destroy(nps_ctx *ctx);
  * are scored in two reads (a tally pass, then the same accumulation with the tallies given); NPS_MODE_FUSED
  * insists on the single read and returns NPS_E_UNSUPPORTED where it cannot be had. */
 #define NPS_FMT_GT2X 3
-/* nps_cohort_create only: a 2-bit cohort in whichever of the two resident layouts is scored in ONE read of the matrix
- * at this cohort size on this device -- NPS_FMT_GT2X while there is a compute unit per 2048-sample strip (N <= 522 240
- * on an MI355X), NPS_FMT_GT2 beyond (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
+/* nps_cohort_create only: a 2-bit cohort in whichever of the two resident layouts is scored fastest in ONE read of the
+ * matrix at this cohort size on this device -- NPS_FMT_GT2X where its grid (P = ceil(N / 2048) strips x floor(CUs / P)
+ * row teams) covers at least nine tenths of the compute units (on an MI355X: N <= 262 144 and about 470 000 <= N <=
+ * 522 240), NPS_FMT_GT2 otherwise (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
  * it became; use row offsets that are multiples of 128 (what NPS_FMT_GT2X asks for) and both behave alike towards the
  * caller (plain rows of NPS_CODE_* codes in and out). */
 #define NPS_FMT_GT_AUTO 4

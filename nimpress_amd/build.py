@@ -42,7 +42,8 @@ def build_libnps(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "nps.h"))
     if force or _stale(LIBNPS, deps):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIBNPS] + srcs
+        # (NPS_HIPCC_EXTRA: experiment builds, e.g. -DNPS_MX_V2 -- never set by the driver or the tests)
+        cmd = [_hipcc()] + HIPCC_FLAGS + os.environ.get("NPS_HIPCC_EXTRA", "").split() + ["-o", LIBNPS] + srcs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

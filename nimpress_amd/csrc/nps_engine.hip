@@ -957,9 +957,15 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
         // whichever 2-bit layout is scored in ONE read at this cohort size: strips (matrix cores, time independent of the
         // genotypes) while there is a compute unit per 2048-sample strip, row groups (table lookups; 14 336 samples per
         // compute unit) beyond that -- on an MI355X up to 522 240 samples and up to about 3.6 million samples
+        // ... and while the strips' grid fills the chip: P strips x Q row teams is P x floor(CUs / P) workgroups, which
+        // leaves 128 < P < ~230 (262 144 < N < ~470 000 samples on 256 CUs) with P workgroups only; the row kernel's
+        // 14 336-sample slices have teams to spare there
         MxPlan mp;
-        HIP_TRY(mx_plan(device, n_samples, std::max<uint64_t>(n_rows, 1), false, &mp));
-        format = (n_samples == 0 || (mp.ok && !mp.given)) ? NPS_FMT_GT2X : NPS_FMT_GT2;
+        HIP_TRY(mx_plan(device, n_samples, std::max<uint64_t>(n_rows, 1 << 20), false, &mp));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        const bool fills = mp.ok && !mp.given && (uint64_t)mp.P * mp.Q * 10 >= (uint64_t)prop.multiProcessorCount * 9;
+        format = (n_samples == 0 || fills) ? NPS_FMT_GT2X : NPS_FMT_GT2;
     }
     nps_cohort *c = new (std::nothrow) nps_cohort;
     if (!c) return fail(NPS_E_NOMEM, "out of host memory");

@@ -43,11 +43,28 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 #define NPS_LDS __attribute__((address_space(3)))
 
-constexpr int kUD = 9;                   // units per data wave (waves 0..5)
-constexpr int kUC = 5;                   // units of the two control waves (6, 7), which also do the per-row work of 64 rows each
+// Data waves 0..5 carry 9 units each, the control waves 6, 7 five units each plus the per-row work of 64 rows each.
+// Two schedules of the control chain, chosen per launch (template parameter EARLY: a run-time flag with both paths in
+// one kernel cost 20 % -- the compiler drains the memory queue where the paths join):
+//   late:  the tables of superblock k are made at the start of step k (poll, operands), in front of the step's barrier.
+//   early: the tables of superblock k + 1 are made during the second half of step k: the look at its tally words is
+//          issued with the returning add of the publication of k + 2, the control wave accumulates its own units
+//          meanwhile, and the operands follow (three table buffers).  Nothing of the control chain is left in front of
+//          the barrier -- unless a word was not complete at that look, one step after its publication.  With few strips
+//          per team the two-stage publication is over by then (49 strips: 62.8 -> 68.2 % of 8 TB/s); with 245 strips
+//          it mostly is not, and a look at an incomplete word queues at the memory side in front of the adds it waits
+//          for (24.1 -> 27.5 ms), so the plan takes the early schedule up to 96 strips only (123 strips: equal).
+//          (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
+//          first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are
+//          the same instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
+constexpr int kBig = 6;                  // data waves 0..kBig-1 carry kUD units, data waves kBig..5 carry kUD2
+constexpr int kUD = 9;
+constexpr int kUD2 = 9;
+constexpr int kUC = 5;                   // units of the two control waves (6, 7), which do the per-row work of 64 rows each
+constexpr int kTabBufs = 3;
 constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
-constexpr uint32_t kLdsTables = 131072;  // [2][3 operands][128 rows][16 bytes]
-constexpr uint32_t kLdsTally = kLdsTables + 12288;  // [2][128] uint32: nmissing << 16 | neffect of the strip
+constexpr uint32_t kLdsTables = 131072;  // [kTabBufs][3 operands][128 rows][16 bytes]
+constexpr uint32_t kLdsTally = kLdsTables + kTabBufs * 6144;  // [2][128] uint32: nmissing << 16 | neffect of the strip
 constexpr uint32_t kLdsBytes = kLdsTally + 1024;
 constexpr uint32_t kMxSpinLimit = 1u << 20;
 
@@ -126,7 +143,7 @@ struct MxPre {
     long long w1, wfb;
 };
 static_assert(sizeof(MxPre) == 32, "MxPre layout");
-static_assert(6 * kUD + 2 * kUC == 64, "units of a strip");
+static_assert(kBig * kUD + (6 - kBig) * kUD2 + 2 * kUC == 64, "units of a strip");
 
 __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows,
                                                       DevParams prm, double scale, MxPre *__restrict__ pre) {
@@ -234,7 +251,7 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, bool kEarly>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -243,7 +260,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave < 6 ? wave * kUD : 6 * kUD + (wave - 6) * kUC;
+    const int u0 = wave < kBig ? wave * kUD
+                   : wave < 6  ? kBig * kUD + (wave - kBig) * kUD2
+                               : kBig * kUD + (6 - kBig) * kUD2 + (wave - 6) * kUC;
     const int crow = lane + 64 * (wave - 6);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
@@ -326,7 +345,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     // scores += code * Wc + is_missing * Wm for the wave's units of superblock k (parked in `slot`)
     auto accumulate = [&](uint32_t k, const char *slot) {
         if (k >= n_t || n_my == 0 || (DBG & 2)) return;
-        const char *tab = smem + kLdsTables + (k & 1) * 6144;
+        const char *tab = smem + kLdsTables + (k % kTabBufs) * 6144;
         v8i Bc, Bme, Bmo;
         {
             const v3i c0 = tr6(tab + fr0), c1 = tr6(tab + fr1);
@@ -391,14 +410,36 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             npre.wfb = (long long)((unsigned long long)p1.z | ((unsigned long long)p1.w << 32));
         }
     };
-    // the tally words of superblock k were published by every strip more than a step ago: normally one poll
+    // the row's tally word of superblock k (a relaxed agent-scope load; GIVEN: a plain one)
+    auto ctl_word = [&](uint32_t k, bool &valid) -> unsigned long long {
+        const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
+        valid = k < n_t && row < a.n_rows;
+        return !valid  ? 0ull
+               : GIVEN ? a.tally[row]
+                       : __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // complete tallies of superblock k (x) -> the row's three operands in table buffer k % kTabBufs
+    auto ctl_build = [&](uint32_t k, unsigned long long x, bool valid, bool ok) {
+        const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
+        uint32_t wc[3], wme[3], wmo[3];
+        int used;
+        double cst;
+        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
+        char *p = smem + kLdsTables + (k % kTabBufs) * 6144 + crow * 16;
+        *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
+        *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
+        *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
+        nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+        cst_local += cst;
+    };
+    // wait (bounded) until every row of superblock k is complete, then build its tables.  v1: the tally words were
+    // published by every strip more than a step ago: normally one poll.  v2: only reached when the look in the
+    // previous step's second half found a word incomplete.
     auto ctl_tables = [&](uint32_t k) {
         if (k >= n_t) return;
         const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
-        const bool valid = row < a.n_rows;
-        unsigned long long x = !valid  ? 0ull
-                               : GIVEN ? a.tally[row]
-                                       : __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool valid;
+        unsigned long long x = ctl_word(k, valid);
         bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
         uint32_t spins = 0;
         while (!GIVEN && !__all(ok) && !timed_out) {
@@ -415,16 +456,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 }
             }
         }
-        uint32_t wc[3], wme[3], wmo[3];
-        int used;
-        double cst;
-        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
-        char *p = smem + kLdsTables + (k & 1) * 6144 + crow * 16;
-        *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
-        *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
-        *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
-        nloci_local += (uint32_t)__popcll(__ballot(used != 0));
-        cst_local += cst;
+        ctl_build(k, x, valid, ok);
     };
     // The strip's tallies of superblock kp are complete in LDS (barrier passed).  Same-line atomics are served one
     // after the other at the memory side (~25 ns each), so 245 strips adding to one row's word would take longer
@@ -492,16 +524,37 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 
     // ---- steps
+    bool next_done = false;  // (early schedule, wave-uniform) the tables of the NEXT step's superblock are already in LDS
     auto step = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park, const char *s_acc) {
-        if (is_ctl) ctl_tables(k);
+        if (is_ctl && !(kEarly && next_done)) {
+            ctl_tables(k);
+            if (kEarly) ctl_fetch_pre(k + 1);  // (normally fetched a step ahead, below)
+        }
         front(k, b_tal, b_park, s_park);
         __syncthreads();
-        if (is_ctl) {  // the returning add and the loads are in flight during the wave's own accumulation
+        if (is_ctl && !kEarly) {  // the returning add and the loads are in flight during the wave's own accumulation
             ctl_publish_begin(k + 2);
             ctl_fetch_pre(k + 1);
         }
-        accumulate(k, s_acc);
-        if (is_ctl) ctl_publish_end(k + 2);
+        if (is_ctl && kEarly) {
+            // publication of k+2 and a look at k+1 (published by every strip a step ago) in ONE round trip, spent on the
+            // wave's own accumulation; where the look finds every row complete, the tables of k+1 are made here, a step
+            // ahead of their barrier
+            ctl_publish_begin(k + 2);
+            bool valid;
+            const unsigned long long x = ctl_word(k + 1, valid);
+            accumulate(k, s_acc);
+            ctl_publish_end(k + 2);
+            const bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
+            next_done = k + 1 < n_t && __all(ok);
+            if (next_done) {
+                ctl_build(k + 1, x, valid, ok);
+                ctl_fetch_pre(k + 2);
+            }
+        } else {
+            accumulate(k, s_acc);
+        }
+        if (is_ctl && !kEarly) ctl_publish_end(k + 2);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
     };
     const uint32_t n_steps = (n_t + 1) / 2 * 2;
@@ -520,18 +573,26 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-template <int DBG, bool GIVEN>
+template <int DBG, bool GIVEN, bool EARLY>
 __global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
+    const int u0 = wave < kBig ? wave * kUD : kBig * kUD + (wave - kBig) * kUD2;  // (data waves)
     if (wave >= 6)
-        mx_body<kUC, true, true, DBG, GIVEN>(a, smem);
-    else if (nu - wave * kUD >= kUD)
-        mx_body<kUD, false, false, DBG, GIVEN>(a, smem);
-    else
-        mx_body<kUD, true, false, DBG, GIVEN>(a, smem);
+        mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN, EARLY>(a, smem);  // (v2: no units, n_my = 0)
+    else if (wave < kBig) {
+        if (nu - u0 >= kUD)
+            mx_body<kUD, false, false, DBG, GIVEN, EARLY>(a, smem);
+        else
+            mx_body<kUD, true, false, DBG, GIVEN, EARLY>(a, smem);
+    } else {
+        if (nu - u0 >= kUD2)
+            mx_body<kUD2, false, false, DBG, GIVEN, EARLY>(a, smem);
+        else
+            mx_body<kUD2, true, false, DBG, GIVEN, EARLY>(a, smem);
+    }
 }
 
 // Epilogue of a pass: the sixteen digit sums of a sample -> float64, plus the pass's locus constants, into chunk 0
@@ -830,28 +891,31 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
     }
-    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true> : (const void *)fused_mx_kernel<0, false>;
+    const bool early = plan.P <= 96;  // (measured: 49 strips +8 %, 123 strips equal, 245 strips -14 %)
+    const void *fn = plan.given ? (early ? (const void *)fused_mx_kernel<0, true, true> : (const void *)fused_mx_kernel<0, true, false>)
+                                : (early ? (const void *)fused_mx_kernel<0, false, true> : (const void *)fused_mx_kernel<0, false, false>);
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
     if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false>; break;
+        case 1: fn = (const void *)fused_mx_kernel<1, false, false>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false, false>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false, false>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false, false>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false, false>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false, false>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false, false>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false, false>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false, false>; break;
         default: break;
         }
 #endif
-    static const void *attr_set[2] = {nullptr, nullptr};
-    if (attr_set[plan.given ? 1 : 0] != fn) {
+    static const void *attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int which = (plan.given ? 2 : 0) + (early ? 1 : 0);
+    if (attr_set[which] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set[plan.given ? 1 : 0] = fn;
+        attr_set[which] = fn;
     }
     MxArgs a;
     a.units = (const v4u *)d_units;
@@ -877,7 +941,10 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.timeout = d_timeout;
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        hipLaunchKernelGGL((fused_mx_kernel<0, true>), grid, dim3(512), kLdsBytes, st, a);
+        if (early)
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, true>), grid, dim3(512), kLdsBytes, st, a);
+        else
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, false>), grid, dim3(512), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};

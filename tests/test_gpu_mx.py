@@ -409,9 +409,11 @@ def test_gt2x_beta_span_plain_relative_bar(mode):
     assert ref[-1] < 1e-12 * ref[0]
 
 
-@pytest.mark.parametrize("n,want", [(3000, capi.FMT_GT2X), (522240, capi.FMT_GT2X), (530000, capi.FMT_GT2)])
+@pytest.mark.parametrize("n,want", [(3000, capi.FMT_GT2X), (250000, capi.FMT_GT2X), (300000, capi.FMT_GT2),
+                                    (522240, capi.FMT_GT2X), (530000, capi.FMT_GT2)])
 def test_gt_auto_layout_is_the_single_read_one(n, want):
-    """NPS_FMT_GT_AUTO: strips while there is a compute unit per 2048-sample strip, row groups beyond -- either way
+    """NPS_FMT_GT_AUTO: strips where their grid (strips x row teams) covers the chip, row groups where it does not
+    (147 strips at 300 000 samples have no second team) or cannot (more strips than compute units) -- either way
     NPS_MODE_FUSED (one read of the matrix) is accepted and equals the oracle"""
     import torch
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
