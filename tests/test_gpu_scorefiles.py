@@ -131,6 +131,78 @@ def test_one_pass_multi_equals_file_by_file(cohort_vcf):
             assert np.max(np.abs(got[i][ok] - ref[ok]), initial=0.0) <= 1e-6 * scale, f
 
 
+def test_results_left_in_device_memory_equal_the_host_copies(cohort_vcf):
+    """what the multi-GPU exchange reads (tools/score_many.py with RCCL): nh_compute_dev / nh_compute_multi_dev leave
+    the scores -- or, rows sharded, a block's un-normalised sums -- in DEVICE memory (nps_finish_device,
+    nps_multi_finish_device, nps_multi_partial_device): bit-identical to what the host-buffer entry points return,
+    with the same nloci and log lines; and the per-stage timings of a call add up to something sane"""
+    files = SCORES[:-1]
+    n = 1500
+    kw = dict(afmisp=0.001)
+    d_row = torch.full((n,), -7.0, dtype=torch.float64, device="cuda")
+    for f in files[:3]:
+        want, nloci, log = host.compute_polygenic_scores(f, cohort_vcf, **kw)
+        none, nloci_d, log_d = host.compute_polygenic_scores(f, cohort_vcf, d_out=d_row.data_ptr(), **kw)
+        assert none is None and nloci_d == nloci and log_d == log
+        assert np.array_equal(d_row.cpu().numpy().view(np.int64), want.view(np.int64)), f
+    t = host.last_timings()
+    assert set(t) == set(host.TIMING_KEYS) and all(v >= 0.0 for v in t.values())
+    # (a file without an index is inflated and parsed by open(): counted there; an indexed one under inflate_parse_s)
+    assert t["open_s"] + t["inflate_parse_s"] > 0.0 and t["hip_init_wait_s"] <= t["hip_init_s"] + 1e-3 and sum(t.values()) < 60.0
+    d_mat = torch.full((len(files), n), -7.0, dtype=torch.float64, device="cuda")
+    want, nloci, logs = host.compute_polygenic_scores_multi(files, cohort_vcf, **kw)
+    none, nloci_d, logs_d = host.compute_polygenic_scores_multi(files, cohort_vcf, d_out=d_mat.data_ptr(), **kw)
+    assert none is None and np.array_equal(nloci_d, nloci) and logs_d == logs
+    assert np.array_equal(d_mat.cpu().numpy().view(np.int64), want.view(np.int64))
+    # rows sharded in two blocks: the blocks' sums, left on the device, add up and normalise to the one-pass scores
+    total = torch.zeros((len(files), n), dtype=torch.float64, device="cuda")
+    cnt = np.zeros(len(files), np.int64)
+    for shard in range(2):
+        d_mat.fill_(-7.0)
+        want_s, nl_s, offs, lg = host.compute_polygenic_scores_multi_partial(files, cohort_vcf, shard, 2, **kw)
+        none, nl_d, offs_d, lg_d = host.compute_polygenic_scores_multi_partial(files, cohort_vcf, shard, 2,
+                                                                             d_out=d_mat.data_ptr(), **kw)
+        assert none is None and np.array_equal(nl_d, nl_s) and np.array_equal(offs_d, offs) and lg_d == lg
+        assert np.array_equal(d_mat.cpu().numpy().view(np.int64), want_s.view(np.int64))
+        total += d_mat
+        cnt += nl_d
+    assert np.array_equal(cnt, nloci)
+    got = multi.normalize_matrix(total, torch.from_numpy(cnt), offs).cpu().numpy()
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    scale = 1e-12 + np.max(np.abs(want[ok]))
+    assert np.max(np.abs(got[ok] - want[ok])) <= 1e-9 * scale
+
+
+def test_log_longer_than_the_callers_buffer_comes_back_whole(cohort_vcf, monkeypatch):
+    """the warnings of eight files do not fit a small buffer: the buffer ends at a line end with the truncation mark,
+    nh_last_log has all of it, and host.py hands every file its own lines"""
+    import ctypes as C
+    files = SCORES[:-1]
+    want, nloci, logs = host.compute_polygenic_scores_multi(files, cohort_vcf, afmisp=0.5)
+    n_lines = sum(len(l) for l in logs)
+    assert n_lines > 50
+    real = C.create_string_buffer
+
+    def small(size_or_init, *a):
+        return real(2048 if size_or_init == (4 << 20) else size_or_init, *a)
+    monkeypatch.setattr(host.C, "create_string_buffer", small)
+    got, nloci2, logs2 = host.compute_polygenic_scores_multi(files, cohort_vcf, afmisp=0.5)
+    assert logs2 == logs and np.array_equal(nloci2, nloci)
+    # and the short buffer itself: whole lines, then the mark
+    L = host.load()
+    buf = real(2048)
+    nl = np.zeros(len(files), np.uint64)
+    sc = np.empty((len(files), 1500))
+    from nimpress_amd import capi
+    n = L.nh_compute_multi("\n".join(files).encode(), cohort_vcf.encode(), None, capi.LOCUS["ps"], capi.MISSING["homref"],
+                           capi.SAMPLE["int_ps"], 0.05, 0.5, 100, 0, 0, sc.ctypes.data, 1500, nl.ctypes.data, buf, 2048)
+    assert n == 1500
+    text = buf.value.decode()
+    assert text.endswith("... log truncated\n") and L.nh_last_log_size() > 2048
+    assert all(l.partition("\t")[0].isdigit() for l in text.split("\n")[:-2])
+
+
 def test_vectorised_float_format_equals_scalar():
     x = np.concatenate([np.random.default_rng(1).normal(0, 1, 2000), [0.0, 1.0, -2.0, 1e22, 1e-7, np.nan, np.inf, 123456789.0]])
     assert host.format_scores(x) == [host.format_score(float(v)) for v in x]
