@@ -458,8 +458,14 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     t0 = time.perf_counter()
     dst.convert_from(src)           # (synchronises at its end)
     pack_s = time.perf_counter() - t0
-    src.close()
     dst.close()
+    dstx = capi.Cohort(n, mp, fmt=capi.FMT_GT2X, device=device)   # ... and into the strip layout of the single-score kernel
+    dstx.convert_from(src)
+    t0 = time.perf_counter()
+    dstx.convert_from(src)
+    packx_s = time.perf_counter() - t0
+    dstx.close()
+    src.close()
     co = capi.Cohort(n, m, fmt=capi.FMT_GT2M, device=device)
     for a in range(0, m, 1 << 15):
         b = min(m, a + (1 << 15))
@@ -550,7 +556,11 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
                                      "tallies (tallyAlleles of every row; the multi-score pass reads them instead of "
                                      "recounting), measured on %d rows" % mp,
                              "ms_per_million_rows": pack_s * 1e3 * 1e6 / mp,
-                             "GBps_read_plus_written": 2.0 * mp * ((n + 15) // 16) * 4 / pack_s / 1e9},
+                             "GBps_read_plus_written": 2.0 * mp * ((n + 15) // 16) * 4 / pack_s / 1e9,
+                             "into_strip_layout": {"what": "nps_cohort_convert: the same cohort -> NPS_FMT_GT2X strips (no "
+                                                           "tallies: the single-score kernel counts while it reads)",
+                                                   "ms_per_million_rows": packx_s * 1e3 * 1e6 / mp,
+                                                   "GBps_read_plus_written": 2.0 * mp * ((n + 15) // 16) * 4 / packx_s / 1e9}},
            "roofline": {"bound": "mfma", "achieved": full["int8_TOPs"], "peak": 5000.0, "unit": "TOP/s (int8 dense)",
                         "frac": full["int8_TOPs"] / 5000.0, "hbm_GBps": full["hbm_GBps"],
                         "hbm_frac": full["hbm_GBps"] / HBM_PEAK_GBS,

@@ -54,6 +54,8 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 //          per team the two-stage publication is over by then (49 strips: 62.8 -> 68.2 % of 8 TB/s); with 245 strips
 //          it mostly is not, and a look at an incomplete word queues at the memory side in front of the adds it waits
 //          for (24.1 -> 27.5 ms), so the plan takes the early schedule up to 96 strips only (123 strips: equal).
+//   mid:   the late schedule with its first look issued a third of a step earlier, right after the control wave's own
+//          accumulation of the step before (123 strips: +3 %; 245 strips: 24.2 -> 26.4 ms): 97 to 160 strips.
 //          (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
 //          first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are
 //          the same instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
@@ -251,8 +253,10 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, bool kEarly>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int SCHED>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
+    constexpr bool kEarly = SCHED == 1;  // 0 late, 1 early, 2 mid (the look at k+1 issued after the control wave's own
+    constexpr bool kMid = SCHED == 2;    // accumulation in step k and consumed at the start of step k+1)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
     const uint32_t strip = blockIdx.x % a.P, team = blockIdx.x / a.P;
@@ -435,11 +439,19 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     // wait (bounded) until every row of superblock k is complete, then build its tables.  v1: the tally words were
     // published by every strip more than a step ago: normally one poll.  v2: only reached when the look in the
     // previous step's second half found a word incomplete.
+    unsigned long long x_first = 0ull;  // (mid schedule) the look issued in the previous step
+    bool have_first = false;
     auto ctl_tables = [&](uint32_t k) {
         if (k >= n_t) return;
         const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
         bool valid;
-        unsigned long long x = ctl_word(k, valid);
+        unsigned long long x;
+        if (kMid && have_first) {
+            valid = row < a.n_rows;
+            x = valid ? x_first : 0ull;
+        } else {
+            x = ctl_word(k, valid);
+        }
         bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
         uint32_t spins = 0;
         while (!GIVEN && !__all(ok) && !timed_out) {
@@ -554,6 +566,11 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         } else {
             accumulate(k, s_acc);
         }
+        if (is_ctl && kMid) {
+            bool v;
+            x_first = ctl_word(k + 1, v);
+            have_first = true;
+        }
         if (is_ctl && !kEarly) ctl_publish_end(k + 2);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
     };
@@ -573,7 +590,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-template <int DBG, bool GIVEN, bool EARLY>
+template <int DBG, bool GIVEN, int EARLY>
 __global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
@@ -891,27 +908,33 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
     }
-    const bool early = plan.P <= 96;  // (measured: 49 strips +8 %, 123 strips equal, 245 strips -14 %)
-    const void *fn = plan.given ? (early ? (const void *)fused_mx_kernel<0, true, true> : (const void *)fused_mx_kernel<0, true, false>)
-                                : (early ? (const void *)fused_mx_kernel<0, false, true> : (const void *)fused_mx_kernel<0, false, false>);
+    // the control chain's schedule by the number of strips that hand over to each other (measured, ms per 1M-row pass,
+    // late / mid / early: 49 strips 4.98 / - / 4.46; 123 strips 12.38 / 11.98 / 12.05; 245 strips 24.2 / 26.4 / 27.5)
+    const int sched = plan.P <= 96 ? 1 : plan.P <= 160 ? 2 : 0;
+    const void *fn = plan.given ? (sched == 1   ? (const void *)fused_mx_kernel<0, true, 1>
+                                   : sched == 2 ? (const void *)fused_mx_kernel<0, true, 2>
+                                                : (const void *)fused_mx_kernel<0, true, 0>)
+                                : (sched == 1   ? (const void *)fused_mx_kernel<0, false, 1>
+                                   : sched == 2 ? (const void *)fused_mx_kernel<0, false, 2>
+                                                : (const void *)fused_mx_kernel<0, false, 0>);
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
     if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false, false>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false, false>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false, false>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false, false>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false, false>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false, false>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false, false>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false, false>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false, false>; break;
+        case 1: fn = (const void *)fused_mx_kernel<1, false, 0>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false, 0>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false, 0>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false, 0>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false, 0>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false, 0>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false, 0>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false, 0>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false, 0>; break;
         default: break;
         }
 #endif
-    static const void *attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int which = (plan.given ? 2 : 0) + (early ? 1 : 0);
+    static const void *attr_set[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int which = (plan.given ? 3 : 0) + sched;
     if (attr_set[which] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -941,10 +964,12 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.timeout = d_timeout;
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        if (early)
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, true>), grid, dim3(512), kLdsBytes, st, a);
+        if (sched == 1)
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, 1>), grid, dim3(512), kLdsBytes, st, a);
+        else if (sched == 2)
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, 2>), grid, dim3(512), kLdsBytes, st, a);
         else
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, false>), grid, dim3(512), kLdsBytes, st, a);
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, 0>), grid, dim3(512), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};
