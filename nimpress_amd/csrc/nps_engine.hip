@@ -1346,6 +1346,11 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_t);
     if (e != hipSuccess) return fail(NPS_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
+    if (c->format == NPS_FMT_DS32 && c->ds_bad_rows)  // the generator clips to [0, 2]: these rows are in range now
+        for (uint64_t r = row0; r < row0 + nrows && r < c->ds_row_bad.size(); ++r) {
+            c->ds_bad_rows -= c->ds_row_bad[r];
+            c->ds_row_bad[r] = 0;
+        }
     return NPS_OK;
 }
 
