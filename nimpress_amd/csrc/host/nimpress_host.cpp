@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <limits>
 #include <sstream>
 #include <stdexcept>
@@ -25,7 +26,7 @@
 namespace nimpress {
 
 // ---- where the time goes, and the HIP context on a thread of its own ------------------------------------
-static Timings g_timings;
+static thread_local Timings g_timings;  // (per calling thread, like the error string of the C hooks)
 Timings &timings() { return g_timings; }
 void timingsReset() { g_timings = Timings(); }
 static double nowSeconds() {
@@ -37,11 +38,17 @@ struct Tick {  // adds the scope's wall time to one of the Timings fields
     explicit Tick(double &a) : acc(a), t0(nowSeconds()) {}
     ~Tick() { acc += nowSeconds() - t0; }
 };
+// one warm-up at a time per process (a second caller while one is in flight simply does without: its first libnps
+// call creates the context as before)
+static std::mutex g_warm_mutex;
 static std::thread g_warm_thread;
+static std::thread::id g_warm_owner;
 static double g_warm_seconds = 0.0;
 void warmupStart(int device) {
+    std::lock_guard<std::mutex> lock(g_warm_mutex);
     if (g_warm_thread.joinable()) return;
     g_warm_seconds = 0.0;
+    g_warm_owner = std::this_thread::get_id();
     g_warm_thread = std::thread([device]() {
         const double t0 = nowSeconds();
         (void)nps_warmup(device);  // (an error shows up again, with its message, in the run's first libnps call)
@@ -49,9 +56,14 @@ void warmupStart(int device) {
     });
 }
 void warmupJoin() {
-    if (!g_warm_thread.joinable()) return;
-    Tick t(g_timings.hip_init_wait);
-    g_warm_thread.join();
+    std::thread t;
+    {
+        std::lock_guard<std::mutex> lock(g_warm_mutex);
+        if (!g_warm_thread.joinable() || g_warm_owner != std::this_thread::get_id()) return;
+        t = std::move(g_warm_thread);
+    }
+    Tick tick(g_timings.hip_init_wait);
+    t.join();
     g_timings.hip_init += g_warm_seconds;
 }
 
