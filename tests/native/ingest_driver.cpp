@@ -5,6 +5,8 @@
 // tests/test_host_logic.py::test_ingest_under_sanitizers.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <stdexcept>
 #include <string>
 
 #include "../../nimpress_amd/csrc/host/nimpress_host.hpp"
@@ -12,8 +14,18 @@
 using namespace nimpress;
 
 static unsigned long long checksum(const Variant &v, size_t n_samples) {
-    const size_t nval = v.is_bed ? 2 * n_samples : v.gt_raw.empty() ? v.gts.size() : v.gt_raw.size() / (size_t)v.gt_bytes;
     unsigned long long h = 1469598103934665603ull;
+    if (v.has_ds) {  // a record scored from FORMAT/DS: its dosage values as they were parsed
+        for (const float f : v.ds) {
+            unsigned int u;
+            memcpy(&u, &f, 4);
+            h = (h ^ (unsigned long long)u) * 1099511628211ull;
+        }
+        return h;
+    }
+    const size_t nval = v.is_bed || v.is_pgen ? 2 * n_samples
+                        : v.gt_raw.empty()    ? v.gts.size()
+                                              : v.gt_raw.size() / (size_t)v.gt_bytes;
     for (size_t i = 0; i < nval; ++i) h = (h ^ (unsigned long long)(unsigned int)v.gtValue(i)) * 1099511628211ull;
     return h;
 }
@@ -31,7 +43,16 @@ static void dump(const char *tag, const ScoreFile &sf, const std::vector<Variant
     }
 }
 
+static int run(int argc, char **argv);
 int main(int argc, char **argv) {
+    try {
+        return run(argc, argv);
+    } catch (const std::exception &e) {  // a file the readers refuse: a message and a status, never a crash
+        printf("refused: %s\n", e.what());
+        return 5;
+    }
+}
+static int run(int argc, char **argv) {
     if (argc < 3) return 2;
     ScoreFile sf;
     if (!sf.open(argv[1])) return 3;

@@ -765,6 +765,57 @@ def test_ingest_under_sanitizers(tmp_path, san):
         outs.append(out)
     # BCF (int16 vectors) and text VCF give the same widened GT values
     assert outs[0] == outs[1]
+    # round 4: the PLINK 2 fixed-width .pgen reader and the in-place FORMAT/DS text parser under the same sanitizers, on
+    # good files and on files they must refuse (truncated records, a header that lies about the samples, a .pvar line with
+    # too few columns, a dosage outside [0, 2], an over-long number): a message and status 5, never a report
+    import pgenwriter
+    m = 40
+    variants = [("1", 1000 + 37 * j, "v%d" % j, "A", "G") for j in range(m)]
+    alt = rng.integers(0, 3, size=(m, n))
+    miss = rng.uniform(size=(m, n)) < 0.05
+    pgenwriter.write_pgen(str(tmp_path / "p"), samples, variants, alt, miss)
+    pscore = str(tmp_path / "p.score")
+    open(pscore, "w").write("\n".join(["t", "", "", "x", "0.0"] + ["1\t%d\tA\t%s\t0.1\t0.2" % (v[1], "GA"[j % 2])
+                                                                   for j, v in enumerate(variants)] + ["1\t5\tA\tG\t0.1\t0.2"]))
+
+    def drive(path, want_rc):
+        r = subprocess.run([exe, pscore, path, "7"], capture_output=True, text=True, env=env)
+        assert r.returncode == want_rc, (path, r.returncode, r.stdout[-300:], r.stderr[-2000:])
+        for bad in ("Sanitizer", "runtime error"):
+            assert bad not in r.stderr, r.stderr[-3000:]
+        return r.stdout
+
+    out = drive(str(tmp_path / "p.pgen"), 0)
+    assert sum("absent" in l for l in out.splitlines()) == 1 and "no index" in out
+    raw = open(str(tmp_path / "p.pgen"), "rb").read()
+    for name, data in (("trunc", raw[:len(raw) // 2]), ("hdr", raw[:7] + np.uint32(n + 3).tobytes() + raw[11:]),
+                       ("short", raw[:9])):
+        for ext in (".pvar", ".psam"):
+            shutil.copy(str(tmp_path / ("p" + ext)), str(tmp_path / (name + ext)))
+        open(str(tmp_path / (name + ".pgen")), "wb").write(data)
+        assert "refused" in drive(str(tmp_path / (name + ".pgen")), 5)
+    shutil.copy(str(tmp_path / "p.pgen"), str(tmp_path / "cols.pgen"))
+    shutil.copy(str(tmp_path / "p.psam"), str(tmp_path / "cols.psam"))
+    open(str(tmp_path / "cols.pvar"), "w").write("#CHROM\tPOS\tID\tREF\tALT\n1\t1000\tv0\n")
+    assert "refused" in drive(str(tmp_path / "cols.pgen"), 5)
+    head = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples[:50])]
+
+    def ds_vcf(name, cell):
+        ds = np.round(rng.uniform(0, 2, size=(m, 50)), 3)
+        lines = list(head)
+        for j, v in enumerate(variants):
+            cells = ["%g" % x for x in ds[j]]
+            cells[j % 50] = "." if j % 7 == 0 else cells[j % 50]
+            if j == 3 and cell is not None:
+                cells[5] = cell
+            lines.append("1\t%d\t.\tA\tG\t.\tPASS\t.\tDS\t%s" % (v[1], "\t".join(cells)))
+        p = str(tmp_path / (name + ".vcf"))
+        open(p, "w").write("\n".join(lines) + "\n")
+        return p
+    assert "refused" not in drive(ds_vcf("ds_ok", None), 0)
+    assert "outside [0, 2]" in drive(ds_vcf("ds_range", "2.25"), 5)
+    assert "refused" in drive(ds_vcf("ds_junk", "1.5x"), 5)
+    assert "refused" in drive(ds_vcf("ds_long", "0." + "1" * 80), 5)
 
 
 def test_pgen_fixed_width_reader_vs_writer_parity_unpinned(host, tmp_path):
