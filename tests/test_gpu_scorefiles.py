@@ -174,6 +174,25 @@ def test_results_left_in_device_memory_equal_the_host_copies(cohort_vcf):
     assert np.max(np.abs(got[ok] - want[ok])) <= 1e-9 * scale
 
 
+@pytest.mark.parametrize("extra", [[], ["--one-pass"], ["--shard", "rows"]])
+def test_score_many_device_result_paths_on_one_gpu(cohort_vcf, tmp_path, extra):
+    """the code score_many.py runs on 8 GPUs -- results left in device memory, handed to the exchange from there -- taken
+    with ONE rank (NIMPRESS_DEVICE_RESULTS=1: the gather / all-reduce of a single rank is the identity): the matrix
+    equals the host-buffer run's, text for text"""
+    import subprocess
+    import sys
+    files = SCORES[:-1]
+    outs = []
+    for env_extra in ({}, {"NIMPRESS_DEVICE_RESULTS": "1"}):
+        out = str(tmp_path / ("m%d.tsv" % len(outs)))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_many.py"), "--gpus", "1", "--afmisp=0",
+                            "--out", out] + extra + files + [cohort_vcf], capture_output=True, text=True,
+                           env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 1500
+
+
 def test_log_longer_than_the_callers_buffer_comes_back_whole(cohort_vcf, monkeypatch):
     """the warnings of eight files do not fit a small buffer: the buffer ends at a line end with the truncation mark,
     nh_last_log has all of it, and host.py hands every file its own lines"""

@@ -76,7 +76,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import numpy as np
     from nimpress_amd import capi, host
-    capi.load(with_torch=world > 1)   # (one process, one GPU: torch is never imported -- its import is a third of such a run)
+    capi.load(with_torch=world > 1 or os.environ.get("NIMPRESS_DEVICE_RESULTS") == "1")   # (one process, one GPU: torch is never imported -- its import is a third of such a run)
     stamp = {"imports_s": time.perf_counter() - T_START}   # numpy, ctypes, dlopen of libnps + the HIP runtime
     torch = dist = multi = device = None
     # (ranks that share a GPU exist only in tests: NIMPRESS_DIST_BACKEND=gloo, the exchange on CPU tensors)
@@ -99,8 +99,15 @@ def main(argv=None):
         else:
             device = torch.device("cpu")
             dist.init_process_group(backend)
-    # results stay in device memory between the scoring and the exchange when the exchange runs on the GPU (RCCL)
-    on_gpu = world > 1 and backend == "nccl"
+    # results stay in device memory between the scoring and the exchange when the exchange runs on the GPU (RCCL);
+    # NIMPRESS_DEVICE_RESULTS=1 takes that path with a single rank too (tests: the one-GPU rehearsal of the 8-GPU code)
+    force_dev = os.environ.get("NIMPRESS_DEVICE_RESULTS") == "1"
+    on_gpu = (world > 1 and backend == "nccl") or force_dev
+    if force_dev and world == 1:
+        import torch
+        from nimpress_amd import multi
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(local_rank)
     score_files, cohort = args.files[:-1], args.files[-1]
     names = host.sample_names(cohort)
     n = len(names)
@@ -135,7 +142,7 @@ def main(argv=None):
         for i, lines in enumerate(lg):
             logs[i] = lines
         one_pass_used = True
-        if world > 1:
+        if world > 1 or on_gpu:
             tg = time.perf_counter()
             t, cnt = multi.all_reduce_partial_matrix(d_sums if on_gpu else torch.from_numpy(sums).to(device), nl)
             mat = multi.normalize_matrix(t, cnt, offs).cpu().numpy()
@@ -146,7 +153,7 @@ def main(argv=None):
     else:
         mine = list(range(rank, S, world))
         # this rank's rows of the matrix, in shard order: on the GPU when the gather runs there
-        local = None if world == 1 else torch.empty((len(mine), n), dtype=torch.float64, device=device)
+        local = None if (world == 1 and not on_gpu) else torch.empty((len(mine), n), dtype=torch.float64, device=device)
         done = set()
         if args.one_pass and mine:
             try:
@@ -159,15 +166,15 @@ def main(argv=None):
                         local[k].copy_(torch.from_numpy(sc[k]))
                 done = set(mine)
                 one_pass_used = True
-                if world == 1:
+                if world == 1 and not on_gpu:
                     mat = sc
             except capi.NpsError as e:
                 sys.stderr.write("score_many: one-pass path not applicable (%s); scoring file by file\n" % e)
-        if mat is None and world == 1:
+        if mat is None and world == 1 and not on_gpu:
             mat = np.empty((S, n), dtype=np.float64)
             for i in range(S):
                 mat[i] = score_file(i)
-        elif world > 1:
+        elif world > 1 or on_gpu:
             for k, i in enumerate(mine):
                 if i in done:
                     continue
