@@ -345,10 +345,11 @@ void nps_multidef_destroy(nps_multidef *d);
 int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_params *params, int n_scores);
 /* Width of the fixed-point weight `(imputed dosage - 3) x beta` that a MISSING genotype adds on top of the
  * `3 x beta` its code already received (the dosage weights always carry 56 bits).  56 (default): as exact as
- * the dosage weights.  32: that weight keeps its four leading base-256 digits -- per sample an error of at most
- * (its missing genotypes) x 2^-30 x B before the division by 2 nloci, B = max|beta| x (3 + max(2, 2 max|eaf|)) of
- * the score, typically the square root of that count -- and with more than 4 scores the pass needs a quarter
- * fewer matrix instructions.  NaN imputation values
+ * the dosage weights.  32: the four leading base-256 digits of the operands that carry it are kept (the kernel
+ * multiplies byte prefixes of four packed genotypes, so a weight is known to 2^-24 of the largest one at worst) --
+ * per sample an error of at most (its missing genotypes) x 2^-24 x B before the division by 2 nloci,
+ * B = max|beta| x (3 + max(2, 2 max|eaf|)) of the score, typically the square root of that count -- and with more
+ * than 4 scores the pass needs a quarter fewer matrix instructions.  NaN imputation values
  * (imp-sample fail / int_fail below --mincs) are exact in both modes.  Applies to the following calls. */
 int nps_multi_set_missing_weight_bits(nps_multi *m, int bits);
 /* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset.

@@ -12,7 +12,7 @@
 //   * the per-row weights are turned into FIXED-POINT integers (49 bits, times a power of two <= 128 that
 //     belongs to the operand extraction, see weight_digits) and split into seven signed base-256 digits:
 //     w = sum_k d_k 256^k / 2^(F+7).  code (int8) x digit (int8) accumulated in int32 by
-//     v_mfma_i32_32x32x32_i8 is EXACT integer arithmetic, independent of the summation order; the seven
+//     v_mfma_i32_16x16x64_i8 is EXACT integer arithmetic, independent of the summation order; the seven
 //     digit sums of a sample are recombined in float64 at the very end.  The only error is the
 //     quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score).
 //   * a missing genotype has code 3 in this layout: it contributes 3 x beta through the dosage
@@ -23,9 +23,12 @@
 //     same constant to every sample: summed exactly in fixed point on the side, no matrix work.
 //
 // Data layout NPS_FMT_GT2M (the A operand wants 16 ROWS of one sample per lane): superblocks of 128
-// rows x groups of 32 samples; unit (superblock, group) = 64 lanes x 16 bytes = 1 KiB contiguous;
-// lane l = sample (l & 31), row half h = l >> 5; its four words w = 0..3 hold rows 64h + 16w + j
-// (j = 0..15, code of row j in bits 2j, 2j+1); codes 0, 1, 2 = dosage, 3 = missing.
+// rows x groups of 32 samples; unit (superblock, group) = 64 lanes x 16 bytes = 1 KiB contiguous, made for the
+// 16 x 16 x 64 shape (16 samples x 64 rows per instruction; measured a fifth faster than 32 x 32 x 32 on this
+// chip, tools/ubench_mfma_shape.hip): lane l = sample (l & 15) of either half of the group, row quarter
+// g = l >> 4; word w = 0..3 belongs to the sample half w >> 1 (sample 16 (w >> 1) + (l & 15) of the group) and
+// holds its rows 32 g + 16 (w & 1) + j (j = 0..15, code of row j in bits 2j, 2j+1); codes 0, 1, 2 = dosage,
+// 3 = missing.
 // Whole-row tallies (tallyAlleles, nimpress.nim:32-47) are produced when the cohort is packed (by the
 // generator / the converter, as the streaming decode kernel does for pushed rows) and kept with it.
 #include <algorithm>
@@ -50,7 +53,7 @@ static __device__ __forceinline__ uint64_t mmix64(uint64_t z) {
 // NPS_CODE_* (0, 1, 3 = dosage 2, 2 = missing) -> layout code (0, 1, 2, 3 = missing)
 static __device__ __forceinline__ uint32_t m_code(uint32_t c) { return c ^ (c >> 1); }
 
-// one thread = one lane of one unit: (sample, row half) x 64 rows.  grid = (units chunks, superblocks)
+// one thread = one lane of one unit: two samples x 32 rows.  grid = (units chunks, superblocks)
 __global__ __launch_bounds__(256) void synth_gt2m_kernel(uint4 *__restrict__ units, uint64_t n_groups,
                                                          uint64_t n_samples, uint64_t sb0,
                                                          uint64_t gen_row0, uint64_t n_rows, uint64_t seed,
@@ -62,16 +65,16 @@ __global__ __launch_bounds__(256) void synth_gt2m_kernel(uint4 *__restrict__ uni
     if (u >= n_groups * 64) return;
     const uint64_t g = u >> 6;
     const uint32_t lane = (uint32_t)(u & 63);
-    const uint64_t s = g * 32 + (lane & 31);
-    const uint32_t h = lane >> 5;
+    const uint32_t rq = lane >> 4;
     uint32_t out[4] = {0, 0, 0, 0};
-    if (s < n_samples) {
+    {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
+            const uint64_t s = g * 32 + 16 * (w >> 1) + (lane & 15);
             uint32_t word = 0;
             for (int j = 0; j < 16; ++j) {
-                const uint64_t r = sb * 128 + 64 * h + 16 * w + j;  // row relative to the first row written
-                if (r < n_rows) {
+                const uint64_t r = sb * 128 + 32 * rq + 16 * (w & 1) + j;  // row relative to the first row written
+                if (r < n_rows && s < n_samples) {
                     const uint64_t key = mmix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull));
                     const uint64_t hsh = mmix64(key + s);
                     const uint32_t gq = (uint32_t)hsh, ms = (uint32_t)(hsh >> 32);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void synth_tally_kernel(unsigned long long *__
 // rows [0, n_rows) of a 2-bit row-major cohort (group-interleaved device layout of nps_kernels.h) ->
 // units of superblocks [0, ceil(n_rows/128)).  A one-time repack.  Workgroup = one superblock x 8 word columns
 // (128 samples = 4 groups): the 128 x 8 word tile comes in as 32 row groups x 128 contiguous bytes, goes through
-// LDS, and every thread assembles one output lane (64 rows of one sample) from it.
+// LDS, and every thread assembles one output lane (32 rows of two samples) from it.
 __global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint4 *__restrict__ src /* first row group */,
                                                            uint64_t src_stride_words, uint64_t n_row_groups,
                                                            uint64_t n_words, uint4 *__restrict__ units,
@@ -163,16 +166,16 @@ __global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint4 *__restri
     }
     const uint64_t g = (uint64_t)blockIdx.x * 4 + (t >> 6);
     if (g >= n_groups) return;
-    const int lane = t & 63, h = lane >> 5;
-    const int sl = 32 * (t >> 6) + (lane & 31);  // sample of the tile
-    const int cc = sl >> 4, pb = plane_bit(sl & 15);
+    const int lane = t & 63, rq = lane >> 4;
     uint32_t out[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+        const int sl = 32 * (t >> 6) + 16 * (w >> 1) + (lane & 15);  // sample of the tile
+        const int cc = sl >> 4, pb = plane_bit(sl & 15);
         uint32_t word = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t x = tile[64 * h + 16 * w + j][cc] >> pb;  // low code bit in bit 0, high in bit 4
+            const uint32_t x = tile[32 * rq + 16 * (w & 1) + j][cc] >> pb;  // low code bit in bit 0, high in bit 4
             const uint32_t c = (x & 1u) | ((x >> 3) & 2u);
             word |= m_code(c) << (2 * j);
         }
@@ -230,39 +233,45 @@ hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t s
 // per (position, score): the decision chain of getImputedDosages for this row (nimpress.nim:523-585)
 // and the weights as signed base-256 digits in MFMA-fragment order.
 //
-// The product kernel never spreads 2-bit codes to bytes: a byte of a unit word holds the codes of four
-// rows (fields f = 0..3 at bits 2f) of one sample, and `word & (0x03030303 << 2f)` IS an int8 operand
-// register whose four bytes are c << 2f for the rows 4b + f of that word (the top field is shifted down
-// first so that its bytes stay positive).  The factor 4^f goes into the weight instead: all weights are kept
-// as V x 128 (|V| <= 2^47, so seven signed base-256 digits hold it) and row r's dosage digits are those of
-// V x 128 / 4^f (f < 3) or V x 128 (f = 3).  The is-missing operand is the bit `code == 3` moved to bit 0 of
-// its byte (`m = w & (w >> 1) & 0x55555555` once per word, `(m >> 2f) & 0x01010101` per field), its digits
-// those of V x 128 for every field -- the same precision for all rows, which the 32-bit option needs.  One
-// MFMA takes the field-f bytes of a lane's four words: K index k = 4 w + b  <->  row 64 h + 16 w + 4 b + f.
-// 15 VALU ops per 16 genotypes for both matrices instead of 24 for spreading codes to bytes.
-//   table bytes: index(sb, f, t, dm, lane, k) = ((((sb*4 + f)*NT + t)*2 + dm)*64 + lane)*16 + k
-//   row r = 128 sb + 64 h + 16 w + 4 b + f ; column c = multi_col(NT, s, digit) ; t = c / 32 ; lane = c % 32 + 32 h
+// The product kernel never spreads 2-bit codes to bytes.  A byte of a unit word holds the codes of four rows
+// (fields f = 0..3 at bits 2f) of one sample: byte = c0 + 4 c1 + 16 c2 + 64 c3.  Its PREFIXES
+//      v0 = byte & 3,  v1 = byte & 15,  v2 = byte & 63,  v3 = byte          (one AND each, v3 none)
+// are int8 operands as they stand, and the four codes are linear in them (c1 = (v1 - v0) / 4, ...), so
+//      sum_f c_f W_f  =  v0 (W0 - W1/4) + v1 (W1/4 - W2/16) + v2 (W2/16 - W3/64) + v3 W3/64 .
+// The change of basis goes into the weights: all weights are kept as V x 128 (|V| < 2^47, the combined
+// coefficients 128 V0 - 32 V1, 32 V1 - 8 V2, 8 V2 - 2 V3, 2 V3 are exact integers below 2^55, which seven signed
+// base-256 digits hold).  v3 can reach 255, int8 operands are signed: the kernel uses v3 - 128 (`word ^
+// 0x80808080`, one op) and the missing 128 x 2 V3 = V3 x 2 (in units of 2^-F) is the same for every sample --
+// it joins the whole-locus constants of the score, summed exactly in fixed point.
+// The is-missing operand is the same construction on m = w & (w >> 1) & 0x55555555 (bit 2f of a byte: field f is
+// code 3): prefixes m & 0x01.., m & 0x05.., m & 0x15.., m itself (at most 85, no sign problem); the NaN flag of a
+// row rides along as a digit 64 x flag in the same basis.  10 VALU ops per 16 genotypes for both matrices
+// (24 for spreading codes to bytes; 15 for masking the fields one by one, the first version of this kernel).
 //
-// Columns.  One tile (S <= 4): column 8 s + d for digit d = 0..6, 8 s + 7 for the NaN flag.  Two tiles: tile 0
-// holds the four HIGH digits of every score (column 4 s + d - 3, d = 3..6), tile 1 the three low digits and the
-// flag (32 + 4 s + d, flag 32 + 4 s + 3).  So a caller who accepts 32-bit weights for the is-missing matrix
-// (nps_multi_set_missing_weight_bits) needs tile 1 of that matrix only where a NaN flag occurs: the weights
-// are rounded to a multiple of 256^3 and their low digits are zero.
+// One MFMA (16 samples x 64 rows) takes the prefixes f = 2p and 2p + 1 (pair p) of the two words a lane holds for
+// one half of the group: K index k = 8 e + 4 i + b  <->  byte b of word i, prefix 2 p + e  (rows 32 g + 16 i + 4 b + ..).
+//   table bytes: index(sb, p, t, dm, lane, k) = ((((sb*2 + p)*2 NT + t)*2 + dm)*64 + lane)*16 + k
+//   column c = multi_col(NT, s, digit) ; t = c / 16 (tiles of 16 columns) ; lane = c % 16 + 16 g
+//
+// Columns.  NT = 1 (S <= 4, 32 columns): column 8 s + d for digit d = 0..6, 8 s + 7 for the NaN flag.  NT = 2 (64
+// columns): columns 0..31 hold the four HIGH digits of every score (column 4 s + d - 3, d = 3..6), columns 32..63 the
+// three low digits and the flag (32 + 4 s + d, flag 32 + 4 s + 3).  So a caller who accepts 32-bit weights for the
+// is-missing matrix (nps_multi_set_missing_weight_bits) needs the upper 32 columns of that matrix only where a NaN
+// flag occurs: the weights are rounded to a multiple of 256^3 and their low digits are zero.
 static __host__ __device__ __forceinline__ int multi_col(int NT, int s, int d /* 0..6, 7 = flag */) {
     if (NT == 1) return 8 * s + d;
     return d >= 3 && d < 7 ? 4 * s + d - 3 : 32 + 4 * s + (d == 7 ? 3 : d);
 }
 
-// the eight digit bytes of one weight (seven signed base-256 digits of V x 128 / 4^f, then the flag)
-static __device__ __forceinline__ void weight_digits(long long V, int dm, int f, int flag, bool coarse, int (&d)[8]) {
-    V *= (dm == 1 || f == 3) ? 128 : (128 >> (2 * f));
+// the seven signed base-256 digits of a coefficient (already scaled: see above)
+static __device__ __forceinline__ void weight_digits(long long V, bool coarse, int (&d)[8]) {
     if (coarse) V = ((V + (1ll << 23)) >> 24) << 24;  // nearest multiple of 256^3 (digits 0..2 become zero)
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         d[k] = (int)((V + 128) & 255) - 128;
         V = (V - d[k]) >> 8;
     }
-    d[7] = flag;
+    d[7] = 0;
 }
 
 struct MultiState {          // per score, on the device
@@ -274,23 +283,23 @@ struct MultiState {          // per score, on the device
     double pad[2];
 };
 
-// One thread per (superblock, row half h, field f, score slot s): the 16 rows 128 sb + 64 h + 16 w + 4 b + f
-// (k = 4 w + b) whose digits make ONE 16-byte MFMA fragment per digit column and matrix -- 16 whole-fragment stores
-// instead of 256 scattered bytes.  Score slots S .. 4 NT - 1 (unused columns) and rows past n_desc get zeros, so
-// the table needs no memset.
+// One thread per (superblock, row quarter g, word i, score slot s): the 16 rows 128 sb + 32 g + 16 i + 4 b + f
+// (b = byte, f = field) -- whole bytes, because the prefix basis couples the four fields of a byte.  It writes
+// 32-bit pieces of the fragments: word 2 e + i of lane (column, g) in the tables of pair p holds prefix 2 p + e.
+// Score slots S .. 4 NT - 1 (unused columns) and rows past n_desc get zeros, so the table needs no memset.
 __global__ __launch_bounds__(256) void multi_params_kernel(
     const unsigned long long *__restrict__ tally /* first cohort row of this call */,
     const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int NT, uint64_t n_samples,
-    DevParams p, const int *__restrict__ F /* [S] */, uint4 *__restrict__ table, MultiState *__restrict__ state,
+    DevParams p, const int *__restrict__ F /* [S] */, uint32_t *__restrict__ table, MultiState *__restrict__ state,
     int coarse_missing, uint32_t n_sb) {
-    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // (sb, h, f): f fastest, so 4 threads read 4 adjacent rows
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // (sb, g, i)
     const int s = blockIdx.y;
     if (u >= (uint64_t)n_sb * 8) return;
     const uint64_t sb = u >> 3;
-    const int h = (int)((u >> 2) & 1), f = (int)(u & 3);
+    const int g = (int)((u >> 1) & 3), wi = (int)(u & 1);
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const int fx = s < S ? F[s] : 0;
-    uint32_t frag[2][8][4];  // [matrix][digit][word w]: byte b of word w = row k = 4 w + b
+    uint32_t frag[2][8][4];  // [matrix][digit][prefix f]: byte b = the coefficient digit of (byte b, prefix f)
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
@@ -299,82 +308,102 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
             for (int w = 0; w < 4; ++w) frag[dm][k][w] = 0;
     unsigned long long n_used = 0, c_lo = 0, c_hi = 0;
     bool c_nan = false, any_m_nan = false;
+    auto add_const = [&](long long V) {  // exact, order-independent sums of both halves
+        c_lo += (unsigned long long)(V & 0xffffffffll);
+        c_hi += (unsigned long long)(V >> 32);
+    };
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint64_t j = sb * 128 + 64 * h + 16 * (k >> 2) + 4 * (k & 3) + f;
-        if (s >= S || j >= n_desc) continue;
-        const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
-        double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
-        int used = 0, has_const = 0;
-        const bool rie = d.ref_is_effect != 0;
-        auto locus = [&]() {  // imputeLocusDosages nimpress.nim:417-447
-            if (p.imp_locus == NPS_LOCUS_IGNORE) return;
-            used = 1;
-            has_const = 1;
-            cst = (p.imp_locus == NPS_LOCUS_PS ? d.eaf * 2.0 : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0) : nan) *
-                  d.beta;
-        };
-        if (d.kind == NPS_ROW_PRESENT) {
-            const unsigned long long t = tally[j];
-            const uint64_t nmiss = t >> 32, neff = t & 0xffffffffull, ngen = n_samples - nmiss;
-            const double missingrate = (double)nmiss / (double)n_samples;
-            if (missingrate > p.max_missing_rate) {  // :565-571
-                locus();
-            } else {  // :582-585 -> imputeSampleDosages :450-481
-                used = 1;
-                double imp;
-                switch (p.imp_sample) {
-                case NPS_SAMPLE_PS: imp = d.eaf * 2.0; break;
-                case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
-                case NPS_SAMPLE_FAIL: imp = nan; break;
-                default:
-                    if ((double)ngen >= p.min_cs)
-                        imp = (double)neff / (double)ngen;
-                    else
-                        imp = p.imp_sample == NPS_SAMPLE_INT_PS ? d.eaf * 2.0 : nan;
-                    break;
-                }
-                wD = d.beta;
-                // a missing genotype has code 3: it already got 3 x beta from the dosage matrix
-                wM = imp * d.beta - 3.0 * d.beta;
-            }
-        } else if (d.kind == NPS_ROW_ABSENT) {  // :536-551
-            if (p.imp_missing == NPS_MISSING_HOMREF) {
+    for (int b = 0; b < 4; ++b) {
+        long long VD[4] = {0, 0, 0, 0}, VM[4] = {0, 0, 0, 0};
+        int flag[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint64_t j = sb * 128 + 32 * g + 16 * wi + 4 * b + f;
+            if (s >= S || j >= n_desc) continue;
+            const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
+            double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
+            int used = 0, has_const = 0;
+            const bool rie = d.ref_is_effect != 0;
+            auto locus = [&]() {  // imputeLocusDosages nimpress.nim:417-447
+                if (p.imp_locus == NPS_LOCUS_IGNORE) return;
                 used = 1;
                 has_const = 1;
-                cst = (rie ? 2.0 : 0.0) * d.beta;
+                cst = (p.imp_locus == NPS_LOCUS_PS ? d.eaf * 2.0 : p.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0) : nan) *
+                      d.beta;
+            };
+            if (d.kind == NPS_ROW_PRESENT) {
+                const unsigned long long t = tally[j];
+                const uint64_t nmiss = t >> 32, neff = t & 0xffffffffull, ngen = n_samples - nmiss;
+                const double missingrate = (double)nmiss / (double)n_samples;
+                if (missingrate > p.max_missing_rate) {  // :565-571
+                    locus();
+                } else {  // :582-585 -> imputeSampleDosages :450-481
+                    used = 1;
+                    double imp;
+                    switch (p.imp_sample) {
+                    case NPS_SAMPLE_PS: imp = d.eaf * 2.0; break;
+                    case NPS_SAMPLE_HOMREF: imp = rie ? 2.0 : 0.0; break;
+                    case NPS_SAMPLE_FAIL: imp = nan; break;
+                    default:
+                        if ((double)ngen >= p.min_cs)
+                            imp = (double)neff / (double)ngen;
+                        else
+                            imp = p.imp_sample == NPS_SAMPLE_INT_PS ? d.eaf * 2.0 : nan;
+                        break;
+                    }
+                    wD = d.beta;
+                    // a missing genotype has code 3: it already got 3 x beta from the dosage matrix
+                    wM = imp * d.beta - 3.0 * d.beta;
+                }
+            } else if (d.kind == NPS_ROW_ABSENT) {  // :536-551
+                if (p.imp_missing == NPS_MISSING_HOMREF) {
+                    used = 1;
+                    has_const = 1;
+                    cst = (rie ? 2.0 : 0.0) * d.beta;
+                }
+            } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
+                locus();
+            }  // else: the row is not part of this score
+            const bool m_nan = !(fabs(wM) < __builtin_huge_val());  // NaN, or an infinite eaf: llrint(inf) is undefined
+            VD[f] = llrint(ldexp(wD, fx));
+            VM[f] = m_nan ? 0ll : llrint(ldexp(wM, fx));
+            flag[f] = m_nan ? 1 : 0;
+            any_m_nan |= m_nan;
+            n_used += used;
+            if (has_const) {
+                if (!(fabs(cst) < __builtin_huge_val()))
+                    c_nan = true;
+                else
+                    add_const(llrint(ldexp(cst, fx)));
             }
-        } else if (d.kind == NPS_ROW_UNCOVERED || d.kind == NPS_ROW_FILTERED) {  // :526-531, :553-558
-            locus();
-        }  // else: the row is not part of this score
-        const bool m_nan = !(fabs(wM) < __builtin_huge_val());  // NaN, or an infinite eaf: llrint(inf) is undefined
-        int dd[8], dmm[8];
-        weight_digits(llrint(ldexp(wD, fx)), 0, f, 0, false, dd);
-        weight_digits(m_nan ? 0ll : llrint(ldexp(wM, fx)), 1, f, m_nan ? 1 : 0, coarse_missing && NT == 2, dmm);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            frag[0][q][k >> 2] |= (uint32_t)(dd[q] & 255) << (8 * (k & 3));
-            frag[1][q][k >> 2] |= (uint32_t)(dmm[q] & 255) << (8 * (k & 3));
         }
-        any_m_nan |= m_nan;
-        n_used += used;
-        if (has_const) {
-            if (!(fabs(cst) < __builtin_huge_val())) {
-                c_nan = true;
-            } else {
-                const long long V = llrint(ldexp(cst, fx));  // exact, order-independent sums of both halves
-                c_lo += (unsigned long long)(V & 0xffffffffll);
-                c_hi += (unsigned long long)(V >> 32);
+        add_const(2 * VD[3]);  // the kernel's top operand is v3 - 128 (see above)
+        // codes -> prefixes: the coefficients of v0 .. v3, scaled by 128
+        const long long cD[4] = {128 * VD[0] - 32 * VD[1], 32 * VD[1] - 8 * VD[2], 8 * VD[2] - 2 * VD[3], 2 * VD[3]};
+        const long long cM[4] = {128 * VM[0] - 32 * VM[1], 32 * VM[1] - 8 * VM[2], 8 * VM[2] - 2 * VM[3], 2 * VM[3]};
+        const int cF[4] = {64 * flag[0] - 16 * flag[1], 16 * flag[1] - 4 * flag[2], 4 * flag[2] - flag[3], flag[3]};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            int dd[8], dmm[8];
+            weight_digits(cD[f], false, dd);
+            weight_digits(cM[f], coarse_missing && NT == 2, dmm);
+            dmm[7] = cF[f];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                frag[0][q][f] |= (uint32_t)(dd[q] & 255) << (8 * b);
+                frag[1][q][f] |= (uint32_t)(dmm[q] & 255) << (8 * b);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int c = multi_col(NT, s, q), t = c >> 5, lane = (c & 31) + 32 * h;
+        const int c = multi_col(NT, s, q), t = c >> 4, lane = (c & 15) + 16 * g;
 #pragma unroll
         for (int dm = 0; dm < 2; ++dm)
-            table[(((sb * 4 + f) * NT + t) * 2 + dm) * 64 + lane] =
-                make_uint4(frag[dm][q][0], frag[dm][q][1], frag[dm][q][2], frag[dm][q][3]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                table[(((((sb * 2 + (f >> 1)) * (2 * NT) + t) * 2 + dm) * 64 + lane) << 2) + 2 * (f & 1) + wi] =
+                    frag[dm][q][f];
     }
     if (s >= S) return;
     if (any_m_nan) atomicOr(&state[0].m_low, 1ull);
@@ -414,8 +443,11 @@ __global__ __launch_bounds__(256) void multi_sbflag_kernel(const unsigned long l
 //     kStage superblocks ahead into the other half of a double buffer, one workgroup barrier per stage;
 //   * the wave's own units (GW x 1 KiB per superblock): a private ring, kStage superblocks ahead.
 // The wave counts its DMAs itself (s_waitcnt vmcnt(N), in order): per step its table pieces, then GW units.
-// Per superblock and group: 60 VALU ops make the 8 operand register sets (4 fields x {dosage, is-missing};
-// see weight_digits) for 4 x NT x 2 MFMAs.
+// Per superblock and group of 32 samples: 40 VALU ops make the 8 operand register sets (2 sample halves x 2 prefix
+// pairs x {dosage, is-missing}; see weight_digits) for 2 x 2 x 2 NT x 2 MFMAs of 16 x 16 x 64.  An MFMA of this
+// shape holds the SIMD's vector issue for half of its 16 cycles: what the other waves' vector work may cost is
+// two ops per MFMA, and the first version of this kernel (60 ops per group) sat exactly on that limit -- 69 % of the
+// matrix pipe's cycles (profiles/r04_pmc_multi.txt).
 //
 // The vector work of one wave overlaps the matrix work of the other three waves of its SIMD only while
 // the waves are out of step; a workgroup barrier puts them back in step, hence kStage > 1.
@@ -465,16 +497,17 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
     const uint32_t sb_a = chunk * sb_per_chunk, sb_b = min(n_sb, sb_a + sb_per_chunk);
     const uint64_t g0 = ((uint64_t)blockIdx.x * WAVES + wave) * GW;
     if (sb_a >= sb_b) return;  // (whole workgroup)
-    // tile 1 of the is-missing matrix: always with full-width weights, else only if a NaN flag is set
+    // columns 32..63 of the is-missing matrix: always with full-width weights, else only if a NaN flag is set
     const bool m_low = NT == 1 || m_low_always || __builtin_amdgcn_readfirstlane((int)state[0].m_low) != 0;
 
-    v16i acc[GW][NT];
+    constexpr int NT16 = 2 * NT;  // tiles of 16 columns
+    v4i acc[GW][2][NT16];         // [group][sample half][tile]
 #pragma unroll
     for (int a = 0; a < GW; ++a)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int hs = 0; hs < 2; ++hs)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0;
+            for (int t = 0; t < NT16; ++t) acc[a][hs][t] = v4i{0, 0, 0, 0};
 
     // Every wave issues the same DMAs in every step (the counted waits rely on it): addresses past the
     // chunk / past the last group are clamped to valid ones, what they fetch is never used.
@@ -523,34 +556,45 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
             if (sb < sb_b) {
                 const bool has_m = sb_has_missing[sb] != 0;  // (uniform: a scalar load)
                 uint32_t miss[GW][4];  // bit 2f of a byte: field f is code 3
-#pragma unroll
-                for (int a = 0; a < GW; ++a)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) miss[a][i] = wd[a][i] & (wd[a][i] >> 1) & 0x55555555u;
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    v4i D[GW], M[GW];
+                if (has_m) {
 #pragma unroll
                     for (int a = 0; a < GW; ++a)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            D[a][i] = f < 3 ? (int)(wd[a][i] & (0x03030303u << (2 * f)))
-                                            : (int)((wd[a][i] >> 6) & 0x03030303u);
-                            M[a][i] = (int)((miss[a][i] >> (2 * f)) & 0x01010101u);
-                        }
+                        for (int i = 0; i < 4; ++i) miss[a][i] = wd[a][i] & (wd[a][i] >> 1) & 0x55555555u;
+                }
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const uint4 bd = lds.tab[buf][k][((f * NT + t) * 2 + 0) * 64 + lane];
-                        const v4i BD = {(int)bd.x, (int)bd.y, (int)bd.z, (int)bd.w};
+                for (int p = 0; p < 2; ++p) {  // prefix pair: prefixes 2p, 2p + 1 (see weight_digits)
+                    // first all of the dosage matrix, then all of the is-missing matrix: one set of operand
+                    // registers alive at a time (the kernel sits at the 128-VGPR cap of a 16-wave workgroup)
+#pragma unroll
+                    for (int dm = 0; dm < 2; ++dm) {
+                        if (dm == 1 && !has_m) break;
+                        v4i A[GW][2];
 #pragma unroll
                         for (int a = 0; a < GW; ++a)
-                            acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(D[a], BD, acc[a][t], 0, 0, 0);
-                        if (has_m && (t == 0 || m_low)) {
-                            const uint4 bm = lds.tab[buf][k][((f * NT + t) * 2 + 1) * 64 + lane];
-                            const v4i BM = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+                            for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int f = 2 * p + (i >> 1);
+                                    const uint32_t w = dm == 0 ? wd[a][2 * hs + (i & 1)] : miss[a][2 * hs + (i & 1)];
+                                    if (dm == 0)
+                                        A[a][hs][i] = f == 0 ? (int)(w & 0x03030303u) : f == 1 ? (int)(w & 0x0F0F0F0Fu)
+                                                    : f == 2 ? (int)(w & 0x3F3F3F3Fu) : (int)(w ^ 0x80808080u);
+                                    else
+                                        A[a][hs][i] = f == 0 ? (int)(w & 0x01010101u) : f == 1 ? (int)(w & 0x05050505u)
+                                                    : f == 2 ? (int)(w & 0x15151515u) : (int)w;
+                                }
+#pragma unroll
+                        for (int t = 0; t < NT16; ++t) {
+                            if (dm == 1 && !(t < 2 || m_low)) break;  // (NT = 1: m_low is always set)
+                            const uint4 bq = lds.tab[buf][k][((p * NT16 + t) * 2 + dm) * 64 + lane];
+                            const v4i B = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
 #pragma unroll
                             for (int a = 0; a < GW; ++a)
-                                acc[a][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(M[a], BM, acc[a][t], 0, 0, 0);
+#pragma unroll
+                                for (int hs = 0; hs < 2; ++hs)
+                                    acc[a][hs][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][hs], B, acc[a][hs][t], 0, 0, 0);
                         }
                     }
                 }
@@ -563,18 +607,20 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
         __builtin_amdgcn_s_barrier();
     }
     wait_vm<0>();  // (clamped prefetches of the last stage: nothing may land after the workgroup has ended)
-    // C/D map of the 32x32 MFMA shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // C/D map of the 16x16 MFMA shapes: column = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
     for (int a = 0; a < GW; ++a) {
         if (g0 + a >= n_groups) continue;
         int32_t *dst = partial + (((uint64_t)chunk * n_groups + g0 + a) * 32) * (NT * 32);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int hs = 0; hs < 2; ++hs)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int samp = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                dst[(uint64_t)samp * (NT * 32) + 32 * t + (lane & 31)] = acc[a][t][r];
-            }
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int samp = 16 * hs + 4 * (lane >> 4) + r;
+                    dst[(uint64_t)samp * (NT * 32) + 16 * t + (lane & 15)] = acc[a][hs][t][r];
+                }
     }
 }
 
@@ -655,7 +701,7 @@ hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally
     const uint32_t n_sb = (uint32_t)((n_desc + 127) / 128);
     (void)hipGetLastError();
     hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)(((uint64_t)n_sb * 8 + 255) / 256), (uint32_t)(4 * NT)),
-                       dim3(256), 0, st, d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (uint4 *)d_table,
+                       dim3(256), 0, st, d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (uint32_t *)d_table,
                        (MultiState *)d_state, coarse_missing, n_sb);
     return hipGetLastError();
 }
@@ -672,9 +718,10 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
     uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
     q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 16));
     q = std::min<uint32_t>(q, 64);
-    // int32 digit sums: |operand byte x digit| <= 64 x 128 per row, so a chunk holds at most 2^31 / 8192 rows
-    // = 2 048 superblocks
-    q = std::max<uint32_t>(q, (pl.n_sb + 2039) / 2040);
+    // int32 digit sums: the operand bytes of one byte of genotypes (four rows, both matrices) are at most
+    // 3 + 15 + 63 + 128 and 1 + 5 + 21 + 85, a digit at most 128: 41 088 per four rows, so a chunk holds at most
+    // 2^31 / 10 272 rows = 1 633 superblocks
+    q = std::max<uint32_t>(q, (pl.n_sb + 1535) / 1536);
     pl.sb_per_chunk = (pl.n_sb + q - 1) / q;
     pl.n_chunks = pl.sb_per_chunk ? (pl.n_sb + pl.sb_per_chunk - 1) / pl.sb_per_chunk : 0;
     return pl;

@@ -106,14 +106,17 @@ def test_multi_vs_oracle_converted_cohort(shape, pk, bits):
     for s in range(S):
         keep = descs[s]["kind"] != capi.ROW_NOT_IN_SCORE
         if bits == 32:
-            # the documented bound (include/nps.h): (missing genotypes of the sample) x 2^-30 x B, here with all
-            # rows of the score as the count, after the division by 2 nloci
+            # the documented bound (include/nps.h): (missing genotypes of the sample) x 2^-24 x B, after the
+            # division by 2 nloci
             d = descs[s][keep]
             B = float(np.max(np.abs(d["beta"])) * (3.0 + max(2.0, 2.0 * float(np.max(np.abs(np.nan_to_num(d["eaf"])))))))
-            bound = keep.sum() * 2.0 ** -30 * B / max(2.0 * int(ref_nloci[s]), 1)
+            # (NPS_CODE_MISSING = 2; 16 codes per word)
+            plain = ((np.asarray(codes)[keep][:, :, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(keep.sum(), -1)
+            n_missing = (plain[:, :n] == 2).sum(axis=0)
+            bound = (n_missing * 2.0 ** -24 * B / max(2.0 * int(ref_nloci[s]), 1))
             ok = ~np.isnan(ref[s])
             assert np.array_equal(np.isnan(got[s]), np.isnan(ref[s]))
-            assert np.all(np.abs(got[s][ok] - ref[s][ok]) <= bound + REL_TOL * np.abs(ref[s][ok])), s
+            assert np.all(np.abs(got[s][ok] - ref[s][ok]) <= bound[ok] + REL_TOL * np.abs(ref[s][ok])), s
             continue
         assert rel_err(got[s], ref[s], float(np.sum(np.abs(descs[s]["beta"][keep]))), int(ref_nloci[s])) <= REL_TOL, s
     # a second call on the same context after a reset gives the same bits

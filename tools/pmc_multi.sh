@@ -1,15 +1,17 @@
 #!/bin/bash
 # dev tool: SQ counter passes of the multi-score product kernel (8 scores x 1M rows x 500k samples)
-#   tools/pmc_multi.sh [out-tag]     -> gpurun_out/pmc_multi_<tag>/summary.txt
+#   tools/pmc_multi.sh [out-tag [qb_multi.py options]]     -> gpurun_out/pmc_multi_<tag>/summary.txt
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r02}
+shift
+QB=("$@")
 O=$R/gpurun_out/pmc_multi_$TAG
 mkdir -p "$O"
 : > "$O/summary.txt"
 run() { # name, counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d "$O/$n" -o "$n" --output-format csv -- python3 "$R/tools/qb_multi.py" --steps 3 > "$O/$n.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d "$O/$n" -o "$n" --output-format csv -- python3 "$R/tools/qb_multi.py" --steps 3 "${QB[@]}" > "$O/$n.log" 2>&1
   f=$(ls "$O/$n"/*/*counter_collection.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(ls "$O/$n"/*counter_collection.csv | head -1)
   python3 - "$f" <<'PY' | tee -a "$O/summary.txt"
 import csv,sys,collections
