@@ -444,7 +444,8 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     cohort (nps_score_cohort_multi: int8 MFMA over the NPS_FMT_GT2M layout, row tallies from the packer),
     against S passes of the single-score kernel.  One step = reset -> weights as base-256 digits ->
     the product -> fold -> /(2 nloci) + offset for all S scores, result in a device buffer.  Measured with
-    full-width weights (the headline of this object) and with nps_multi_set_missing_weight_bits(32)."""
+    full-width weights (the headline of this object), with nps_multi_set_missing_weight_bits(32) and with
+    41-bit weights (nps_multidef_create_bits: six digits per weight instead of seven)."""
     import torch
     _, eaf, miss = synth_score(m, seed)
     th, tm, tmi = hwe_thresholds(eaf, miss)
@@ -474,7 +475,7 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     for s in range(S):
         descs[s]["beta"] = np.round(np.random.default_rng(seed + 1000 + s).normal(0.0, 0.02, m), 4)
         descs[s]["eaf"] = eaf
-    mdef = capi.MultiDef(descs, device=device)
+    mdefs = {49: capi.MultiDef(descs, device=device), 41: capi.MultiDef(descs, device=device, weight_bits=41)}
     msc = capi.MultiScorer(n, capi.make_params(), S, device=device)
     d_scores = torch.empty((S, n), dtype=torch.float64, device="cuda")
     off = np.zeros(S)
@@ -509,12 +510,12 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
                     "checked": "scores 1 and %d: %d samples x all %d rows by oracle/refcpu.c (ref_score_subset); "
                                "%d whole-row tallies recounted" % (S, samples.size, m, rows.size)}
 
-    def step():
-        msc.reset()
-        msc.score_cohort(co, mdef)
-        return msc.finish_device(off, d_scores.data_ptr())
+    def measure(bits, wbits=49):
+        def step():
+            msc.reset()
+            msc.score_cohort(co, mdefs[wbits])
+            return msc.finish_device(off, d_scores.data_ptr())
 
-    def measure(bits):
         msc.set_missing_weight_bits(bits)
         nloci = step()
         torch.cuda.synchronize()
@@ -527,9 +528,11 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / steps
         ms_params, ms_prod, ms_fold = (float(np.mean([p[k] for p in prod_ms])) for k in range(3))
-        tiles = (8 * S + 31) // 32
-        # dosage matrix: every column tile; is-missing matrix: every tile, or the high-digit tile only
-        int8_ops = 2.0 * n * m * 32 * (tiles + (1 if bits == 32 and tiles == 2 else tiles))
+        nd = 7 if wbits == 49 else 6
+        # tiles of 16 columns (nps_multi.hip multi_plan): the dosage matrix's digits; the is-missing matrix's, or its
+        # four leading digits only
+        td = (nd * S + 15) // 16
+        int8_ops = 2.0 * n * m * 16 * (td + ((4 * S + 15) // 16 if bits == 32 else td))
         r = {"ms_per_pass": wall * 1e3, "ms_per_score": wall * 1e3 / S, "value": S * float(n) * m / wall,
              "kernel_ms": {"weights_to_digits": ms_params, "product": ms_prod, "fold": ms_fold},
              "int8_TOPs": int8_ops / (ms_prod * 1e-3) / 1e12, "hbm_GBps": alg / (ms_prod * 1e-3) / 1e9}
@@ -540,6 +543,7 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     alg = m * ((n + 15) // 16) * 4 + 40 * m * S + 8 * n * S
     full, nloci = measure(56)
     fast, _ = measure(32)
+    w41, _ = measure(56, 41)
     # the same cohort without its missing genotypes (imputed hard calls have none): superblocks whose rows have no
     # missing sample skip the is-missing matrix (timing only; the parity of that path is tests/test_gpu_multi.py's)
     checker, zeros = None, np.zeros_like(tmi)
@@ -547,6 +551,7 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
         b = min(m, a + (1 << 15))
         co.synth_at(a, a, seed, th[a:b], tm[a:b], zeros[a:b])
     nomiss, _ = measure(56)
+    nomiss41, _ = measure(56, 41)
     out = {"workload": "%d score definitions x %d rows x %d samples in one pass (NPS_FMT_GT2M cohort, int8 MFMA, "
                        "7 base-256 digits per weight), CLI-default imputation flags" % (S, m, n),
            "scores": S, "value": full["value"], "unit": "genotype-dosage accumulations/s (x scores)",
@@ -568,13 +573,20 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
                                 "power cap allows under int8 MFMA load (DESIGN.md 4.3)"},
            "missing_weight_bits_32": {k: fast[k] for k in ("ms_per_pass", "ms_per_score", "value", "kernel_ms",
                                                             "int8_TOPs")},
+           "weight_bits_41": dict({k: w41[k] for k in ("ms_per_pass", "ms_per_score", "value", "kernel_ms", "int8_TOPs")},
+                                  what="nps_multidef_create_bits(.., 41): six base-256 digits per weight, a quarter "
+                                       "fewer matrix instructions for 8 scores; an option, not the default: a sample "
+                                       "whose terms cancel is not within 1e-6 of its own score (include/nps.h)",
+                                  cohort_without_missing_genotypes_ms_per_pass=nomiss41["ms_per_pass"]),
            "cohort_without_missing_genotypes": {k: nomiss[k] for k in ("ms_per_pass", "ms_per_score", "value",
                                                                        "kernel_ms")}}
     if "score_delta_vs_reference" in full:
         out["score_delta_vs_reference"] = full["score_delta_vs_reference"]
         out["missing_weight_bits_32"]["score_delta_vs_reference"] = fast["score_delta_vs_reference"]
+        out["weight_bits_41"]["score_delta_vs_reference"] = w41["score_delta_vs_reference"]
     msc.close()
-    mdef.close()
+    for d in mdefs.values():
+        d.close()
     co.close()
     return out
 
@@ -1067,13 +1079,14 @@ def main():
 def parity_failures(obj, path=""):
     """Every place of the bench line where a parity check did not hold: a `score_delta_vs_reference` (headline or
     secondary) with a false `within...`, `nloci_equal`, `tally_recount_equal` or `tallies_and_nloci_equal`, and any
-    `..._equal` / `outputs_equal...` of the end-to-end legs.  The one documented exception is the off-by-default
-    `missing_weight_bits_32` option of the multi-score pass (not inside the bar, reported as such)."""
+    `..._equal` / `outputs_equal...` of the end-to-end legs.  The documented exceptions are the two off-by-default
+    precision options of the multi-score pass, `missing_weight_bits_32` and `weight_bits_41` (not
+    inside the bar for every sample, reported as such)."""
     bad = []
     if isinstance(obj, dict):
         for k, v in obj.items():
             here = path + "/" + str(k)
-            if k == "missing_weight_bits_32":
+            if k in ("missing_weight_bits_32", "weight_bits_41"):
                 continue
             if isinstance(v, bool) and not v and (
                     k.startswith("within") or k in ("nloci_equal", "tally_recount_equal", "tallies_and_nloci_equal")

@@ -339,8 +339,15 @@ int nps_score_cohort_def(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0
 #define NPS_MULTI_MAX_SCORES 8
 typedef struct nps_multi nps_multi;
 typedef struct nps_multidef nps_multidef;
-/* rows: [n_scores][n_desc], score-major */
+/* rows: [n_scores][n_desc], score-major.  The weights of a definition are kept in fixed point, 49 bits below the
+ * largest weight of the score (seven base-256 digits on the matrix cores).  nps_multidef_create_bits(.., 41) keeps 41
+ * bits (six digits): every term of a score is then within 2^-41 of the largest weight, a typical score within 1e-10
+ * relative -- but a sample whose terms cancel to 1e-5 of the typical size is only within ~1e-5 of its own value, so
+ * it is NOT inside the 1e-6 relative bar for every sample and stays an option; with 5, 6 or 8 scores the pass needs
+ * a quarter fewer matrix instructions for it. */
 int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc);
+int nps_multidef_create_bits(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc,
+                             int weight_bits /* 49, 41; 0 = default (49) */);
 void nps_multidef_destroy(nps_multidef *d);
 int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_params *params, int n_scores);
 /* Width of the fixed-point weight `(imputed dosage - 3) x beta` that a MISSING genotype adds on top of the
@@ -349,7 +356,7 @@ int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_
  * multiplies byte prefixes of four packed genotypes, so a weight is known to 2^-24 of the largest one at worst) --
  * per sample an error of at most (its missing genotypes) x 2^-24 x B before the division by 2 nloci,
  * B = max|beta| x (3 + max(2, 2 max|eaf|)) of the score, typically the square root of that count -- and with more
- * than 4 scores the pass needs a quarter fewer matrix instructions.  NaN imputation values
+ * than 4 scores the pass needs up to a quarter fewer matrix instructions.  NaN imputation values
  * (imp-sample fail / int_fail below --mincs) are exact in both modes.  Applies to the following calls. */
 int nps_multi_set_missing_weight_bits(nps_multi *m, int bits);
 /* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset.

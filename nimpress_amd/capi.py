@@ -58,7 +58,7 @@ SYMBOLS = [
     "nps_cohort_optimize",
     "nps_cohort_destroy",
     "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream", "nps_fused_geometry",
-    "nps_multidef_create", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
+    "nps_multidef_create", "nps_multidef_create_bits", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
     "nps_cohort_convert", "nps_cohort_row_tallies", "nps_multi_set_missing_weight_bits",
     "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device", "nps_multi_partial",
@@ -176,6 +176,7 @@ def load(with_torch: bool = True):
     u32p = C.POINTER(C.c_uint32)
     L.nps_fused_geometry.argtypes = [vp, i32, u64, u32p, u32p, u32p]
     L.nps_multidef_create.argtypes = [C.POINTER(vp), i32, vp, i32, u64]
+    L.nps_multidef_create_bits.argtypes = [C.POINTER(vp), i32, vp, i32, u64, i32]
     L.nps_multidef_destroy.argtypes = [vp]
     L.nps_multidef_destroy.restype = None
     L.nps_multi_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams), i32]
@@ -454,12 +455,14 @@ class Scorer:
 class MultiDef:
     """S score definitions over the same cohort rows ([S, n_desc] row descriptors), resident on the device"""
 
-    def __init__(self, rows: np.ndarray, device: int = 0):
+    def __init__(self, rows: np.ndarray, device: int = 0, weight_bits: int = 0):
+        """weight_bits: 49 (default: seven digits per weight) or 41 (six) -- include/nps.h"""
         rows = np.ascontiguousarray(rows, dtype=ROW_DESC_DTYPE)
         assert rows.ndim == 2
         self._h = C.c_void_p()
         self.n_scores, self.n_desc = rows.shape
-        _check(load().nps_multidef_create(C.byref(self._h), device, rows.ctypes.data, self.n_scores, self.n_desc))
+        _check(load().nps_multidef_create_bits(C.byref(self._h), device, rows.ctypes.data, self.n_scores, self.n_desc,
+                                               weight_bits))
 
     def close(self):
         if self._h:

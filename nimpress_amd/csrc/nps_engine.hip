@@ -1982,13 +1982,17 @@ struct nps_multidef {
     int S = 0;
     uint64_t n_desc = 0;
     nps_row_desc *d_desc = nullptr;  // [S][n_desc]
-    int *d_F = nullptr;              // fixed-point exponent per score: weight * 2^F is an integer below 2^47
+    int *d_F = nullptr;              // fixed-point exponent per score: weight * 2^F is an integer below 2^(8 ND - 9)
+    int ND = 7;                      // base-256 digits per weight
 };
 
-extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores,
-                                   uint64_t n_desc) {
+extern "C" int nps_multidef_create_bits(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores,
+                                        uint64_t n_desc, int weight_bits) {
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
+    if (weight_bits != 0 && weight_bits != 41 && weight_bits != 49)
+        return fail(NPS_E_INVAL, "weight_bits must be 41 or 49 (0 = default 49), not %d", weight_bits);
+    const int ND = weight_bits == 41 ? 6 : 7;
     if (n_scores < 1 || n_scores > NPS_MULTI_MAX_SCORES)
         return fail(NPS_E_INVAL, "n_scores %d outside 1..%d", n_scores, NPS_MULTI_MAX_SCORES);
     if (n_desc && !rows) return fail(NPS_E_INVAL, "rows is NULL");
@@ -2011,7 +2015,7 @@ extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row
         const double bound = maxb * (3.0 + std::max(2.0, 2.0 * maxe));
         int e = 0;
         if (bound > 0.0) (void)std::frexp(bound, &e);  // bound < 2^e
-        F[s] = 47 - e;
+        F[s] = 8 * ND - 9 - e;  // the kernel's coefficients (up to 160 x weight) stay below 2^(8 ND - 1)
     }
     int rc = select_device(device);
     if (rc) return rc;
@@ -2019,6 +2023,7 @@ extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row
     if (!d) return fail(NPS_E_NOMEM, "out of host memory");
     d->device = device;
     d->S = n_scores;
+    d->ND = ND;
     d->n_desc = n_desc;
     hipError_t e = hipMalloc(&d->d_F, sizeof(int) * NPS_MULTI_MAX_SCORES);
     if (e == hipSuccess) e = hipMemcpy(d->d_F, F, sizeof(int) * n_scores, hipMemcpyHostToDevice);
@@ -2036,6 +2041,11 @@ extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row
     }
     *out = d;
     return NPS_OK;
+}
+
+extern "C" int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores,
+                                   uint64_t n_desc) {
+    return nps_multidef_create_bits(out, device, rows, n_scores, n_desc, 0);
 }
 
 extern "C" void nps_multidef_destroy(nps_multidef *d) {
@@ -2175,7 +2185,7 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
     if (rc) return rc;
     if (def->n_desc == 0) return NPS_OK;
     HIP_TRY(hipSetDevice(m->device));
-    const MultiPlan pl = multi_plan(m->n, def->n_desc, m->S, m->cus);
+    const MultiPlan pl = multi_plan(m->n, def->n_desc, m->S, def->ND, m->coarse_missing, m->cus);
     if (pl.table_bytes() + pl.flag_bytes() > m->table_cap) {
         HIP_TRY(hipStreamSynchronize(m->stream));
         (void)hipFree(m->d_table);
@@ -2202,14 +2212,14 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
     auto run = [&]() -> hipError_t {
         hipError_t e = hipEventRecord(m->ev[0], m->stream);
         if (e != hipSuccess) return e;
-        e = launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl.NT, m->n,
+        e = launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl, m->n,
                                 dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0);
         if (e != hipSuccess) return e;
         e = hipEventRecord(m->ev[1], m->stream);
         if (e != hipSuccess) return e;
         if (m->n) {
             e = launch_multi_mfma(m->stream, pl, co->d_data, cohort_row0 / 128, m->d_table, m->d_partial, m->d_state,
-                                  m->coarse_missing ? 1 : 0, co->d_row_tally + cohort_row0, def->n_desc,
+                                  co->d_row_tally + cohort_row0, def->n_desc,
                                   reinterpret_cast<uint32_t *>(static_cast<char *>(m->d_table) + pl.table_bytes()));
             if (e != hipSuccess) return e;
         }

@@ -219,20 +219,23 @@ hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, 
 hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t src_stride_words,
                                uint64_t n_samples, uint64_t n_rows, void *d_units, unsigned long long *d_tally);
 struct MultiPlan {
-    int NT = 0, GW = 0;          // column tiles of 32 (4 scores each); sample groups per wave
+    int ND = 0;                  // base-256 digits per weight (6 or 7)
+    int T = 0;                   // tiles of 16 columns: ND digit columns and one flag column per score
+    int TD = 0, TM = 0, TF0 = 0; // tiles of the dosage / the is-missing matrix (flags apart); first tile with flags
+    int GW = 0;                  // sample groups per wave
     uint64_t n_groups = 0;
     uint32_t n_sb = 0, tiles = 0, sb_per_chunk = 0, n_chunks = 0;
-    uint64_t table_bytes() const { return (uint64_t)n_sb * 4 * NT * 2 * 64 * 16; }
+    uint64_t table_bytes() const { return (uint64_t)n_sb * 2 * T * 2 * 64 * 16; }
     uint64_t flag_bytes() const { return (uint64_t)n_sb * 4; }  // one word per superblock, behind the tables
-    uint64_t partial_elems() const { return (uint64_t)n_chunks * n_groups * 32 * NT * 32; }
+    uint64_t partial_elems() const { return (uint64_t)n_chunks * n_groups * 32 * T * 16; }
 };
-MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus);
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, bool coarse_missing, int cus);
 size_t multi_state_bytes();
 hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
-                               uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
-                               void *d_table, void *d_state, int coarse_missing);
+                               uint64_t n_desc, int S, const MultiPlan &pl, uint64_t n_samples, DevParams p,
+                               const int *d_F, void *d_table, void *d_state, int coarse_missing);
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing,
+                             const void *d_table, int32_t *d_partial, const void *d_state,
                              const unsigned long long *d_tally, uint64_t n_rows, uint32_t *d_sbflag);
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state);

@@ -9,12 +9,12 @@
 // and that belongs on MFMA -- provided the arithmetic stays exact enough for the 1e-6 bar.  float64
 // MFMA runs at the vector rate and would need every genotype converted to a double.  Instead:
 //
-//   * the per-row weights are turned into FIXED-POINT integers (49 bits, times a power of two <= 128 that
-//     belongs to the operand extraction, see weight_digits) and split into seven signed base-256 digits:
-//     w = sum_k d_k 256^k / 2^(F+7).  code (int8) x digit (int8) accumulated in int32 by
-//     v_mfma_i32_16x16x64_i8 is EXACT integer arithmetic, independent of the summation order; the seven
+//   * the per-row weights are turned into FIXED-POINT integers (49 bits, 41 on request; times 128 and
+//     recombined for the operand extraction, see weight_digits) and split into ND = seven (six) signed base-256
+//     digits: w = sum_k d_k 256^k / 2^(F+7).  code (int8) x digit (int8) accumulated in int32 by
+//     v_mfma_i32_16x16x64_i8 is EXACT integer arithmetic, independent of the summation order; the
 //     digit sums of a sample are recombined in float64 at the very end.  The only error is the
-//     quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score).
+//     quantisation of the weights (2^-49 of the largest weight per row: ~1e-15 of a score; 2^-41 with six digits).
 //   * a missing genotype has code 3 in this layout: it contributes 3 x beta through the dosage
 //     matrix, and (imputed - 3) x beta through a second 0/1 matrix "is missing" (same accumulators).
 //     A weight that is NaN in the reference (imp-sample fail / int_fail below --mincs, NaN eaf) sets a
@@ -250,22 +250,27 @@ hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t s
 //
 // One MFMA (16 samples x 64 rows) takes the prefixes f = 2p and 2p + 1 (pair p) of the two words a lane holds for
 // one half of the group: K index k = 8 e + 4 i + b  <->  byte b of word i, prefix 2 p + e  (rows 32 g + 16 i + 4 b + ..).
-//   table bytes: index(sb, p, t, dm, lane, k) = ((((sb*2 + p)*2 NT + t)*2 + dm)*64 + lane)*16 + k
-//   column c = multi_col(NT, s, digit) ; t = c / 16 (tiles of 16 columns) ; lane = c % 16 + 16 g
+//   table bytes: index(sb, p, t, dm, lane, k) = ((((sb*2 + p)*T + t)*2 + dm)*64 + lane)*16 + k   (T tiles of 16 columns)
+//   column c = multi_col(S, ND, s, digit) ; t = c / 16 ; lane = c % 16 + 16 g
 //
-// Columns.  NT = 1 (S <= 4, 32 columns): column 8 s + d for digit d = 0..6, 8 s + 7 for the NaN flag.  NT = 2 (64
-// columns): columns 0..31 hold the four HIGH digits of every score (column 4 s + d - 3, d = 3..6), columns 32..63 the
-// three low digits and the flag (32 + 4 s + d, flag 32 + 4 s + 3).  So a caller who accepts 32-bit weights for the
-// is-missing matrix (nps_multi_set_missing_weight_bits) needs the upper 32 columns of that matrix only where a NaN
-// flag occurs: the weights are rounded to a multiple of 256^3 and their low digits are zero.
-static __host__ __device__ __forceinline__ int multi_col(int NT, int s, int d /* 0..6, 7 = flag */) {
-    if (NT == 1) return 8 * s + d;
-    return d >= 3 && d < 7 ? 4 * s + d - 3 : 32 + 4 * s + (d == 7 ? 3 : d);
+// Columns, most significant first: digit d of score s in column (ND - 1 - d) S + s, the NaN flags behind all
+// digits in columns ND S + s; T = ceil((ND + 1) S / 16) tiles.  So
+//   * the dosage matrix has no flags and needs the tiles below TD = ceil(ND S / 16) only; eight scores of six
+//     digits: 3 tiles, their flags alone in the fourth; of seven digits: 4 tiles, the flags in the last;
+//   * the is-missing matrix needs the same, plus the tiles from TF0 = floor(ND S / 16) on -- those holding flag
+//     columns -- in calls in which a NaN imputation value occurs at all (MultiState.m_flag);
+//   * a caller who accepts 32-bit is-missing weights (nps_multi_set_missing_weight_bits) needs the tiles below
+//     ceil(4 S / 16) of that matrix: the coefficients are rounded to a multiple of 256^(ND-4), their low digits are zero.
+static __host__ __device__ constexpr __forceinline__ int multi_col(int S, int ND, int s, int d /* 0..ND-1, ND = flag */) {
+    return d < ND ? (ND - 1 - d) * S + s : ND * S + s;
 }
 
-// the seven signed base-256 digits of a coefficient (already scaled: see above)
-static __device__ __forceinline__ void weight_digits(long long V, bool coarse, int (&d)[8]) {
-    if (coarse) V = ((V + (1ll << 23)) >> 24) << 24;  // nearest multiple of 256^3 (digits 0..2 become zero)
+// the signed base-256 digits of a coefficient (already scaled: see above; |V| < 2^(8 ND - 1))
+static __device__ __forceinline__ void weight_digits(long long V, int ND, bool coarse, int (&d)[8]) {
+    if (coarse) {  // nearest multiple of 256^(ND-4): only the four leading digits remain
+        const int sh = 8 * (ND - 4);
+        V = ((V + (1ll << (sh - 1))) >> sh) << sh;
+    }
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         d[k] = (int)((V + 128) & 255) - 128;
@@ -279,17 +284,18 @@ struct MultiState {          // per score, on the device
     long long const_lo, const_hi;  // whole-locus constants of this call in fixed point: (hi << 32) + lo
     unsigned long long const_nan;  // a whole-locus constant was NaN (imp-locus fail / NaN eaf)
     double const_sum;          // float64 sum over the calls so far
-    unsigned long long m_low;  // (score 0 only) this call's is-missing weights need tile 1: a NaN flag occurred
+    unsigned long long m_low;  // (score 0 only) m_flag: a NaN imputation value occurred in this call (flag tiles needed)
     double pad[2];
 };
 
 // One thread per (superblock, row quarter g, word i, score slot s): the 16 rows 128 sb + 32 g + 16 i + 4 b + f
 // (b = byte, f = field) -- whole bytes, because the prefix basis couples the four fields of a byte.  It writes
 // 32-bit pieces of the fragments: word 2 e + i of lane (column, g) in the tables of pair p holds prefix 2 p + e.
-// Score slots S .. 4 NT - 1 (unused columns) and rows past n_desc get zeros, so the table needs no memset.
+// blockIdx.y = score; one more (y = S) writes zeros to the columns behind the flags, rows past n_desc get zeros,
+// so the table needs no memset.
 __global__ __launch_bounds__(256) void multi_params_kernel(
     const unsigned long long *__restrict__ tally /* first cohort row of this call */,
-    const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int NT, uint64_t n_samples,
+    const nps_row_desc *__restrict__ desc /* [S][n_desc] */, uint64_t n_desc, int S, int ND, int T, uint64_t n_samples,
     DevParams p, const int *__restrict__ F /* [S] */, uint32_t *__restrict__ table, MultiState *__restrict__ state,
     int coarse_missing, uint32_t n_sb) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // (sb, g, i)
@@ -297,8 +303,15 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
     if (u >= (uint64_t)n_sb * 8) return;
     const uint64_t sb = u >> 3;
     const int g = (int)((u >> 1) & 3), wi = (int)(u & 1);
+    if (s == S) {  // the unused columns of the last tile
+        for (int c = (ND + 1) * S; c < 16 * T; ++c)
+            for (int dm = 0; dm < 2; ++dm)
+                for (int f = 0; f < 4; ++f)
+                    table[(((((sb * 2 + (f >> 1)) * T + (c >> 4)) * 2 + dm) * 64 + (c & 15) + 16 * g) << 2) + 2 * (f & 1) + wi] = 0;
+        return;
+    }
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    const int fx = s < S ? F[s] : 0;
+    const int fx = F[s];
     uint32_t frag[2][8][4];  // [matrix][digit][prefix f]: byte b = the coefficient digit of (byte b, prefix f)
 #pragma unroll
     for (int dm = 0; dm < 2; ++dm)
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const uint64_t j = sb * 128 + 32 * g + 16 * wi + 4 * b + f;
-            if (s >= S || j >= n_desc) continue;
+            if (j >= n_desc) continue;
             const nps_row_desc d = desc[(uint64_t)s * n_desc + j];
             double wD = 0.0, wM = 0.0, cst = 0.0;  // weights of the dosage / the is-missing matrix; constant
             int used = 0, has_const = 0;
@@ -385,8 +398,8 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             int dd[8], dmm[8];
-            weight_digits(cD[f], false, dd);
-            weight_digits(cM[f], coarse_missing && NT == 2, dmm);
+            weight_digits(cD[f], ND, false, dd);
+            weight_digits(cM[f], ND, coarse_missing != 0, dmm);
             dmm[7] = cF[f];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -396,16 +409,16 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = multi_col(NT, s, q), t = c >> 4, lane = (c & 15) + 16 * g;
+    for (int q = 0; q < 8; ++q) {  // digits 0..6 (those below ND), 7 = the flag
+        if (q < 7 && q >= ND) continue;
+        const int c = multi_col(S, ND, s, q < 7 ? q : ND), t = c >> 4, lane = (c & 15) + 16 * g;
 #pragma unroll
         for (int dm = 0; dm < 2; ++dm)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                table[(((((sb * 2 + (f >> 1)) * (2 * NT) + t) * 2 + dm) * 64 + lane) << 2) + 2 * (f & 1) + wi] =
+                table[(((((sb * 2 + (f >> 1)) * T + t) * 2 + dm) * 64 + lane) << 2) + 2 * (f & 1) + wi] =
                     frag[dm][q][f];
     }
-    if (s >= S) return;
     if (any_m_nan) atomicOr(&state[0].m_low, 1ull);
     if (n_used) atomicAdd(&state[s].nloci, n_used);
     if (c_nan) atomicOr(&state[s].const_nan, 1ull);
@@ -439,12 +452,12 @@ __global__ __launch_bounds__(256) void multi_sbflag_kernel(const unsigned long l
 // 1 KiB per wave instruction, no VGPR destination), because the kernel sits at the 128-VGPR cap of a
 // 16-wave workgroup and a register prefetch had nowhere to live (the compiler sank the loads to the end of
 // the step and every wave then sat out a full HBM round trip per superblock: 10 ms of a 48 ms pass):
-//   * the superblock's digit tables (NT x 8 KiB, shared by the 16 waves): one 1 KiB piece per wave, staged
+//   * the superblock's digit tables (T x 4 KiB, shared by the 16 waves): one 1 KiB piece per wave, staged
 //     kStage superblocks ahead into the other half of a double buffer, one workgroup barrier per stage;
 //   * the wave's own units (GW x 1 KiB per superblock): a private ring, kStage superblocks ahead.
 // The wave counts its DMAs itself (s_waitcnt vmcnt(N), in order): per step its table pieces, then GW units.
 // Per superblock and group of 32 samples: 40 VALU ops make the 8 operand register sets (2 sample halves x 2 prefix
-// pairs x {dosage, is-missing}; see weight_digits) for 2 x 2 x 2 NT x 2 MFMAs of 16 x 16 x 64.  An MFMA of this
+// pairs x {dosage, is-missing}; see weight_digits) for up to 2 x 2 x T x 2 MFMAs of 16 x 16 x 64.  An MFMA of this
 // shape holds the SIMD's vector issue for half of its 16 cycles: what the other waves' vector work may cost is
 // two ops per MFMA, and the first version of this kernel (60 ops per group) sat exactly on that limit -- 69 % of the
 // matrix pipe's cycles (profiles/r04_pmc_multi.txt).
@@ -453,9 +466,9 @@ __global__ __launch_bounds__(256) void multi_sbflag_kernel(const unsigned long l
 // the waves are out of step; a workgroup barrier puts them back in step, hence kStage > 1.
 constexpr int kStage = 2;  // superblocks per barrier = prefetch distance of the units
 
-template <int NT, int GW, int WAVES>
+template <int T, int GW, int WAVES>
 struct __attribute__((aligned(16))) MultiLds {
-    uint4 tab[2][kStage][4 * NT * 2 * 64];
+    uint4 tab[2][kStage][2 * T * 2 * 64];
     uint4 unit[kStage][WAVES][GW][64];
 };
 
@@ -479,29 +492,31 @@ static __device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byt
 #ifndef NPS_MULTI_GW
 #define NPS_MULTI_GW 2  // sample groups per wave; the workgroup has 32 / GW waves (-DNPS_MULTI_GW=4: measured equal)
 #endif
-template <int NT, int GW, int WAVES>
+// T tiles of 16 columns; the dosage matrix uses the tiles below TD, the is-missing matrix those below TM and, in
+// calls with a NaN imputation value, those from TF0 on (all compile-time: the MFMAs of a step must stay one
+// basic block for the scheduler to interleave the fragment reads with them).
+template <int T, int TD, int TM, int TF0, int GW, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__restrict__ units, uint64_t n_groups,
                                                           uint64_t sb_first, uint32_t n_sb, uint32_t sb_per_chunk,
                                                           const uint4 *__restrict__ table,
                                                           int32_t *__restrict__ partial,
-                                                          const MultiState *__restrict__ state, int m_low_always,
+                                                          const MultiState *__restrict__ state,
                                                           const uint32_t *__restrict__ sb_has_missing) {
-    constexpr int kTab = 4 * NT * 2 * 64;  // uint4 per superblock: 1024 (NT = 2) or 512
+    constexpr int kTab = 2 * T * 2 * 64;   // uint4 per superblock: T x 4 KiB
     constexpr int kPieces = kTab / 64;     // 1 KiB pieces of a superblock's tables
-    constexpr int kPW = kPieces >= WAVES ? kPieces / WAVES : 1;  // table DMAs per wave and step
-    static_assert(kPieces % WAVES == 0 || WAVES % kPieces == 0, "table pieces per wave");
-    __shared__ MultiLds<NT, GW, WAVES> lds;
+    constexpr int kPW = (kPieces + WAVES - 1) / WAVES;  // table DMAs per wave and step (some pieces twice)
+    __shared__ MultiLds<T, GW, WAVES> lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk = blockIdx.y;
     const uint32_t sb_a = chunk * sb_per_chunk, sb_b = min(n_sb, sb_a + sb_per_chunk);
     const uint64_t g0 = ((uint64_t)blockIdx.x * WAVES + wave) * GW;
     if (sb_a >= sb_b) return;  // (whole workgroup)
-    // columns 32..63 of the is-missing matrix: always with full-width weights, else only if a NaN flag is set
-    const bool m_low = NT == 1 || m_low_always || __builtin_amdgcn_readfirstlane((int)state[0].m_low) != 0;
+    // the flag tiles of the is-missing matrix: only in calls with a NaN imputation value
+    const bool m_flag = __builtin_amdgcn_readfirstlane((int)state[0].m_low) != 0;
 
-    constexpr int NT16 = 2 * NT;  // tiles of 16 columns
-    v4i acc[GW][2][NT16];         // [group][sample half][tile]
+    constexpr int NT16 = T;  // tiles of 16 columns
+    v4i acc[GW][2][NT16];    // [group][sample half][tile]
 #pragma unroll
     for (int a = 0; a < GW; ++a)
 #pragma unroll
@@ -511,12 +526,12 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
 
     // Every wave issues the same DMAs in every step (the counted waits rely on it): addresses past the
     // chunk / past the last group are clamped to valid ones, what they fetch is never used.
-    const int piece0 = (wave * kPW) % kPieces;  // (more waves than pieces: some pieces are fetched twice)
+    const int piece0 = wave * kPW;  // (more slots than pieces: some pieces are fetched twice)
     auto dma_table = [&](uint32_t sb, int buf, int slot) {
         const uint32_t s = min(sb, sb_b - 1);
 #pragma unroll
         for (int i = 0; i < kPW; ++i) {
-            const int e = (piece0 + i) * 64;
+            const int e = ((piece0 + i) % kPieces) * 64;
             glds16(table + (uint64_t)s * kTab + e + lane, lds_addr(&lds.tab[buf][slot][e]));
         }
     };
@@ -587,7 +602,8 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
                                 }
 #pragma unroll
                         for (int t = 0; t < NT16; ++t) {
-                            if (dm == 1 && !(t < 2 || m_low)) break;  // (NT = 1: m_low is always set)
+                            if (dm == 0 ? t >= TD : (t >= TM && t < TF0)) continue;  // (compile-time)
+                            if (dm == 1 && t >= TM && !m_flag) continue;             // (flag tiles: uniform, rare)
                             const uint4 bq = lds.tab[buf][k][((p * NT16 + t) * 2 + dm) * 64 + lane];
                             const v4i B = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
 #pragma unroll
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
 #pragma unroll
     for (int a = 0; a < GW; ++a) {
         if (g0 + a >= n_groups) continue;
-        int32_t *dst = partial + (((uint64_t)chunk * n_groups + g0 + a) * 32) * (NT * 32);
+        int32_t *dst = partial + (((uint64_t)chunk * n_groups + g0 + a) * 32) * (T * 16);
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs)
 #pragma unroll
@@ -619,21 +635,21 @@ __global__ __launch_bounds__(64 * WAVES) void multi_mfma_kernel(const uint4 *__r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int samp = 16 * hs + 4 * (lane >> 4) + r;
-                    dst[(uint64_t)samp * (NT * 32) + 16 * t + (lane & 15)] = acc[a][hs][t][r];
+                    dst[(uint64_t)samp * (T * 16) + 16 * t + (lane & 15)] = acc[a][hs][t][r];
                 }
     }
 }
 
-// per (sample, score): the digit sums of all row chunks -> float64, added to the running sums
+// per sample: the digit sums of all row chunks -> float64 per score, added to the running sums
+template <int S, int ND>
 __global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restrict__ partial, uint32_t n_chunks,
-                                                         uint64_t n_groups, uint64_t n_samples, int S, int NT,
+                                                         uint64_t n_groups, uint64_t n_samples,
                                                          const int *__restrict__ F, double *__restrict__ part,
                                                          int overwrite, MultiState *__restrict__ state) {
-    // a thread folds the scores 2p and 2p + 1 of one sample: their columns are runs of 8 int32 (32-byte sectors)
+    constexpr int T = ((ND + 1) * S + 15) / 16;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const int s0 = 2 * blockIdx.y;
-    if (i < 2 && s0 + (int)i < S) {  // this call's whole-locus constants -> the float64 running constant of the score
-        const int s = s0 + (int)i;
+    if (i < (uint64_t)S) {  // this call's whole-locus constants -> the float64 running constant of the score
+        const int s = (int)i;
         MultiState &st = state[s];
         const double c = ldexp((double)st.const_hi * 4294967296.0 + (double)st.const_lo, -F[s]);
         st.const_sum = (overwrite ? 0.0 : st.const_sum) + (st.const_nan ? __longlong_as_double(0x7ff8000000000000ll) : c);
@@ -643,34 +659,25 @@ __global__ __launch_bounds__(256) void multi_fold_kernel(const int32_t *__restri
     }
     if (i >= n_samples) return;
     const uint64_t g = i >> 5, si = i & 31;
-    long long sum[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};  // [score][digit 0..6, flag]
+    long long sum[16 * T];  // the sample's row of the partial sums: one entry per column
+#pragma unroll
+    for (int c = 0; c < 16 * T; ++c) sum[c] = 0;
     for (uint32_t c = 0; c < n_chunks; ++c) {
-        const int4 *src = reinterpret_cast<const int4 *>(partial + (((uint64_t)c * n_groups + g) * 32 + si) * (NT * 32));
-        if (NT == 1) {  // columns 8 s + d
+        const int4 *src = reinterpret_cast<const int4 *>(partial + (((uint64_t)c * n_groups + g) * 32 + si) * (T * 16));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int4 lo = src[2 * (s0 + j)], hi = src[2 * (s0 + j) + 1];
-                sum[j][0] += lo.x, sum[j][1] += lo.y, sum[j][2] += lo.z, sum[j][3] += lo.w;
-                sum[j][4] += hi.x, sum[j][5] += hi.y, sum[j][6] += hi.z, sum[j][7] += hi.w;
-            }
-        } else {        // multi_col: digits 3..6 at 4 s, digits 0..2 and the flag at 32 + 4 s
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int4 hi = src[s0 + j], lo = src[8 + s0 + j];
-                sum[j][0] += lo.x, sum[j][1] += lo.y, sum[j][2] += lo.z, sum[j][7] += lo.w;
-                sum[j][3] += hi.x, sum[j][4] += hi.y, sum[j][5] += hi.z, sum[j][6] += hi.w;
-            }
+        for (int q = 0; q < 4 * T; ++q) {
+            if (4 * q >= (ND + 1) * S) break;  // (columns behind the flags are zero)
+            const int4 v = src[q];
+            sum[4 * q] += v.x, sum[4 * q + 1] += v.y, sum[4 * q + 2] += v.z, sum[4 * q + 3] += v.w;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int s = s0 + j;
-        if (s >= S) break;
-        double v = (double)sum[j][6];
+    for (int s = 0; s < S; ++s) {
+        double v = 0.0;
 #pragma unroll
-        for (int k = 5; k >= 0; --k) v = v * 256.0 + (double)sum[j][k];
+        for (int d = ND - 1; d >= 0; --d) v = v * 256.0 + (double)sum[multi_col(S, ND, s, d)];
         v = ldexp(v, -F[s] - 7);  // the digits are those of weight x 2^F x 128 (weight_digits)
-        if (sum[j][7] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
+        if (sum[multi_col(S, ND, s, ND)] != 0) v = __longlong_as_double(0x7ff8000000000000ll);
         double *dst = part + (uint64_t)s * n_samples + i;
         *dst = overwrite ? v : *dst + v;
     }
@@ -695,20 +702,24 @@ __global__ __launch_bounds__(256) void multi_finish_kernel(const double *__restr
 
 // ---- host side ------------------------------------------------------------------------------
 hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
-                               uint64_t n_desc, int S, int NT, uint64_t n_samples, DevParams p, const int *d_F,
-                               void *d_table, void *d_state, int coarse_missing) {
+                               uint64_t n_desc, int S, const MultiPlan &pl, uint64_t n_samples, DevParams p,
+                               const int *d_F, void *d_table, void *d_state, int coarse_missing) {
     if (n_desc == 0 || S == 0) return hipSuccess;
     const uint32_t n_sb = (uint32_t)((n_desc + 127) / 128);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)(((uint64_t)n_sb * 8 + 255) / 256), (uint32_t)(4 * NT)),
-                       dim3(256), 0, st, d_tally, d_desc, n_desc, S, NT, n_samples, p, d_F, (uint32_t *)d_table,
+    hipLaunchKernelGGL(multi_params_kernel, dim3((uint32_t)(((uint64_t)n_sb * 8 + 255) / 256), (uint32_t)(S + 1)),
+                       dim3(256), 0, st, d_tally, d_desc, n_desc, S, pl.ND, pl.T, n_samples, p, d_F, (uint32_t *)d_table,
                        (MultiState *)d_state, coarse_missing, n_sb);
     return hipGetLastError();
 }
 
-MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, bool coarse_missing, int cus) {
     MultiPlan pl;
-    pl.NT = (8 * S + 31) / 32;
+    pl.ND = ND;
+    pl.T = ((ND + 1) * S + 15) / 16;
+    pl.TD = (ND * S + 15) / 16;
+    pl.TM = coarse_missing ? (4 * S + 15) / 16 : pl.TD;
+    pl.TF0 = (ND * S) / 16;
     pl.GW = NPS_MULTI_GW;
     pl.n_groups = (n_samples + 31) / 32;
     pl.n_sb = (uint32_t)((n_rows + 127) / 128);
@@ -727,33 +738,72 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int cus) {
     return pl;
 }
 
+template <int T, int TD, int TM, int TF0>
+static void launch_mfma_t(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
+                          const void *d_table, int32_t *d_partial, const void *d_state, const uint32_t *d_sbflag) {
+    constexpr int GW = NPS_MULTI_GW, WAVES = 32 / GW;
+    hipLaunchKernelGGL((multi_mfma_kernel<T, TD, TM, TF0, GW, WAVES>), dim3(pl.tiles, pl.n_chunks), dim3(64 * WAVES), 0,
+                       st, (const uint4 *)d_units, pl.n_groups, sb_first, pl.n_sb, pl.sb_per_chunk,
+                       (const uint4 *)d_table, d_partial, (const MultiState *)d_state, d_sbflag);
+}
+
 hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_units, uint64_t sb_first,
-                             const void *d_table, int32_t *d_partial, const void *d_state, int coarse_missing,
+                             const void *d_table, int32_t *d_partial, const void *d_state,
                              const unsigned long long *d_tally, uint64_t n_rows, uint32_t *d_sbflag) {
     if (pl.n_sb == 0 || pl.n_groups == 0) return hipSuccess;
     (void)hipGetLastError();
     hipLaunchKernelGGL(multi_sbflag_kernel, dim3((pl.n_sb + 3) / 4), dim3(256), 0, st, d_tally, n_rows, pl.n_sb, d_sbflag);
-    constexpr int GW = NPS_MULTI_GW, WAVES = 32 / GW;
-    const dim3 grid(pl.tiles, pl.n_chunks), block(64 * WAVES);
-    if (pl.NT == 1)
-        hipLaunchKernelGGL((multi_mfma_kernel<1, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
-                           sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
-                           (const MultiState *)d_state, coarse_missing ? 0 : 1, d_sbflag);
-    else if (pl.NT == 2)
-        hipLaunchKernelGGL((multi_mfma_kernel<2, GW, WAVES>), grid, block, 0, st, (const uint4 *)d_units, pl.n_groups,
-                           sb_first, pl.n_sb, pl.sb_per_chunk, (const uint4 *)d_table, d_partial,
-                           (const MultiState *)d_state, coarse_missing ? 0 : 1, d_sbflag);
-    else
-        return hipErrorInvalidValue;
+#define NPS_MFMA_CASE(T_, TD_, TM_, TF0_)                                                                   \
+    case T_ * 1000 + TD_ * 100 + TM_ * 10 + TF0_:                                                           \
+        launch_mfma_t<T_, TD_, TM_, TF0_>(st, pl, d_units, sb_first, d_table, d_partial, d_state, d_sbflag); \
+        break;
+    // every (score count 1..8, 6 or 7 digits, full or 32-bit is-missing weights) of multi_plan
+    switch (pl.T * 1000 + pl.TD * 100 + pl.TM * 10 + pl.TF0) {
+        NPS_MFMA_CASE(1, 1, 1, 0)
+        NPS_MFMA_CASE(2, 2, 2, 1)
+        NPS_MFMA_CASE(2, 2, 1, 1)
+        NPS_MFMA_CASE(3, 3, 3, 2)
+        NPS_MFMA_CASE(3, 3, 2, 2)
+        NPS_MFMA_CASE(3, 2, 2, 1)
+        NPS_MFMA_CASE(4, 4, 4, 3)
+        NPS_MFMA_CASE(4, 4, 2, 3)
+        NPS_MFMA_CASE(4, 3, 3, 2)
+        NPS_MFMA_CASE(4, 3, 2, 2)
+        NPS_MFMA_CASE(4, 3, 3, 3)
+        NPS_MFMA_CASE(4, 3, 2, 3)
+    default: return hipErrorInvalidValue;
+    }
+#undef NPS_MFMA_CASE
     return hipGetLastError();
+}
+
+template <int S>
+static void launch_fold_s(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples,
+                          const int *d_F, double *d_part, int overwrite, void *d_state) {
+    const dim3 grid((uint32_t)std::max<uint64_t>(1, (n_samples + 255) / 256));
+    if (pl.ND == 6)
+        hipLaunchKernelGGL((multi_fold_kernel<S, 6>), grid, dim3(256), 0, st, d_partial, pl.n_chunks, pl.n_groups,
+                           n_samples, d_F, d_part, overwrite, (MultiState *)d_state);
+    else
+        hipLaunchKernelGGL((multi_fold_kernel<S, 7>), grid, dim3(256), 0, st, d_partial, pl.n_chunks, pl.n_groups,
+                           n_samples, d_F, d_part, overwrite, (MultiState *)d_state);
 }
 
 hipError_t launch_multi_fold(hipStream_t st, const MultiPlan &pl, const int32_t *d_partial, uint64_t n_samples, int S,
                              const int *d_F, double *d_part, int overwrite, void *d_state) {
+    if (pl.ND != 6 && pl.ND != 7) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_fold_kernel, dim3((uint32_t)std::max<uint64_t>(1, (n_samples + 255) / 256), (uint32_t)((S + 1) / 2)),
-                       dim3(256), 0, st, d_partial, pl.n_chunks, pl.n_groups, n_samples, S, pl.NT, d_F, d_part, overwrite,
-                       (MultiState *)d_state);
+    switch (S) {
+    case 1: launch_fold_s<1>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 2: launch_fold_s<2>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 3: launch_fold_s<3>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 4: launch_fold_s<4>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 5: launch_fold_s<5>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 6: launch_fold_s<6>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 7: launch_fold_s<7>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    case 8: launch_fold_s<8>(st, pl, d_partial, n_samples, d_F, d_part, overwrite, d_state); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

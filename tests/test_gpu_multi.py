@@ -72,17 +72,17 @@ def oracle_scores(codes, n, descs, params_kw, offsets):
     return np.stack(out), np.array(nl)
 
 
+@pytest.mark.parametrize("wbits", [0, 41])
 @pytest.mark.parametrize("bits", [56, 32])
 @pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
-@pytest.mark.parametrize("shape", [(1, 1, 1), (6, 7, 3), (33, 129, 4), (257, 300, 5), (1000, 1025, 8), (4099, 64, 8)])
-def test_multi_vs_oracle_converted_cohort(shape, pk, bits):
+@pytest.mark.parametrize("shape", [(1, 1, 1), (17, 33, 2), (6, 7, 3), (33, 129, 4), (257, 300, 5), (65, 130, 6),
+                                   (40, 260, 7), (1000, 1025, 8), (4099, 64, 8)])
+def test_multi_vs_oracle_converted_cohort(shape, pk, bits, wbits):
     """a 2-bit cohort uploaded row-major, repacked on the device (nps_cohort_convert), S definitions with
     their own beta / eaf / effect allele, rows a score does not list, absent / uncovered / FILTER rows; with
-    full-width and with 32-bit weights for the imputed value of a missing genotype (the second changes the pass
-    only for more than 4 scores; the NaN cases of PARAM_GRID 3 and 4 must stay exact in both)"""
+    full-width and with 32-bit weights for the imputed value of a missing genotype (the NaN cases of PARAM_GRID 3
+    and 4 must stay exact in both), with six and with seven digits per weight"""
     n, m, S = shape
-    if bits == 32 and S <= 4:
-        pytest.skip("one column tile: the option changes nothing")
     kw = PARAM_GRID[pk]
     eaf_c, th, tm, tmi, descs = make_case(n, m, S, 1000 * pk + n + m)
     codes = refcpu.synth_rows(n, 0, m, 31, th, tm, tmi)
@@ -98,22 +98,28 @@ def test_multi_vs_oracle_converted_cohort(shape, pk, bits):
     offsets = np.linspace(-0.5, 0.5, S)
     msc = capi.MultiScorer(n, capi.make_params(**kw), S)
     msc.set_missing_weight_bits(bits)
-    mdef = capi.MultiDef(descs)
+    mdef = capi.MultiDef(descs, weight_bits=wbits)   # (49-bit weights, 41 on request: every score count 1..8 has its own
+    # number of column tiles in both)
     msc.score_cohort(co, mdef)
     got, nloci = msc.finish(offsets)
     ref, ref_nloci = oracle_scores(codes, n, descs, kw, offsets)
     assert np.array_equal(nloci.astype(np.int64), ref_nloci)
     for s in range(S):
         keep = descs[s]["kind"] != capi.ROW_NOT_IN_SCORE
-        if bits == 32:
-            # the documented bound (include/nps.h): (missing genotypes of the sample) x 2^-24 x B, after the
-            # division by 2 nloci
+        if bits == 32 or wbits == 41:
+            # the documented bounds (include/nps.h), after the division by 2 nloci: 32-bit is-missing weights:
+            # (missing genotypes of the sample) x 2^-24 x B; 41-bit weights: every term within 3 x 2^-41 of the
+            # largest weight the fixed point holds (< 2 B)
             d = descs[s][keep]
             B = float(np.max(np.abs(d["beta"])) * (3.0 + max(2.0, 2.0 * float(np.max(np.abs(np.nan_to_num(d["eaf"])))))))
-            # (NPS_CODE_MISSING = 2; 16 codes per word)
-            plain = ((np.asarray(codes)[keep][:, :, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(keep.sum(), -1)
-            n_missing = (plain[:, :n] == 2).sum(axis=0)
-            bound = (n_missing * 2.0 ** -24 * B / max(2.0 * int(ref_nloci[s]), 1))
+            bound = np.zeros(n)
+            if bits == 32:
+                # (NPS_CODE_MISSING = 2; 16 codes per word)
+                plain = ((np.asarray(codes)[keep][:, :, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(keep.sum(), -1)
+                bound += (plain[:, :n] == 2).sum(axis=0) * 2.0 ** -24 * B
+            if wbits == 41:
+                bound += keep.sum() * 6.0 * 2.0 ** -40 * B
+            bound /= max(2.0 * int(ref_nloci[s]), 1)
             ok = ~np.isnan(ref[s])
             assert np.array_equal(np.isnan(got[s]), np.isnan(ref[s]))
             assert np.all(np.abs(got[s][ok] - ref[s][ok]) <= bound[ok] + REL_TOL * np.abs(ref[s][ok])), s

@@ -12,6 +12,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--zero", action="store_true", help="all genotypes 0 (clock / power experiment)")
 ap.add_argument("--no-missing", action="store_true", help="a cohort without missing genotypes")
 ap.add_argument("--missing-bits", type=int, default=0, help="nps_multi_set_missing_weight_bits (32 or 56)")
+ap.add_argument("--weight-bits", type=int, default=0, help="nps_multidef_create_bits (49 or 41)")
 a = ap.parse_args()
 import torch
 from nimpress_amd import capi
@@ -33,7 +34,7 @@ descs = np.zeros((S, m), dtype=capi.ROW_DESC_DTYPE)
 for s in range(S):
     descs[s]["beta"] = np.round(np.random.default_rng(seed + 1000 + s).normal(0.0, 0.02, m), 4)
     descs[s]["eaf"] = eaf
-mdef = capi.MultiDef(descs)
+mdef = capi.MultiDef(descs, weight_bits=a.weight_bits)
 msc = capi.MultiScorer(n, capi.make_params(), S)
 if a.missing_bits:
     msc.set_missing_weight_bits(a.missing_bits)
