@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--no-multi-legs", action="store_true",
                     help="N > 1: skip the two strong-scaling legs that follow the headline (one GT score with its rows "
                          "sharded over the GPUs = configs[2] at N GPUs; the FORMAT/DS score of configs[4] likewise)")
+    ap.add_argument("--multi-legs-timeout", type=float, default=420.0,
+                    help="N > 1: seconds after which the headline line is printed WITHOUT the strong-scaling legs and the "
+                         "run ends with status 3 (a hung collective must not cost the measurement)")
     ap.add_argument("--ds-samples", type=int, default=200_000, help="cohort size of the N > 1 FORMAT/DS leg (configs[4])")
     ap.add_argument("--ds-variants", type=int, default=2_000_000, help="score rows of the N > 1 FORMAT/DS leg (configs[4])")
     ap.add_argument("--ds-chunk-rows", type=int, default=300_000,
@@ -544,6 +547,27 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     full, nloci = measure(56)
     fast, _ = measure(32)
     w41, _ = measure(56, 41)
+    # ONE definition through the same pass (one tile of 16 columns): what a single score costs on a cohort that
+    # carries its whole-row tallies (the headline kernel counts them while it reads -- not the same work)
+    msc1 = capi.MultiScorer(n, capi.make_params(), 1, device=device)
+    mdef1 = capi.MultiDef(descs[:1], device=device)
+    d1 = torch.empty((1, n), dtype=torch.float64, device="cuda")
+    one_ms = []
+    for i in range(steps + 1):
+        msc1.reset()
+        msc1.score_cohort(co, mdef1)
+        msc1.finish_device(np.zeros(1), d1.data_ptr())
+        torch.cuda.synchronize()
+        if i:
+            one_ms.append(sum(msc1.timing()))
+    one = {"what": "ONE score definition through the multi-score pass on the same cohort (tallies from the packer, "
+                   "one tile of 16 digit columns): kernel time per pass",
+           "ms_per_pass": float(np.mean(one_ms)),
+           "hbm_GBps": (m * ((n + 15) // 16) * 4) / (float(np.mean(one_ms)) * 1e-3) / 1e9}
+    one["hbm_frac"] = one["hbm_GBps"] / HBM_PEAK_GBS
+    msc1.close()
+    mdef1.close()
+    del d1
     # the same cohort without its missing genotypes (imputed hard calls have none): superblocks whose rows have no
     # missing sample skip the is-missing matrix (timing only; the parity of that path is tests/test_gpu_multi.py's)
     checker, zeros = None, np.zeros_like(tmi)
@@ -579,7 +603,8 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
                                        "whose terms cancel is not within 1e-6 of its own score (include/nps.h)",
                                   cohort_without_missing_genotypes_ms_per_pass=nomiss41["ms_per_pass"]),
            "cohort_without_missing_genotypes": {k: nomiss[k] for k in ("ms_per_pass", "ms_per_score", "value",
-                                                                       "kernel_ms")}}
+                                                                       "kernel_ms")},
+           "one_score_given_tallies": one}
     if "score_delta_vs_reference" in full:
         out["score_delta_vs_reference"] = full["score_delta_vs_reference"]
         out["missing_weight_bits_32"]["score_delta_vs_reference"] = fast["score_delta_vs_reference"]
@@ -929,22 +954,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # N > 1: the two strong-scaling curves of the north star, by all ranks, in this order on every rank
-    multi_legs = None
-    if world > 1 and not args.no_multi_legs and not strong and not is_ds and resident:
-        multi_legs = {"configs2_gt_rows_sharded": strong_scaling_leg(
-            torch, dist, multi, capi, args, rank, world, local_rank, fmt, n, m, args.seed, 0, max(1, min(args.steps, 5)),
-            cohort=cohort)}
-        sc.close()
-        for sd in sdefs:
-            sd.close()
-        cohort.close()      # the DS chunk needs the room
-        torch.cuda.empty_cache()
-        multi_legs["configs4_ds_rows_sharded"] = strong_scaling_leg(
-            torch, dist, multi, capi, args, rank, world, local_rank, capi.FMT_DS32, args.ds_samples, args.ds_variants,
-            20250105, args.ds_chunk_rows, 1)
-
     failed = []   # secondary measurements that raised (rank 0): the line is printed, the exit status is 1
+    out = None
     if rank == 0:
         steps = max(args.steps, 1)
         genotypes_per_step = float(n) * float(m)
@@ -1011,6 +1022,38 @@ def main():
                                                "accumulate": prof.n_accumulate / steps,
                                                "fused": prof.n_fused / steps}},
         }
+    # N > 1: the two strong-scaling curves of the north star, by all ranks, in this order on every rank.  The headline
+    # line exists already: if a leg hangs (a collective some rank never reaches), a watchdog prints the line without the
+    # legs and ends the process instead of losing the measurement to the caller's timeout.
+    multi_legs = None
+    if world > 1 and not args.no_multi_legs and not strong and not is_ds and resident:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["multi_gpu"] = {"error": "the strong-scaling legs did not finish within %.0f s" % args.multi_legs_timeout}
+                print(json.dumps(out), flush=True)
+            else:
+                time.sleep(5.0)
+            os._exit(3)
+
+        watchdog = threading.Timer(args.multi_legs_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        multi_legs = {"configs2_gt_rows_sharded": strong_scaling_leg(
+            torch, dist, multi, capi, args, rank, world, local_rank, fmt, n, m, args.seed, 0, max(1, min(args.steps, 5)),
+            cohort=cohort)}
+        sc.close()
+        for sd in sdefs:
+            sd.close()
+        cohort.close()      # the DS chunk needs the room
+        torch.cuda.empty_cache()
+        multi_legs["configs4_ds_rows_sharded"] = strong_scaling_leg(
+            torch, dist, multi, capi, args, rank, world, local_rank, capi.FMT_DS32, args.ds_samples, args.ds_variants,
+            20250105, args.ds_chunk_rows, 1)
+        watchdog.cancel()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if not is_ds:
                 out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)

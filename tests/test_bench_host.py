@@ -32,7 +32,7 @@ def test_bench_spawns_its_ranks_without_a_launcher():
     assert "must be launched" not in r.stderr
 
 
-def _rehearse(world, extra):
+def _rehearse(world, extra, expect_rc=0):
     """N ranks of tests/rehearse_bench.py (a fake libnps, CPU tensors, gloo): bench.main() of every rank, unchanged"""
     import json
     import socket
@@ -49,8 +49,9 @@ def _rehearse(world, extra):
                                        "1000", "--ds-chunk-rows", "256"] + extra,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=300) for p in procs]
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, se[-3000:]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        # (after rank 0 has given up, the others end with the watchdog's status or with a broken collective)
+        assert p.returncode == expect_rc or (expect_rc and r and p.returncode), se[-3000:]
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not any(ln.startswith("{") for so, _ in outs[1:] for ln in so.splitlines())
     return json.loads(lines[0])
@@ -80,3 +81,11 @@ def test_bench_three_ranks_strong_scaling_rehearsal():
     # every rank contributed partial sums of 1.0: 3.0 / (2 x 640) after the all-reduce and the normalisation
     assert abs(d["rehearsal_normalised"][0] - 3.0 / 1280.0) < 1e-15 and d["rehearsal_normalised"][1] == 640
     assert d["config"]["parallelism"].startswith("one score, rows sharded x3")
+
+
+def test_bench_legs_watchdog_keeps_the_headline_line():
+    """N > 1: if the strong-scaling legs do not finish in time (a collective some rank never reaches), rank 0 still
+    prints the headline line -- without the legs -- and ends with status 3 (the other ranks: non-zero)"""
+    d = _rehearse(2, ["--multi-legs-timeout", "0"], expect_rc=3)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "did not finish" in d["multi_gpu"]["error"]
