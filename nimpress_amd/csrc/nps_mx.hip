@@ -46,16 +46,19 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 // Data waves 0..5 carry 9 units each, the control waves 6, 7 five units each plus the per-row work of 64 rows each.
 // Two schedules of the control chain, chosen per launch (template parameter EARLY: a run-time flag with both paths in
 // one kernel cost 20 % -- the compiler drains the memory queue where the paths join):
-//   late:  the tables of superblock k are made at the start of step k (poll, operands), in front of the step's barrier.
+//   late:  the tables of superblock k are made in step k, in front of the step's barrier: the look at the rows' tally
+//          words is issued at the start of the step and travels while the control wave tallies and parks its own
+//          units; the operands follow when it is back.  (Until the end of round 4 the look was issued, waited for and
+//          turned into operands BEFORE the wave's own tallying: 24.3 -> 22.5-23.2 ms at 245 strips, and the "mid"
+//          schedule -- the look a third of a step earlier -- that served 97..160 strips lost to it everywhere.)
 //   early: the tables of superblock k + 1 are made during the second half of step k: the look at its tally words is
 //          issued with the returning add of the publication of k + 2, the control wave accumulates its own units
 //          meanwhile, and the operands follow (three table buffers).  Nothing of the control chain is left in front of
 //          the barrier -- unless a word was not complete at that look, one step after its publication.  With few strips
-//          per team the two-stage publication is over by then (49 strips: 62.8 -> 68.2 % of 8 TB/s); with 245 strips
-//          it mostly is not, and a look at an incomplete word queues at the memory side in front of the adds it waits
-//          for (24.1 -> 27.5 ms), so the plan takes the early schedule up to 96 strips only (123 strips: equal).
-//   mid:   the late schedule with its first look issued a third of a step earlier, right after the control wave's own
-//          accumulation of the step before (123 strips: +3 %; 245 strips: 24.2 -> 26.4 ms): 97 to 160 strips.
+//          per team the two-stage publication is over by then; with 245 strips it mostly is not, and a look at an
+//          incomplete word queues at the memory side in front of the adds it waits for.  Measured with the present late
+//          schedule (ms per 1M-row pass, late / early): 49 strips 4.66 / 4.59; 98 strips 10.21 / 10.38; 123 strips
+//          11.19 / 11.69; 196 strips 21.17 / 22.11; 245 strips 23.4 / 27.6 -- the plan takes early up to 64 strips.
 //          (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
 //          first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are
 //          the same instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
@@ -95,6 +98,12 @@ struct MxArgs {
     unsigned int *timeout;
 };
 
+#ifdef NPS_MX_TIMERS
+__device__ unsigned long long g_mx_timers[8][16];  // [wave][phase]: cycles summed over the steps of one workgroup
+#define MXT(i) do { if (timing) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define MXT(i) do { } while (0)
+#endif
 static __device__ __forceinline__ v2i tr4(const char *p) {
     return __builtin_amdgcn_ds_read_tr4_b64_v2i32((NPS_LDS v2i *)p);
 }
@@ -255,8 +264,7 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
 template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int SCHED>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
-    constexpr bool kEarly = SCHED == 1;  // 0 late, 1 early, 2 mid (the look at k+1 issued after the control wave's own
-    constexpr bool kMid = SCHED == 2;    // accumulation in step k and consumed at the start of step k+1)
+    constexpr bool kEarly = SCHED == 1;  // 0 late, 1 early
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
     const uint32_t strip = blockIdx.x % a.P, team = blockIdx.x / a.P;
@@ -439,16 +447,14 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     // wait (bounded) until every row of superblock k is complete, then build its tables.  v1: the tally words were
     // published by every strip more than a step ago: normally one poll.  v2: only reached when the look in the
     // previous step's second half found a word incomplete.
-    unsigned long long x_first = 0ull;  // (mid schedule) the look issued in the previous step
-    bool have_first = false;
-    auto ctl_tables = [&](uint32_t k) {
+    auto ctl_tables = [&](uint32_t k, bool have_x = false, unsigned long long x_in = 0ull) {
         if (k >= n_t) return;
         const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
         bool valid;
         unsigned long long x;
-        if (kMid && have_first) {
+        if (have_x) {
             valid = row < a.n_rows;
-            x = valid ? x_first : 0ull;
+            x = valid ? x_in : 0ull;
         } else {
             x = ctl_word(k, valid);
         }
@@ -536,18 +542,50 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 
     // ---- steps
+    unsigned long long x_look = 0ull;  // (late schedule) the look in flight
     bool next_done = false;  // (early schedule, wave-uniform) the tables of the NEXT step's superblock are already in LDS
+#ifdef NPS_MX_TIMERS
+    const bool timing = strip == a.P / 2 && team == 0;
+    unsigned long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     auto step = [&](uint32_t k, const v4u(&b_tal)[NU], v4u(&b_park)[NU], char *s_park, const char *s_acc) {
-        if (is_ctl && !(kEarly && next_done)) {
+        MXT(8);
+        // late schedule: the look at the row's word travels while the control wave does its own tallying and parking
+        // (its result is waited for by hand: the compiler does not know the load, so its own counted waits only become
+        // stricter).  Before round 4's last change the look was issued, waited for and turned into tables BEFORE front():
+        // 24.3 -> 22.5-23.2 ms at 245 strips.
+        constexpr bool kUnder = !kEarly && !GIVEN;
+        if (is_ctl && kUnder) {
+            const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
+            x_look = 0ull;
+            if (k < n_t && row < a.n_rows)  // (an agent-scope relaxed load, as ctl_word's)
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(x_look) : "v"(&a.tally[row]) : "memory");
+        }
+        if (is_ctl && !kUnder && !(kEarly && next_done)) {
             ctl_tables(k);
             if (kEarly) ctl_fetch_pre(k + 1);  // (normally fetched a step ahead, below)
         }
+        MXT(0);
         front(k, b_tal, b_park, s_park);
+        MXT(1);
+        if (is_ctl && kUnder) {
+            // the wave's loads return in order: once at most the NU loads front() issued after the look are
+            // outstanding, the look has returned (whatever else -- an add of the last step -- is still under way)
+            if (k + 3 < n_t && n_my == NU)
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x_look) : "n"(NU) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_look) : : "memory");
+            MXT(6);
+            ctl_tables(k, true, x_look);
+        }
+        MXT(7);
         __syncthreads();
+        MXT(2);
         if (is_ctl && !kEarly) {  // the returning add and the loads are in flight during the wave's own accumulation
             ctl_publish_begin(k + 2);
             ctl_fetch_pre(k + 1);
         }
+        MXT(3);
         if (is_ctl && kEarly) {
             // publication of k+2 and a look at k+1 (published by every strip a step ago) in ONE round trip, spent on the
             // wave's own accumulation; where the look finds every row complete, the tables of k+1 are made here, a step
@@ -566,12 +604,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         } else {
             accumulate(k, s_acc);
         }
-        if (is_ctl && kMid) {
-            bool v;
-            x_first = ctl_word(k + 1, v);
-            have_first = true;
-        }
+        MXT(4);
         if (is_ctl && !kEarly) ctl_publish_end(k + 2);
+        MXT(5);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
     };
     const uint32_t n_steps = (n_t + 1) / 2 * 2;
@@ -580,6 +615,10 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         step(k + 1, bank[1], bank[0], slot0, slot1);
     }
     store_c((n_t - 1) / kFlushSb, false);
+#ifdef NPS_MX_TIMERS
+    if (timing && lane == 0)
+        for (int i = 0; i < 16; ++i) g_mx_timers[wave][i] = tph[i];
+#endif
     if (is_ctl && strip == 0) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
@@ -908,15 +947,10 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
     }
-    // the control chain's schedule by the number of strips that hand over to each other (measured, ms per 1M-row pass,
-    // late / mid / early: 49 strips 4.98 / - / 4.46; 123 strips 12.38 / 11.98 / 12.05; 245 strips 24.2 / 26.4 / 27.5)
-    const int sched = plan.P <= 96 ? 1 : plan.P <= 160 ? 2 : 0;
-    const void *fn = plan.given ? (sched == 1   ? (const void *)fused_mx_kernel<0, true, 1>
-                                   : sched == 2 ? (const void *)fused_mx_kernel<0, true, 2>
-                                                : (const void *)fused_mx_kernel<0, true, 0>)
-                                : (sched == 1   ? (const void *)fused_mx_kernel<0, false, 1>
-                                   : sched == 2 ? (const void *)fused_mx_kernel<0, false, 2>
-                                                : (const void *)fused_mx_kernel<0, false, 0>);
+    // the control chain's schedule by the number of strips that hand over to each other (table at the top of the file)
+    const int sched = plan.P <= 64 ? 1 : 0;
+    const void *fn = plan.given ? (sched == 1 ? (const void *)fused_mx_kernel<0, true, 1> : (const void *)fused_mx_kernel<0, true, 0>)
+                                : (sched == 1 ? (const void *)fused_mx_kernel<0, false, 1> : (const void *)fused_mx_kernel<0, false, 0>);
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
@@ -966,13 +1000,30 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
         if (sched == 1)
             hipLaunchKernelGGL((fused_mx_kernel<0, true, 1>), grid, dim3(512), kLdsBytes, st, a);
-        else if (sched == 2)
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, 2>), grid, dim3(512), kLdsBytes, st, a);
         else
             hipLaunchKernelGGL((fused_mx_kernel<0, true, 0>), grid, dim3(512), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};
+#ifdef NPS_MX_TIMERS
+    {
+        hipError_t e = hipLaunchCooperativeKernel(fn, grid, dim3(512), args, kLdsBytes, st);
+        if (e != hipSuccess) return e;
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[8][16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mx_timers), sizeof(h));
+        // phases of a step, in order (control waves: 0 = look issue, early/mid table work; 6 = what is left of the look's
+        // round trip after front(); 7 = tables)
+        static const char *nm[16] = {"look-issue", "front", "barrier", "publish-begin", "accumulate", "publish-end", "look-wait",
+                                     "tables", "loop/flush", "-", "-", "-", "-", "-", "-", "-"};
+        for (int w : {0, 3, 6, 7}) {
+            fprintf(stderr, "mx timers wave %d (cycles per step):", w);
+            for (int i = 0; i < 9; ++i) fprintf(stderr, "  %s %.0f", nm[i], (double)h[w][i] / plan.n_sb);
+            fprintf(stderr, "\n");
+        }
+        return hipSuccess;
+    }
+#endif
     return hipLaunchCooperativeKernel(fn, grid, dim3(512), args, kLdsBytes, st);
 }
 
