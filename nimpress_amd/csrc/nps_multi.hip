@@ -131,31 +131,37 @@ __global__ __launch_bounds__(256) void synth_tally_kernel(unsigned long long *__
 }
 
 // rows [0, n_rows) of a 2-bit row-major cohort (group-interleaved device layout of nps_kernels.h) ->
-// units of superblocks [0, ceil(n_rows/128)).  A one-time repack.  Workgroup = one superblock x 8 word columns
-// (128 samples = 4 groups): the 128 x 8 word tile comes in as 32 row groups x 128 contiguous bytes, goes through
-// LDS, and every thread assembles one output lane (32 rows of two samples) from it.
+// units of superblocks [0, ceil(n_rows/128)).  A one-time repack.  Workgroup = one superblock x 32 word columns
+// (512 samples = 16 groups): the 128 x 32 word tile comes in as 32 row groups x 512 contiguous bytes and goes
+// through LDS; every thread takes the 16 rows x 16 samples of one word column and one block of 16 rows, turns the
+// 16 words into plain 2-bit order and TRANSPOSES them in registers (four butterfly stages on 2-bit elements: 24
+// vector ops per word; gathering the codes one by one took 112), and the 16 words it ends up with -- 16 rows of one
+// sample each -- go back through LDS in unit order, so that the units leave as whole 16-byte lanes.
 __global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint4 *__restrict__ src /* first row group */,
                                                            uint64_t src_stride_words, uint64_t n_row_groups,
                                                            uint64_t n_words, uint4 *__restrict__ units,
                                                            uint64_t n_groups,
                                                            unsigned long long *__restrict__ tally /* zeroed */) {
-    __shared__ uint32_t tile[128][9];  // [row][word column], padded
+    __shared__ uint32_t tile[128][33];       // [row][word column], padded
+    __shared__ uint32_t outw[16][64 * 4 + 4];  // [group of the tile][lane x word], padded
     const int t = threadIdx.x;
-    const uint64_t sb = blockIdx.y, c0 = (uint64_t)blockIdx.x * 8;
-    {
-        const uint64_t rg = sb * 32 + (t >> 3), c = c0 + (t & 7);
+    const uint64_t sb = blockIdx.y, c0 = (uint64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = t + 256 * i;  // (row group 0..31, column 0..31)
+        const uint64_t rg = sb * 32 + (e >> 5), c = c0 + (e & 31);
         uint4 q = make_uint4(0, 0, 0, 0);
         if (rg < n_row_groups && c < n_words) q = src[rg * src_stride_words + c];
-        const int r = 4 * (t >> 3);
-        tile[r][t & 7] = q.x, tile[r + 1][t & 7] = q.y, tile[r + 2][t & 7] = q.z, tile[r + 3][t & 7] = q.w;
+        const int r = 4 * (e >> 5);
+        tile[r][e & 31] = q.x, tile[r + 1][e & 31] = q.y, tile[r + 2][e & 31] = q.z, tile[r + 3][e & 31] = q.w;
     }
     __syncthreads();
     {   // whole-row tallies (tallyAlleles, nimpress.nim:32-47) while the tile is here: two threads per row
         const int r = t >> 1;
         uint32_t cw = 0, cm = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t w = tile[r][4 * (t & 1) + c];
+        for (int c = 0; c < 16; ++c) {
+            const uint32_t w = tile[r][16 * (t & 1) + c];
             cw += __popc(w);
             cm += __popc((w >> 4) & ~w & 0x0F0F0F0Fu);  // (nps_kernels.hip tally_word)
         }
@@ -164,24 +170,40 @@ __global__ __launch_bounds__(256) void convert_gt2m_kernel(const uint4 *__restri
         if ((t & 1) == 0 && (cw | cm))
             atomicAdd(&tally[sb * 128 + r], ((unsigned long long)cm << 32) | (unsigned long long)(cw - cm));
     }
-    const uint64_t g = (uint64_t)blockIdx.x * 4 + (t >> 6);
-    if (g >= n_groups) return;
-    const int lane = t & 63, rq = lane >> 4;
-    uint32_t out[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const int sl = 32 * (t >> 6) + 16 * (w >> 1) + (lane & 15);  // sample of the tile
-        const int cc = sl >> 4, pb = plane_bit(sl & 15);
-        uint32_t word = 0;
+    {
+        const int cc = t & 31, rb = t >> 5;  // word column (16 samples), block of 16 rows
+        uint32_t a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t x = tile[32 * rq + 16 * (w & 1) + j][cc] >> pb;  // low code bit in bit 0, high in bit 4
-            const uint32_t c = (x & 1u) | ((x >> 3) & 2u);
-            word |= m_code(c) << (2 * j);
+            uint32_t x = word_from_planes(tile[16 * rb + j][cc]);  // sample s in bits 2s, 2s+1 (NPS_CODE_*)
+            a[j] = x ^ ((x >> 1) & 0x55555555u);                   // -> layout codes (m_code on all 16 fields)
         }
-        out[w] = word;
+        // a[j] = row j, element s = sample s  ->  a[s] = sample s, element j = row j
+#define NPS_T2(d, mask)                                               \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) if (!(j & d)) {    \
+        const uint32_t u = ((a[j] >> (2 * d)) ^ a[j + d]) & mask;     \
+        a[j + d] ^= u;                                                \
+        a[j] ^= u << (2 * d);                                         \
     }
-    units[(sb * n_groups + g) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
+        NPS_T2(8, 0x0000FFFFu)
+        NPS_T2(4, 0x00FF00FFu)
+        NPS_T2(2, 0x0F0F0F0Fu)
+        NPS_T2(1, 0x33333333u)
+#undef NPS_T2
+        // unit layout: lane = 16 (row quarter) + (sample & 15), word = 2 (sample half) + (row block & 1)
+        uint32_t *o = &outw[cc >> 1][((rb >> 1) * 16) * 4 + 2 * (cc & 1) + (rb & 1)];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) o[s2 * 4] = a[s2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = t + 256 * i;  // (group 0..15, lane 0..63)
+        const uint64_t g = (uint64_t)blockIdx.x * 16 + (e >> 6);
+        if (g >= n_groups) continue;
+        const uint32_t *o = &outw[e >> 6][(e & 63) * 4];
+        units[(sb * n_groups + g) * 64 + (e & 63)] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 hipError_t launch_synth_gt2m(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t row0, uint64_t gen_row0,
@@ -221,7 +243,7 @@ hipError_t launch_convert_gt2m(hipStream_t st, const uint32_t *d_src, uint64_t s
     (void)hipGetLastError();
     for (uint64_t sb = 0; sb < n_sb; sb += 65535) {
         const uint64_t k = std::min<uint64_t>(65535, n_sb - sb);
-        hipLaunchKernelGGL(convert_gt2m_kernel, dim3((uint32_t)((n_words + 7) / 8), (uint32_t)k), dim3(256), 0, st,
+        hipLaunchKernelGGL(convert_gt2m_kernel, dim3((uint32_t)((n_words + 31) / 32), (uint32_t)k), dim3(256), 0, st,
                            reinterpret_cast<const uint4 *>(d_src) + sb * 32 * src_stride_words, src_stride_words,
                            n_row_groups - sb * 32, n_words, (uint4 *)d_units + sb * n_groups * 64, n_groups,
                            d_tally + sb * 128);

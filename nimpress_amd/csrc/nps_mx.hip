@@ -806,25 +806,36 @@ __global__ __launch_bounds__(256) void gt2x_to_rows_kernel(const unsigned long l
     if (unit * 2 + 1 < n_words) p[1] = (uint32_t)(x >> 32);
 }
 
-// a NPS_FMT_GT2 cohort (group-interleaved, plane-separated words, plain layout) -> units
-__global__ __launch_bounds__(256) void gt2_to_gt2x_kernel(const uint32_t *__restrict__ src, uint64_t stride_words,
-                                                          uint64_t n_words, uint64_t n_rows,
+// a NPS_FMT_GT2 cohort (group-interleaved, plane-separated words, plain layout) -> units.  Workgroup = one superblock
+// x 32 word columns (16 units): the 128 x 32 word tile comes in as 32 row groups x 512 contiguous bytes (a thread that
+// fetches its own two words reads 32-byte pieces: 3.7 TB/s read + written), goes through LDS, and every unit leaves as
+// 1 KiB of consecutive rows.
+__global__ __launch_bounds__(256) void gt2_to_gt2x_kernel(const uint4 *__restrict__ src, uint64_t stride_words,
+                                                          uint64_t n_words, uint64_t n_row_groups,
                                                           unsigned long long *__restrict__ units, uint64_t n_units,
                                                           uint64_t n_sb, uint64_t sb_off) {
-    const uint64_t unit = (uint64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
-    const uint32_t rho = threadIdx.x & 127;
-    const uint64_t sb = sb_off + blockIdx.y;
-    if (unit >= n_units) return;
-    const uint64_t r = sb * 128 + rho;
-    unsigned long long out = 0;
-    if (r < n_rows) {
-        const unsigned long long lo = unit * 2 < n_words ? word_from_planes(src[g4_word_index(r, unit * 2, stride_words)]) : 0u;
-        const unsigned long long hi =
-            unit * 2 + 1 < n_words ? word_from_planes(src[g4_word_index(r, unit * 2 + 1, stride_words)]) : 0u;
-        const unsigned long long x = lo | (hi << 32);
-        out = x ^ ((x >> 1) & 0x5555555555555555ull);
+    __shared__ uint32_t tile[128][33];  // [row][word column], padded
+    const int t = threadIdx.x;
+    const uint64_t sb = sb_off + blockIdx.y, c0 = (uint64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = t + 256 * i;  // (row group 0..31, column 0..31)
+        const uint64_t rg = sb * 32 + (e >> 5), c = c0 + (e & 31);
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (rg < n_row_groups && c < n_words) q = src[rg * stride_words + c];
+        const int r = 4 * (e >> 5);
+        tile[r][e & 31] = q.x, tile[r + 1][e & 31] = q.y, tile[r + 2][e & 31] = q.z, tile[r + 3][e & 31] = q.w;
     }
-    units[gt2x_unit_index(unit, sb, n_units, n_sb) * 128 + rho] = out;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i, u = e >> 7, rho = e & 127;
+        const uint64_t unit = (uint64_t)blockIdx.x * 16 + u;
+        if (unit >= n_units) continue;
+        const unsigned long long lo = word_from_planes(tile[rho][2 * u]), hi = word_from_planes(tile[rho][2 * u + 1]);
+        const unsigned long long x = lo | (hi << 32);
+        units[gt2x_unit_index(unit, sb, n_units, n_sb) * 128 + rho] = x ^ ((x >> 1) & 0x5555555555555555ull);
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -883,9 +894,9 @@ hipError_t launch_gt2_to_gt2x(hipStream_t st, const uint32_t *d_src, uint64_t st
     (void)hipGetLastError();
     for (uint64_t sb = 0; sb < gm.n_sb; sb += 32768) {
         const uint64_t k = std::min<uint64_t>(32768, gm.n_sb - sb);
-        hipLaunchKernelGGL(gt2_to_gt2x_kernel, dim3((uint32_t)((gm.n_units + 1) / 2), (uint32_t)k), dim3(256), 0, st,
-                           d_src, stride_words, words_for(n_samples), n_rows, (unsigned long long *)d_units, gm.n_units,
-                           gm.n_sb, sb);
+        hipLaunchKernelGGL(gt2_to_gt2x_kernel, dim3((uint32_t)((gm.n_units + 15) / 16), (uint32_t)k), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(d_src), stride_words, words_for(n_samples), (n_rows + 3) / 4,
+                           (unsigned long long *)d_units, gm.n_units, gm.n_sb, sb);
     }
     return hipGetLastError();
 }
