@@ -62,10 +62,17 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 //          (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
 //          first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are
 //          the same instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
-constexpr int kBig = 6;                  // data waves 0..kBig-1 carry kUD units, data waves kBig..5 carry kUD2
-constexpr int kUD = 9;
-constexpr int kUD2 = 9;
-constexpr int kUC = 5;                   // units of the two control waves (6, 7), which do the per-row work of 64 rows each
+#ifndef NPS_MX_DW
+#define NPS_MX_DW 6   // data waves; NPS_MX_UD units each, the two control waves NPS_MX_UC each: 64 in all
+#define NPS_MX_UD 9
+#define NPS_MX_UC 5
+#endif
+constexpr int kDW = NPS_MX_DW;           // data waves 0..kDW-1; the two control waves follow
+constexpr int kMxThreads = (kDW + 2) * 64;
+constexpr int kBig = kDW;                // data waves 0..kBig-1 carry kUD units, data waves kBig..kDW-1 carry kUD2
+constexpr int kUD = NPS_MX_UD;
+constexpr int kUD2 = NPS_MX_UD;
+constexpr int kUC = NPS_MX_UC;           // units of the two control waves, which do the per-row work of 64 rows each
 constexpr int kTabBufs = 3;
 constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
 constexpr uint32_t kLdsTables = 131072;  // [kTabBufs][3 operands][128 rows][16 bytes]
@@ -99,7 +106,7 @@ struct MxArgs {
 };
 
 #ifdef NPS_MX_TIMERS
-__device__ unsigned long long g_mx_timers[8][16];  // [wave][phase]: cycles summed over the steps of one workgroup
+__device__ unsigned long long g_mx_timers[16][16];  // [wave][phase]: cycles summed over the steps of one workgroup
 #define MXT(i) do { if (timing) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[i] += now_ - tlast; tlast = now_; } } while (0)
 #else
 #define MXT(i) do { } while (0)
@@ -154,7 +161,7 @@ struct MxPre {
     long long w1, wfb;
 };
 static_assert(sizeof(MxPre) == 32, "MxPre layout");
-static_assert(kBig * kUD + (6 - kBig) * kUD2 + 2 * kUC == 64, "units of a strip");
+static_assert(kBig * kUD + (kDW - kBig) * kUD2 + 2 * kUC == 64, "units of a strip");
 
 __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows,
                                                       DevParams prm, double scale, MxPre *__restrict__ pre) {
@@ -273,9 +280,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
     const int u0 = wave < kBig ? wave * kUD
-                   : wave < 6  ? kBig * kUD + (wave - kBig) * kUD2
-                               : kBig * kUD + (6 - kBig) * kUD2 + (wave - 6) * kUC;
-    const int crow = lane + 64 * (wave - 6);  // control waves: the row of the superblock this lane works for
+                   : wave < kDW ? kBig * kUD + (wave - kBig) * kUD2
+                                : kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
+    const int crow = lane + 64 * (wave - kDW);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
 
@@ -624,21 +631,27 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
         if (lane == 0) {
             if (nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
-            if (cst_local != 0.0) a.const_sum[2 * team + (wave - 6)] = cst_local;  // (NaN != 0 is true)
+            if (cst_local != 0.0) a.const_sum[2 * team + (wave - kDW)] = cst_local;  // (NaN != 0 is true)
         }
     }
 }
 
 template <int DBG, bool GIVEN, int EARLY>
-__global__ __launch_bounds__(512, 2) void fused_mx_kernel(const MxArgs a) {
+__global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
     const int u0 = wave < kBig ? wave * kUD : kBig * kUD + (wave - kBig) * kUD2;  // (data waves)
-    if (wave >= 6)
-        mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN, EARLY>(a, smem);  // (v2: no units, n_my = 0)
-    else if (wave < kBig) {
+    if (wave >= kDW) {
+        // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units,
+        //  and the control waves are the step's critical path -- their five units took as long as a data wave's nine)
+        const int uc0 = kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
+        if (kUC > 0 && nu - uc0 >= kUC)
+            mx_body<(kUC > 0 ? kUC : 1), false, true, DBG, GIVEN, EARLY>(a, smem);
+        else
+            mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN, EARLY>(a, smem);  // (kUC = 0: no units, n_my = 0)
+    } else if (wave < kBig) {
         if (nu - u0 >= kUD)
             mx_body<kUD, false, false, DBG, GIVEN, EARLY>(a, smem);
         else
@@ -1010,24 +1023,24 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
         if (sched == 1)
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, 1>), grid, dim3(512), kLdsBytes, st, a);
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, 1>), grid, dim3(kMxThreads), kLdsBytes, st, a);
         else
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, 0>), grid, dim3(512), kLdsBytes, st, a);
+            hipLaunchKernelGGL((fused_mx_kernel<0, true, 0>), grid, dim3(kMxThreads), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};
 #ifdef NPS_MX_TIMERS
     {
-        hipError_t e = hipLaunchCooperativeKernel(fn, grid, dim3(512), args, kLdsBytes, st);
+        hipError_t e = hipLaunchCooperativeKernel(fn, grid, dim3(kMxThreads), args, kLdsBytes, st);
         if (e != hipSuccess) return e;
         (void)hipStreamSynchronize(st);
-        unsigned long long h[8][16];
+        unsigned long long h[16][16];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mx_timers), sizeof(h));
         // phases of a step, in order (control waves: 0 = look issue, early/mid table work; 6 = what is left of the look's
         // round trip after front(); 7 = tables)
         static const char *nm[16] = {"look-issue", "front", "barrier", "publish-begin", "accumulate", "publish-end", "look-wait",
                                      "tables", "loop/flush", "-", "-", "-", "-", "-", "-", "-"};
-        for (int w : {0, 3, 6, 7}) {
+        for (int w : {0, 3, kDW, kDW + 1}) {
             fprintf(stderr, "mx timers wave %d (cycles per step):", w);
             for (int i = 0; i < 9; ++i) fprintf(stderr, "  %s %.0f", nm[i], (double)h[w][i] / plan.n_sb);
             fprintf(stderr, "\n");
@@ -1035,7 +1048,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         return hipSuccess;
     }
 #endif
-    return hipLaunchCooperativeKernel(fn, grid, dim3(512), args, kLdsBytes, st);
+    return hipLaunchCooperativeKernel(fn, grid, dim3(kMxThreads), args, kLdsBytes, st);
 }
 
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
