@@ -559,7 +559,11 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         MXT(8);
         // late schedule: the look at the row's word travels while the control wave does its own tallying and parking
         // (its result is waited for by hand: the compiler does not know the load, so its own counted waits only become
-        // stricter).  Before round 4's last change the look was issued, waited for and turned into tables BEFORE front():
+        // stricter.  With a load the compiler does know -- the atomic builtin, or a buffer load with sc1 -- it waits
+        // with vmcnt(0) at the first use, i.e. for the five unit loads front() has just issued: the branches around
+        // them make it lose count.  The price of the asm: x_look must stay in its register until the hand-written
+        // wait -- the compiler may not copy it meanwhile, and has no reason to; if a future compiler did, every
+        // parity test of tests/test_gpu_mx.py would fail, the tables would be made of stale words).  Before round 4's last change the look was issued, waited for and turned into tables BEFORE front():
         // 24.3 -> 22.5-23.2 ms at 245 strips.
         constexpr bool kUnder = !kEarly && !GIVEN;
         if (is_ctl && kUnder) {
