@@ -144,11 +144,10 @@ static __device__ __forceinline__ void mx_codes(long long w, uint32_t flag, uint
     c[0] = c0 | (c1 << 24);
     c[1] = (c1 >> 8) | (c2 << 16);
     c[2] = (c2 >> 16) | (c3 << 8) | (flag << 26);
-    if (w < 0) {
-        c[0] |= 0x20820820u;
-        c[1] |= 0x08208208u;
-        c[2] |= 0x02082082u;
-    }
+    const uint32_t neg = (uint32_t)(w >> 63);  // all ones for a negative weight: the sign bit of every digit
+    c[0] |= neg & 0x20820820u;
+    c[1] |= neg & 0x08208208u;
+    c[2] |= neg & 0x02082082u;
 }
 
 // Per score row, everything that does not depend on the row's tally (one launch per pass, before the fused kernel):
@@ -204,15 +203,20 @@ static __device__ __forceinline__ double fast_ratio(double n, double d) {
 
 // One row, from its complete tally word: the decisions of getImputedDosages (nimpress.nim:565-571), the locus
 // constant (:417-447) or the sample imputation value (:450-481), as the three weight operands of the row.
+// what mx_row needs of the row's precomputed part beyond MxPre itself: made BEFORE the row's tally word is back
+struct MxPreX {
+    double w1d;        // (double)w1
+    long long w3, w4;  // 3 w1, 4 w1
+};
 static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long long x, bool live, uint64_t row,
-                                              const MxPre &pre, bool write_stats, uint32_t (&wc)[3], uint32_t (&wme)[3],
-                                              uint32_t (&wmo)[3], int &used, double &cst) {
+                                              const MxPre &pre, const MxPreX &px, bool write_stats, uint32_t (&wc)[3],
+                                              uint32_t (&wme)[3], uint32_t (&wmo)[3], int &used, double &cst) {
     wc[0] = wc[1] = wc[2] = wme[0] = wme[1] = wme[2] = wmo[0] = wmo[1] = wmo[2] = 0u;
     used = 0;
     cst = 0.0;
     if (!live) return;
-    const uint64_t nmiss = (x >> 28) & 0xFFFFFFFull, neff = x & 0xFFFFFFFull;
-    const uint64_t ngen = a.n_samples - nmiss;
+    const uint32_t nmiss = (uint32_t)(x >> 28) & 0xFFFFFFFu, neff = (uint32_t)x & 0xFFFFFFFu;  // (both < 2^28)
+    const uint32_t ngen = (uint32_t)a.n_samples - nmiss;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     int reason;
     if ((int64_t)nmiss > a.t_maxmis) {  // == (double)nmiss / (double)N > --maxmis, t_maxmis found with that very division
@@ -229,23 +233,27 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
     } else {
         reason = NPS_REASON_GENOTYPED;
         used = 1;
-        if (pre.flags & 1u) {
-            cst = nan;  // a non-finite beta makes every sample's sum NaN (0 * NaN, NaN + x), as in the reference
-        } else {
-            long long wi = pre.wfb;
-            bool bad = (pre.flags & 2u) != 0;
-            const bool internal = a.prm.imp_sample == NPS_SAMPLE_INT_PS || a.prm.imp_sample == NPS_SAMPLE_INT_FAIL;
-            if (internal && (double)ngen >= a.prm.min_cs) {
-                const double imp = fast_ratio((double)neff, (double)ngen);
-                bad = imp != imp;
-                wi = bad ? 3 * pre.w1 : __double2ll_rn(imp * (double)pre.w1);
-            }
-            wc[0] = pre.c[0];
-            wc[1] = pre.c[1];
-            wc[2] = pre.c[2];
-            mx_codes(wi - 3 * pre.w1, bad ? 1u : 0u, wme);  // a missing genotype has code 3 (4 in the odd operand)
-            mx_codes(wi - 4 * pre.w1, bad ? 1u : 0u, wmo);
+        // the common path without branches: the internal imputation value is worked out for every row and
+        // selected (the control wave's step waits for exactly this chain of dependent operations)
+        const bool internal = a.prm.imp_sample == NPS_SAMPLE_INT_PS || a.prm.imp_sample == NPS_SAMPLE_INT_FAIL;
+        const double dgen = (double)ngen;
+        const bool use_int = internal && dgen >= a.prm.min_cs;
+        const double imp = fast_ratio((double)neff, dgen);
+        const bool imp_nan = imp != imp;
+        const long long wint = __double2ll_rn((imp_nan ? 0.0 : imp) * px.w1d);
+        const bool bad = use_int ? imp_nan : (pre.flags & 2u) != 0;
+        const long long wi = use_int ? (imp_nan ? px.w3 : wint) : pre.wfb;
+        const bool dead = (pre.flags & 1u) != 0;  // a non-finite beta makes every sample's sum NaN (0 * NaN, NaN + x), as in the reference
+        uint32_t e[3], o[3];
+        mx_codes(wi - px.w3, bad ? 1u : 0u, e);  // a missing genotype has code 3 (4 in the odd operand)
+        mx_codes(wi - px.w4, bad ? 1u : 0u, o);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wc[i] = dead ? 0u : pre.c[i];
+            wme[i] = dead ? 0u : e[i];
+            wmo[i] = dead ? 0u : o[i];
         }
+        if (dead) cst = nan;
     }
     if (write_stats) {
         nps_locus_stat s;
@@ -438,12 +446,20 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                        : __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // complete tallies of superblock k (x) -> the row's three operands in table buffer k % kTabBufs
+    MxPreX px;  // (of npre: made by ctl_pre_extra() while the look at the row's word is still under way)
+    px.w1d = 0.0;
+    px.w3 = px.w4 = 0;
+    auto ctl_pre_extra = [&]() {
+        px.w1d = (double)npre.w1;
+        px.w3 = 3 * npre.w1;
+        px.w4 = 4 * npre.w1;
+    };
     auto ctl_build = [&](uint32_t k, unsigned long long x, bool valid, bool ok) {
         const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
         uint32_t wc[3], wme[3], wmo[3];
         int used;
         double cst;
-        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
+        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, px, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
         char *p = smem + kLdsTables + (k % kTabBufs) * 6144 + crow * 16;
         *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
         *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
@@ -481,6 +497,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 }
             }
         }
+        if (!have_x) ctl_pre_extra();
         ctl_build(k, x, valid, ok);
     };
     // The strip's tallies of superblock kp are complete in LDS (barrier passed).  Same-line atomics are served one
@@ -580,6 +597,8 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         front(k, b_tal, b_park, s_park);
         MXT(1);
         if (is_ctl && kUnder) {
+            ctl_pre_extra();  // (what the operands need of the precomputed row, before the look is waited for)
+            asm volatile("" : : "v"(px.w1d), "v"(px.w3), "v"(px.w4));
             // the wave's loads return in order: once at most the NU loads front() issued after the look are
             // outstanding, the look has returned (whatever else -- an add of the last step -- is still under way)
             if (k + 3 < n_t && n_my == NU)
@@ -609,6 +628,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             const bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
             next_done = k + 1 < n_t && __all(ok);
             if (next_done) {
+                ctl_pre_extra();
                 ctl_build(k + 1, x, valid, ok);
                 ctl_fetch_pre(k + 2);
             }
