@@ -99,6 +99,13 @@ static __device__ __forceinline__ double uniform_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// diagnostics builds (-DNPS_DS_TIMERS): cycles per phase of the control wave and of data wave 1 of one workgroup
+#ifdef NPS_DS_TIMERS
+__device__ unsigned long long g_ds_timers[2][8];
+#define DST(i) do { if (timing) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define DST(i) do { } while (0)
+#endif
 template <int T>
 __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     constexpr uint32_t kDsSliceSamples = ds_slice_samples(T);
@@ -111,6 +118,10 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     const uint32_t n_local = a.n_batches > team ? (a.n_batches - team + a.Q - 1) / a.Q : 0;
     const uint32_t n_steps = (n_local + D - 1) / D * D;
 
+#ifdef NPS_DS_TIMERS
+    const bool timing = slice == a.P / 2 && team == 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     auto batch_row0 = [&](uint32_t k) -> uint64_t { return (uint64_t)(team + (uint64_t)k * a.Q) * R; };
 
     // Barrier #j closes the phase in which the data waves tallied batch j.
@@ -277,13 +288,22 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         poll_finish(1, cur);
         __syncthreads();  // #4
         for (uint32_t k = 0; k < n_steps; ++k) {
+            DST(7);
             Polled nxt = poll_issue(k + 2);   // batch k+2: published by every slice TWO phases ago: complete unless a slice lags
             publish(k + 4);
+            DST(0);
             poll_finish(k + 2, nxt);
+            DST(1);
             params(k + 1, cur);
+            DST(2);
             cur = nxt;
             __syncthreads();  // #(k+5)
+            DST(3);
         }
+#ifdef NPS_DS_TIMERS
+        if (timing && lane == 0)
+            for (int i = 0; i < 8; ++i) g_ds_timers[0][i] = tph[i];
+#endif
         if (slice == 0 && lane == 0 && nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
         return;
     }
@@ -373,12 +393,17 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     };
 
     auto step = [&](uint32_t k, float(&r_cur)[R * kDsPerThread], const float(&r_tal)[R * kDsPerThread]) {
+        DST(7);
         accumulate(k, r_cur);
+        DST(0);
         load_batch(k + 6, r_cur);  // in flight during the tally below and the next accumulation
         __builtin_amdgcn_sched_barrier(0);
+        DST(1);
         tally(k + 5, r_tal);
         __builtin_amdgcn_sched_barrier(0);
+        DST(2);
         __syncthreads();  // #(k+5)
+        DST(3);
     };
 
     load_batch(0, ring[0]);
@@ -405,6 +430,10 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
         step(k + 4, ring[4], ring[3]);
         step(k + 5, ring[5], ring[4]);
     }
+#ifdef NPS_DS_TIMERS
+    if (timing && tid == 64)
+        for (int i = 0; i < 8; ++i) g_ds_timers[1][i] = tph[i];
+#endif
     double *dst = a.part + (uint64_t)team * a.part_team_stride;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -496,6 +525,21 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
     const void *fn = plan.threads == 1024  ? (const void *)ds_fused_kernel<1024>
                      : plan.threads == 960 ? (const void *)ds_fused_kernel<960>
                                            : (const void *)ds_fused_kernel<896>;
+#ifdef NPS_DS_TIMERS
+    {
+        hipError_t e = hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
+        if (e != hipSuccess) return e;
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[2][8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ds_timers), sizeof(h));
+        const double steps = (double)((plan.n_batches + plan.Q - 1) / plan.Q);
+        fprintf(stderr, "ds timers control wave (cycles per phase): issue+publish %.0f  poll-finish %.0f  params %.0f  barrier %.0f  loop %.0f\n",
+                h[0][0] / steps, h[0][1] / steps, h[0][2] / steps, h[0][3] / steps, h[0][7] / steps);
+        fprintf(stderr, "ds timers data wave 1 (cycles per phase): accumulate %.0f  load-issue %.0f  tally %.0f  barrier %.0f  loop %.0f\n",
+                h[1][0] / steps, h[1][1] / steps, h[1][2] / steps, h[1][3] / steps, h[1][7] / steps);
+        return hipSuccess;
+    }
+#endif
     return hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);
 }
 
