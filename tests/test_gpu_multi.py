@@ -257,6 +257,8 @@ def test_multi_bad_arguments():
         msc.score_cohort(co, mdef, 64)                # not on a superblock boundary
     with pytest.raises(capi.NpsError):
         capi.MultiDef(np.zeros((9, 4), dtype=capi.ROW_DESC_DTYPE))   # more than 8 scores
+    with pytest.raises(capi.NpsError):
+        capi.MultiDef(d, weight_bits=40)              # 41 or 49 (nps_multidef_create_bits)
     bad = d.copy()
     bad["beta"][0, 0] = np.inf
     with pytest.raises(capi.NpsError):
