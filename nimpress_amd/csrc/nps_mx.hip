@@ -103,6 +103,7 @@ struct MxArgs {
                              // order the teams finish in, which a float atomicAdd per team was not)
     float *cpart;            // [n_flush][Q][P][64][2][256]
     unsigned int *timeout;
+    uint32_t ctl_prio;       // the control waves run at raised issue priority (see fused_mx_kernel)
 };
 
 #ifdef NPS_MX_TIMERS
@@ -668,6 +669,10 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
     const int u0 = wave < kBig ? wave * kUD : kBig * kUD + (wave - kBig) * kUD2;  // (data waves)
     if (wave >= kDW) {
+        // the control waves are the step's critical path and share their SIMD with a data wave: up to ~200 strips per
+        // team they issue first (200 000 samples 9.95 -> 9.29 ms, 400 000 20.5 -> 19.6, 100 000 and 250 000 +1 %); at
+        // 245 strips the step is set by the hand-over chain instead and the priority costs up to 2.5 %
+        if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
         // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units,
         //  and the control waves are the step's critical path -- their five units took as long as a data wave's nine)
         const int uc0 = kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
@@ -1044,6 +1049,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.const_sum = d_const_sum;
     a.cpart = d_cpart;
     a.timeout = d_timeout;
+    a.ctl_prio = plan.P <= 208 ? 1u : 0u;
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
         if (sched == 1)
