@@ -253,8 +253,8 @@ void nps_destroy(nps_ctx *ctx);
 #define NPS_FMT_GT2X 3
 /* nps_cohort_create only: a 2-bit cohort in whichever of the two resident layouts is scored fastest in ONE read of the
  * matrix at this cohort size on this device -- NPS_FMT_GT2X where its grid (P = ceil(N / 2048) strips x floor(CUs / P)
- * row teams) covers at least nine tenths of the compute units (on an MI355X: N <= 262 144 and about 470 000 <= N <=
- * 522 240), NPS_FMT_GT2 otherwise (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
+ * row teams) covers at least seven tenths of the compute units (on an MI355X: N <= 262 144 but for a few sizes around
+ * 180 000, and 366 593 <= N <= 522 240), NPS_FMT_GT2 otherwise (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
  * it became; use row offsets that are multiples of 128 (what NPS_FMT_GT2X asks for) and both behave alike towards the
  * caller (plain rows of NPS_CODE_* codes in and out). */
 #define NPS_FMT_GT_AUTO 4

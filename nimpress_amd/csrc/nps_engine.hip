@@ -957,14 +957,16 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
         // whichever 2-bit layout is scored in ONE read at this cohort size: strips (matrix cores, time independent of the
         // genotypes) while there is a compute unit per 2048-sample strip, row groups (table lookups; 14 336 samples per
         // compute unit) beyond that -- on an MI355X up to 522 240 samples and up to about 3.6 million samples
-        // ... and while the strips' grid fills the chip: P strips x Q row teams is P x floor(CUs / P) workgroups, which
-        // leaves 128 < P < ~230 (262 144 < N < ~470 000 samples on 256 CUs) with P workgroups only; the row kernel's
-        // 14 336-sample slices have teams to spare there
+        // ... and while the strips' grid fills enough of the chip: P strips x Q row teams is P x floor(CUs / P)
+        // workgroups, which leaves 128 < P < 180 (262 144 < N <= 366 592 samples on 256 CUs) with less than seven
+        // tenths of the compute units; the row kernel's 14 336-sample slices have teams to spare there (measured, ms
+        // per 1M rows, strips / rows: 300 000 samples 18.8 / 14.9, 350 000 17.9 / 17.6, 400 000 18.7 / 20.6, 450 000
+        // 21.3 / 23.1)
         MxPlan mp;
         HIP_TRY(mx_plan(device, n_samples, std::max<uint64_t>(n_rows, 1 << 20), false, &mp));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        const bool fills = mp.ok && !mp.given && (uint64_t)mp.P * mp.Q * 10 >= (uint64_t)prop.multiProcessorCount * 9;
+        const bool fills = mp.ok && !mp.given && (uint64_t)mp.P * mp.Q * 10 >= (uint64_t)prop.multiProcessorCount * 7;
         format = (n_samples == 0 || fills) ? NPS_FMT_GT2X : NPS_FMT_GT2;
     }
     nps_cohort *c = new (std::nothrow) nps_cohort;

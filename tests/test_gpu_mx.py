@@ -410,7 +410,7 @@ def test_gt2x_beta_span_plain_relative_bar(mode):
 
 
 @pytest.mark.parametrize("n,want", [(3000, capi.FMT_GT2X), (250000, capi.FMT_GT2X), (300000, capi.FMT_GT2),
-                                    (522240, capi.FMT_GT2X), (530000, capi.FMT_GT2)])
+                                    (400000, capi.FMT_GT2X), (522240, capi.FMT_GT2X), (530000, capi.FMT_GT2)])
 def test_gt_auto_layout_is_the_single_read_one(n, want):
     """NPS_FMT_GT_AUTO: strips where their grid (strips x row teams) covers the chip, row groups where it does not
     (147 strips at 300 000 samples have no second team) or cannot (more strips than compute units) -- either way
