@@ -331,13 +331,15 @@ def size_sweep(capi, device, args, seed, steps=3):
     """The single-score pass by COHORT SIZE (the strip kernel fitted one shape).  The reference scores
     any N (nimpress.nim:626-628).  100 000 samples (BASELINE configs[1]'s cohort: 49 strips x 5 row teams), 250 000
     (123 x 2), 300 000 (147 strips and no second team: 147 of 256 compute units -- the row layout's 21 slices x 12 teams
-    fill the chip there, and NPS_FMT_GT_AUTO picks it), 1 000 000 (489 strips, more than the chip has compute units:
+    fill the chip there, and NPS_FMT_GT_AUTO picks it), 400 000 (196 strips, seven tenths of the chip: strips again),
+    1 000 000 (489 strips, more than the chip has compute units:
     tally pass + accumulation, two reads; the row-layout kernel reads once), each on the bench distribution, both
     single-score kernels, NPS_MODE_AUTO;
     HIP events on the library's stream, best of `steps`; with the oracle's subset check per shape and kernel."""
     import torch
     out = []
-    for n, m in ((100_000, 1_000_000), (250_000, 1_000_000), (300_000, 1_000_000), (1_000_000, 500_000)):
+    for n, m in ((100_000, 1_000_000), (250_000, 1_000_000), (300_000, 1_000_000), (400_000, 1_000_000),
+                 (1_000_000, 500_000)):
         beta, eaf, miss = synth_score(m, seed, "gt")
         th, tm, tmi = hwe_thresholds(eaf, miss)
         alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
