@@ -95,7 +95,7 @@ struct MxArgs {
     int64_t t_maxmis;        // the largest nmissing for which nmissing / N > --maxmis is false (-1: none)
     double scale;            // 2^F
     unsigned long long *tally;  // [n_sb * 128], zero on entry (GIVEN: the complete whole-row tallies, from mx_tally_kernel)
-    unsigned long long *tally1;  // [groups of 16 strips][n_sb * 128], zero on entry: first stage of the hand-over
+    unsigned long long *tally1;  // [groups of grp_strips strips][n_sb * 128] (sized for groups of 16), zero on entry: first stage of the hand-over
     nps_locus_stat *stats;
     unsigned long long *nloci;
     double *const_sum;       // [2 Q], zero on entry: slot 2 team + control wave = the locus constants of that wave's rows over
@@ -104,6 +104,7 @@ struct MxArgs {
     float *cpart;            // [n_flush][Q][P][64][2][256]
     unsigned int *timeout;
     uint32_t ctl_prio;       // the control waves run at raised issue priority (see fused_mx_kernel)
+    uint32_t grp_strips;     // strips per first-stage group of the hand-over (16 .. 64: tally1 is sized for groups of 16)
 };
 
 #ifdef NPS_MX_TIMERS
@@ -503,10 +504,10 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     };
     // The strip's tallies of superblock kp are complete in LDS (barrier passed).  Same-line atomics are served one
     // after the other at the memory side (~25 ns each), so 245 strips adding to one row's word would take longer
-    // than the step and a half the pipeline allows: the strips arrive in groups of 16 on a word of their group,
-    // and the strip whose add completes a group (told by the value its add returned) adds the group's sum to the
-    // row's word: at most 16 adds in a row on either word.
-    const uint32_t grp = strip >> 4, grp_size = min(16u, a.P - (grp << 4));
+    // than the step and a half the pipeline allows: the strips arrive in groups (of 48, a.grp_strips: 16 at first) on a
+    // word of their group, and the strip whose add completes a group (told by the value its add returned) adds the
+    // group's sum to the row's word: at most 48 adds in a row on a group's word, at most 6 on the row's.
+    const uint32_t grp = strip / a.grp_strips, grp_size = min(a.grp_strips, a.P - grp * a.grp_strips);
     unsigned long long pub_old = 0ull, pub_add = 0ull;
     bool pub_live = false;
     auto ctl_publish_begin = [&](uint32_t kp) {
@@ -1050,6 +1051,16 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.cpart = d_cpart;
     a.timeout = d_timeout;
     a.ctl_prio = plan.P <= 208 ? 1u : 0u;
+    // strips per first-stage group (measured at 16 / 32 / 48 / 64, ms per 1M rows: 200 000 samples 9.48 / 9.27 / 9.07 /
+    // 9.09, 400 000 20.1 / 19.6 / 19.6 / 19.7, 500 000 23.80 / 23.55 / 23.48 / 23.49; 8: slower, 128: slower)
+    a.grp_strips = 48u;
+#ifdef NPS_MX_GRP_ENV
+    if (getenv("NPS_MX_GRP")) {  // (experiment builds) 0 = balanced groups of at most 64
+        const int g = atoi(getenv("NPS_MX_GRP"));
+        const uint32_t ng = (plan.P + 63) / 64;
+        a.grp_strips = g > 0 ? (uint32_t)std::max(16, g) : (plan.P + ng - 1) / ng;
+    }
+#endif
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
         if (sched == 1)
