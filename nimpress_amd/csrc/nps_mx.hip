@@ -44,24 +44,18 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 #define NPS_LDS __attribute__((address_space(3)))
 
 // Data waves 0..5 carry 9 units each, the control waves 6, 7 five units each plus the per-row work of 64 rows each.
-// Two schedules of the control chain, chosen per launch (template parameter EARLY: a run-time flag with both paths in
-// one kernel cost 20 % -- the compiler drains the memory queue where the paths join):
-//   late:  the tables of superblock k are made in step k, in front of the step's barrier: the look at the rows' tally
-//          words is issued at the start of the step and travels while the control wave tallies and parks its own
-//          units; the operands follow when it is back.  (Until the end of round 4 the look was issued, waited for and
-//          turned into operands BEFORE the wave's own tallying: 24.3 -> 22.5-23.2 ms at 245 strips, and the "mid"
-//          schedule -- the look a third of a step earlier -- that served 97..160 strips lost to it everywhere.)
-//   early: the tables of superblock k + 1 are made during the second half of step k: the look at its tally words is
-//          issued with the returning add of the publication of k + 2, the control wave accumulates its own units
-//          meanwhile, and the operands follow (three table buffers).  Nothing of the control chain is left in front of
-//          the barrier -- unless a word was not complete at that look, one step after its publication.  With few strips
-//          per team the two-stage publication is over by then; with 245 strips it mostly is not, and a look at an
-//          incomplete word queues at the memory side in front of the adds it waits for.  Measured with the present late
-//          schedule (ms per 1M-row pass, late / early): 49 strips 4.66 / 4.59; 98 strips 10.21 / 10.38; 123 strips
-//          11.19 / 11.69; 196 strips 21.17 / 22.11; 245 strips 23.4 / 27.6 -- the plan takes early up to 64 strips.
-//          (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
-//          first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are
-//          the same instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
+// The control chain: the tables of superblock k are made in step k, in front of the step's barrier -- the look at the
+// rows' tally words is issued at the start of the step and travels while the control wave tallies and parks its own
+// units; the operands follow when it is back.  History: until the end of round 4 the look was issued,
+// waited for and turned into operands BEFORE the wave's own tallying (24.3 -> 22.5-23.2 ms at 245 strips).  Two other
+// schedules existed as template instantiations (a run-time flag with both paths in one kernel cost 20 %): "early" --
+// the tables of k + 1 made during the second half of step k, the look issued with the returning add of the
+// publication of k + 2 (three table buffers) -- which won below 96 strips per team over the old order and loses to the
+// present one at every size (ms per 1M rows, present / early: 29 strips 2.65 / 2.70, 49 strips 4.23 / 4.33, 64 strips
+// 5.34 / 5.56, 98 strips 8.94 / 9.72, 245 strips 23.4 / 27.6), and "mid" (the look a third of a step earlier).  Both
+// are gone.  (Control waves without units -- 11 / 10 units per data wave -- need 273 VGPRs: 136 spilled.  Keeping the
+// first stage of the publication inside an XCD's L2 is not possible: workgroup- and agent-scope atomics are the same
+// instruction on gfx950 -- sc1 only selects system scope -- and execute at the memory side.)
 #ifndef NPS_MX_DW
 #define NPS_MX_DW 6   // data waves; NPS_MX_UD units each, the two control waves NPS_MX_UC each: 64 in all
 #define NPS_MX_UD 9
@@ -73,7 +67,7 @@ constexpr int kBig = kDW;                // data waves 0..kBig-1 carry kUD units
 constexpr int kUD = NPS_MX_UD;
 constexpr int kUD2 = NPS_MX_UD;
 constexpr int kUC = NPS_MX_UC;           // units of the two control waves, which do the per-row work of 64 rows each
-constexpr int kTabBufs = 3;
+constexpr int kTabBufs = 2;
 constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
 constexpr uint32_t kLdsTables = 131072;  // [kTabBufs][3 operands][128 rows][16 bytes]
 constexpr uint32_t kLdsTally = kLdsTables + kTabBufs * 6144;  // [2][128] uint32: nmissing << 16 | neffect of the strip
@@ -279,9 +273,8 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int SCHED>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
-    constexpr bool kEarly = SCHED == 1;  // 0 late, 1 early
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
     const uint32_t strip = blockIdx.x % a.P, team = blockIdx.x / a.P;
@@ -569,7 +562,6 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 
     // ---- steps
     unsigned long long x_look = 0ull;  // (late schedule) the look in flight
-    bool next_done = false;  // (early schedule, wave-uniform) the tables of the NEXT step's superblock are already in LDS
 #ifdef NPS_MX_TIMERS
     const bool timing = strip == a.P / 2 && team == 0;
     unsigned long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -584,17 +576,14 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         // wait -- the compiler may not copy it meanwhile, and has no reason to; if a future compiler did, every
         // parity test of tests/test_gpu_mx.py would fail, the tables would be made of stale words).  Before round 4's last change the look was issued, waited for and turned into tables BEFORE front():
         // 24.3 -> 22.5-23.2 ms at 245 strips.
-        constexpr bool kUnder = !kEarly && !GIVEN;
+        constexpr bool kUnder = !GIVEN;
         if (is_ctl && kUnder) {
             const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
             x_look = 0ull;
             if (k < n_t && row < a.n_rows)  // (an agent-scope relaxed load, as ctl_word's)
                 asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(x_look) : "v"(&a.tally[row]) : "memory");
         }
-        if (is_ctl && !kUnder && !(kEarly && next_done)) {
-            ctl_tables(k);
-            if (kEarly) ctl_fetch_pre(k + 1);  // (normally fetched a step ahead, below)
-        }
+        if (is_ctl && !kUnder) ctl_tables(k);  // (given tallies: plain loads)
         MXT(0);
         front(k, b_tal, b_park, s_park);
         MXT(1);
@@ -613,32 +602,14 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         MXT(7);
         __syncthreads();
         MXT(2);
-        if (is_ctl && !kEarly) {  // the returning add and the loads are in flight during the wave's own accumulation
+        if (is_ctl) {  // the returning add and the loads are in flight during the wave's own accumulation
             ctl_publish_begin(k + 2);
             ctl_fetch_pre(k + 1);
         }
         MXT(3);
-        if (is_ctl && kEarly) {
-            // publication of k+2 and a look at k+1 (published by every strip a step ago) in ONE round trip, spent on the
-            // wave's own accumulation; where the look finds every row complete, the tables of k+1 are made here, a step
-            // ahead of their barrier
-            ctl_publish_begin(k + 2);
-            bool valid;
-            const unsigned long long x = ctl_word(k + 1, valid);
-            accumulate(k, s_acc);
-            ctl_publish_end(k + 2);
-            const bool ok = !valid || GIVEN || (uint32_t)(x >> 56) == a.P || (DBG & 4);
-            next_done = k + 1 < n_t && __all(ok);
-            if (next_done) {
-                ctl_pre_extra();
-                ctl_build(k + 1, x, valid, ok);
-                ctl_fetch_pre(k + 2);
-            }
-        } else {
-            accumulate(k, s_acc);
-        }
+        accumulate(k, s_acc);
         MXT(4);
-        if (is_ctl && !kEarly) ctl_publish_end(k + 2);
+        if (is_ctl) ctl_publish_end(k + 2);
         MXT(5);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
     };
@@ -662,7 +633,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-template <int DBG, bool GIVEN, int EARLY>
+template <int DBG, bool GIVEN>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
     extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
@@ -678,19 +649,19 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
         //  and the control waves are the step's critical path -- their five units took as long as a data wave's nine)
         const int uc0 = kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
         if (kUC > 0 && nu - uc0 >= kUC)
-            mx_body<(kUC > 0 ? kUC : 1), false, true, DBG, GIVEN, EARLY>(a, smem);
+            mx_body<(kUC > 0 ? kUC : 1), false, true, DBG, GIVEN>(a, smem);
         else
-            mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN, EARLY>(a, smem);  // (kUC = 0: no units, n_my = 0)
+            mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN>(a, smem);  // (kUC = 0: no units, n_my = 0)
     } else if (wave < kBig) {
         if (nu - u0 >= kUD)
-            mx_body<kUD, false, false, DBG, GIVEN, EARLY>(a, smem);
+            mx_body<kUD, false, false, DBG, GIVEN>(a, smem);
         else
-            mx_body<kUD, true, false, DBG, GIVEN, EARLY>(a, smem);
+            mx_body<kUD, true, false, DBG, GIVEN>(a, smem);
     } else {
         if (nu - u0 >= kUD2)
-            mx_body<kUD2, false, false, DBG, GIVEN, EARLY>(a, smem);
+            mx_body<kUD2, false, false, DBG, GIVEN>(a, smem);
         else
-            mx_body<kUD2, true, false, DBG, GIVEN, EARLY>(a, smem);
+            mx_body<kUD2, true, false, DBG, GIVEN>(a, smem);
     }
 }
 
@@ -1001,28 +972,25 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
     }
-    // the control chain's schedule by the number of strips that hand over to each other (table at the top of the file)
-    const int sched = plan.P <= 64 ? 1 : 0;
-    const void *fn = plan.given ? (sched == 1 ? (const void *)fused_mx_kernel<0, true, 1> : (const void *)fused_mx_kernel<0, true, 0>)
-                                : (sched == 1 ? (const void *)fused_mx_kernel<0, false, 1> : (const void *)fused_mx_kernel<0, false, 0>);
+    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true> : (const void *)fused_mx_kernel<0, false>;
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
     if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false, 0>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false, 0>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false, 0>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false, 0>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false, 0>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false, 0>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false, 0>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false, 0>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false, 0>; break;
+        case 1: fn = (const void *)fused_mx_kernel<1, false>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false>; break;
         default: break;
         }
 #endif
-    static const void *attr_set[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const int which = (plan.given ? 3 : 0) + sched;
+    static const void *attr_set[2] = {nullptr, nullptr};
+    const int which = plan.given ? 1 : 0;
     if (attr_set[which] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -1063,10 +1031,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
 #endif
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        if (sched == 1)
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, 1>), grid, dim3(kMxThreads), kLdsBytes, st, a);
-        else
-            hipLaunchKernelGGL((fused_mx_kernel<0, true, 0>), grid, dim3(kMxThreads), kLdsBytes, st, a);
+        hipLaunchKernelGGL((fused_mx_kernel<0, true>), grid, dim3(kMxThreads), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};
