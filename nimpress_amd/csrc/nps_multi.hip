@@ -746,11 +746,24 @@ MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, bool co
     pl.n_groups = (n_samples + 31) / 32;
     pl.n_sb = (uint32_t)((n_rows + 127) / 128);
     pl.tiles = (uint32_t)((pl.n_groups + 31) / 32);  // 32 groups = 1 024 samples per workgroup
-    // one workgroup per CU at a time: enough of them (~12 rounds) that the last, partly filled round costs
-    // little, every chunk at least 16 superblocks long
-    uint32_t q = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
-    q = std::min<uint32_t>(q, std::max<uint32_t>(1, pl.n_sb / 16));
-    q = std::min<uint32_t>(q, 64);
+    // one workgroup per CU at a time: enough row chunks (12 rounds of workgroups or more) that the last round is nearly
+    // full -- the smallest count whose last round wastes at most 1.5 % of the grid's slots (489 tiles of 1 024 samples:
+    // 7 chunks left 0.63 of a round empty, 41.6 ms; 12 chunks fill 22.92 rounds, 39.9 ms), every chunk at least 16
+    // superblocks long
+    const uint32_t q_hi = std::min<uint32_t>(64, std::max<uint32_t>(1, pl.n_sb / 16));
+    uint32_t q_lo = (uint32_t)std::max<uint64_t>(1, ((uint64_t)cus * 12 + pl.tiles - 1) / pl.tiles);
+    q_lo = std::min(q_lo, q_hi);
+    uint32_t q = q_lo;
+    double best = 2.0;
+    for (uint32_t c = q_lo; c <= std::min<uint32_t>(q_hi, 4 * q_lo + 8); ++c) {
+        const uint64_t wgs = (uint64_t)pl.tiles * c, rounds = (wgs + cus - 1) / cus;
+        const double waste = 1.0 - (double)wgs / (double)(rounds * cus);
+        if (waste < best - 1e-12) {
+            best = waste;
+            q = c;
+        }
+        if (waste <= 0.015) break;
+    }
     // int32 digit sums: the operand bytes of one byte of genotypes (four rows, both matrices) are at most
     // 3 + 15 + 63 + 128 and 1 + 5 + 21 + 85, a digit at most 128: 41 088 per four rows, so a chunk holds at most
     // 2^31 / 10 272 rows = 1 633 superblocks
