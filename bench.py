@@ -32,6 +32,8 @@ import subprocess
 import sys
 import time
 
+T_START = time.perf_counter()
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +79,19 @@ def parse_args():
     ap.add_argument("--ds-chunk-rows", type=int, default=300_000,
                     help="resident chunk of the N > 1 FORMAT/DS leg (rows; 300 000 x 200 000 float32 = 240 GB)")
     ap.add_argument("--cpu-rows", type=int, default=2000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--full-sweeps", action="store_true",
+                    help="every secondary leg at full width (all six genotype distributions, the size x distribution "
+                         "sweep, the multi-score options): what tools/profile_round.sh runs; the default keeps the run "
+                         "inside the driver's window")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the FULL object (headline + every secondary leg) is written; the last stdout line is the "
+                         "compact one (< 4 KiB) the driver parses")
+    ap.add_argument("--extras-budget", type=float, default=150.0,
+                    help="seconds since process start after which no further secondary leg is STARTED (the ones skipped "
+                         "are listed); --full-sweeps: no budget")
+    ap.add_argument("--extras-deadline", type=float, default=420.0,
+                    help="seconds since process start after which the compact line is printed without the unfinished "
+                         "secondary legs and the run ends with status 3")
     ap.add_argument("--seed", type=int, default=20250103)
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="--gpus N without a launcher: seconds after which all ranks are killed (exit status 124)")
@@ -327,33 +342,57 @@ def strong_scaling_leg(torch, dist, multi, capi, args, rank, world, device, fmt,
 
 # ------------------------------------------------------------------------------------------------
 # secondary measurements (rank 0, N = 1, after the headline; none of them is `value`)
-def size_sweep(capi, device, args, seed, steps=3):
-    """The single-score pass by COHORT SIZE (the strip kernel fitted one shape).  The reference scores
-    any N (nimpress.nim:626-628).  100 000 samples (BASELINE configs[1]'s cohort: 49 strips x 5 row teams), 250 000
-    (123 x 2), 300 000 (147 strips and no second team: 147 of 256 compute units -- the row layout's 21 slices x 12 teams
-    fill the chip there, and NPS_FMT_GT_AUTO picks it), 400 000 (196 strips, seven tenths of the chip: strips again),
-    1 000 000 (489 strips, more than the chip has compute units:
-    tally pass + accumulation, two reads; the row-layout kernel reads once), each on the bench distribution, both
-    single-score kernels, NPS_MODE_AUTO;
-    HIP events on the library's stream, best of `steps`; with the oracle's subset check per shape and kernel."""
+def size_sweep(capi, device, args, seed, steps=3, full=True):
+    """The single-score pass by COHORT SIZE x GENOTYPE DISTRIBUTION (VERDICT round 3: the strip kernel fitted one shape;
+    round 4: NPS_FMT_GT_AUTO's worst case over size AND distribution was unreported).  The reference scores any N
+    (nimpress.nim:626-628).  Sizes: 100 000 samples (BASELINE configs[1]'s cohort), 250 000, 300 000 (147 strips: the
+    awkward middle), 400 000, 500 000, 1 000 000 (more strips than compute units); distributions: the bench cohort,
+    eaf 0.5 in every row (the table-lookup kernel's worst case), uniformly random codes (--maxmis=1).  On the bench
+    distribution both single-score kernels run; elsewhere the layout NPS_FMT_GT_AUTO picks for the size.  NPS_MODE_AUTO, HIP
+    events on the library's stream, best of `steps`; every case with the oracle's subset check.
+    Default run (not --full-sweeps): 100 000 and 1 000 000 samples on the bench distribution and 300 000 on eaf 0.5, the
+    automatic layout only."""
     import torch
+    SC = 4294967296.0
+    f = lambda x: np.minimum(np.floor(np.asarray(x, dtype=np.float64) * SC), 4294967295.0).astype(np.uint32)
+    sizes = ((100_000, 1_000_000), (250_000, 1_000_000), (300_000, 1_000_000), (400_000, 1_000_000),
+             (500_000, 1_000_000), (1_000_000, 500_000))
+    dists = ("bench", "eaf 0.5", "uniform codes")
+    if full:
+        plan = [(n, m, d) for n, m in sizes for d in dists]
+    else:
+        plan = [(100_000, 1_000_000, "bench"), (300_000, 1_000_000, "eaf 0.5"), (1_000_000, 500_000, "bench")]
+        steps = 2
+    labels = {capi.FMT_GT2X: "strip_layout_matrix_cores", capi.FMT_GT2: "row_layout_table_lookups"}
     out = []
-    for n, m in ((100_000, 1_000_000), (250_000, 1_000_000), (300_000, 1_000_000), (400_000, 1_000_000),
-                 (1_000_000, 500_000)):
+    for n, m, dist in plan:
         beta, eaf, miss = synth_score(m, seed, "gt")
-        th, tm, tmi = hwe_thresholds(eaf, miss)
+        kw = {}
+        if dist == "bench":
+            th, tm, tmi = hwe_thresholds(eaf, miss)
+        elif dist == "eaf 0.5":
+            th, tm, tmi = hwe_thresholds(0.5 * np.ones(m), miss)
+        else:
+            one = np.ones(m)
+            th, tm, tmi = f(2 * one / 3), f(one / 3), f(0.25 * one)
+            kw = dict(maxmis=1.0)
         alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
         d = torch.empty(n, dtype=torch.float64, device="cuda")
         sdef = capi.ScoreDef(capi.row_descs(beta, eaf), device=device)
-        row = {"samples": n, "rows": m}
-        for label, fmt in (("strip_layout_matrix_cores", capi.FMT_GT2X), ("row_layout_table_lookups", capi.FMT_GT2)):
+        auto = capi.Cohort(n, 128, fmt=capi.FMT_GT_AUTO, device=device)   # what nps_cohort_create picks for this size
+        auto_fmt = auto.fmt
+        auto.close()
+        row = {"samples": n, "rows": m, "cohort": dist, "NPS_FMT_GT_AUTO_picks": labels[auto_fmt]}
+        fmts = (capi.FMT_GT2X, capi.FMT_GT2) if (full and dist == "bench") else (auto_fmt,)
+        for fmt in fmts:
             co = capi.Cohort(n, m, fmt=fmt, device=device)
             for x in range(0, m, 1 << 15):
                 y = min(m, x + (1 << 15))
                 co.synth_at(x, x, seed, th[x:y], tm[x:y], tmi[x:y])
             if fmt == capi.FMT_GT2:
                 co.optimize()
-            sc = capi.Scorer(n, capi.make_params(), device=device)
+            prm = capi.make_params(**kw)
+            sc = capi.Scorer(n, prm, device=device)
             geo = sc.fused_geometry(m, fmt)
             best, reads = None, 1
             for i in range(steps + 1):
@@ -370,24 +409,81 @@ def size_sweep(capi, device, args, seed, steps=3):
             r = {"ms_per_pass": best, "frac_of_8TBps": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "reads_of_the_matrix": reads,
                  "persistent_grid": {"slices": geo[0], "teams": geo[1], "samples_per_slice": geo[2]}}
             if not args.no_cpu_baseline:
+                from oracle import refcpu
                 sc.reset()
                 sc.score_cohort_def(co, sdef, 0, capi.MODE_AUTO)
                 stats = sc.flush()
                 got, nl = sc.finish(0.0)
-                r["score_delta_vs_reference"] = score_delta(stats, got, nl, "gt", beta, eaf, seed, n, m, th, tm, tmi,
-                                                            geo, recount=1000)
+                sd = score_delta(stats, got, nl, "gt", beta, eaf, seed, n, m, th, tm, tmi, geo, recount=1000,
+                                 params=refcpu.make_params(**kw))
+                sd.pop("checked", None)
+                r["score_delta_vs_reference"] = sd
             sc.close()
             co.close()
             torch.cuda.empty_cache()
-            row[label] = r
+            row[labels[fmt]] = r
         sdef.close()
-        auto = capi.Cohort(n, 128, fmt=capi.FMT_GT_AUTO, device=device)   # what nps_cohort_create picks for this size
-        row["NPS_FMT_GT_AUTO_picks"] = "strip_layout_matrix_cores" if auto.fmt == capi.FMT_GT2X else "row_layout_table_lookups"
-        auto.close()
-        row["auto_layout_frac_of_8TBps"] = row[row["NPS_FMT_GT_AUTO_picks"]]["frac_of_8TBps"]
+        row["auto_layout_frac_of_8TBps"] = row[labels[auto_fmt]]["frac_of_8TBps"]
         out.append(row)
-    return {"cases": out, "strip_layout_worst_frac": min(r["strip_layout_matrix_cores"]["frac_of_8TBps"] for r in out),
-            "auto_layout_worst_frac": min(r["auto_layout_frac_of_8TBps"] for r in out)}
+    res = {"cases": out, "auto_layout_worst_frac": min(r["auto_layout_frac_of_8TBps"] for r in out),
+           "auto_layout_worst_case": min(out, key=lambda r: r["auto_layout_frac_of_8TBps"])["cohort"] + " x %d samples"
+                                     % min(out, key=lambda r: r["auto_layout_frac_of_8TBps"])["samples"]}
+    strips = [r["strip_layout_matrix_cores"]["frac_of_8TBps"] for r in out if "strip_layout_matrix_cores" in r]
+    if strips:
+        res["strip_layout_worst_frac"] = min(strips)
+    return res
+
+
+def given_tallies(capi, sc, cohort, sdef, d_scores, n, m, headline_ms, steps=5):
+    """Experiment B of the round-4 verdict, a SECONDARY (the headline counts its tallies in the pass): the same resident
+    cohort after nps_cohort_keep_tallies -- tallyAlleles of every row counted once, kept with the cohort -- scored under
+    NPS_MODE_AUTO with the tallies given: one read, no popcounts, no hand-over between the strips.  Legitimate for many
+    score files over one cohort (configs[3]: tally once, score 8 times); the one-time cost is reported beside it.  The
+    scores must equal the headline pass's (same kernel arithmetic, same tallies; 1e-9 relative because the two grids
+    group the exact digit sums differently), the row statistics bit for bit."""
+    import torch
+    sc.reset()
+    sc.score_cohort_def(cohort, sdef, 0, capi.MODE_AUTO)
+    sc.finish_device(0.0, d_scores.data_ptr())
+    want = d_scores.clone()
+    st_want = sc.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cohort.keep_tallies()
+    keep_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cohort.keep_tallies()           # (the second call has its buffer: the cost of the count alone)
+    keep_s = min(keep_s, time.perf_counter() - t0)
+    best, nl = None, 0
+    for i in range(steps + 1):
+        sc.reset()
+        sc.profile_enable(True)
+        sc.profile_get(reset=True)
+        sc.score_cohort_def(cohort, sdef, 0, capi.MODE_AUTO)
+        nl = sc.finish_device(0.0, d_scores.data_ptr())
+        p = sc.profile_get(reset=True)
+        ms = p.ms_fused + p.ms_tally + p.ms_params + p.ms_accumulate
+        if i:
+            best = ms if best is None else min(best, ms)
+    sc.profile_enable(False)
+    st = sc.flush()
+    # (teams differ between the two grids, so the float64 sums of the exact digit sums group differently: 1e-9
+    # relative, |ref| floored at 1e-12 of the largest score, NaN positions equal)
+    a, b = d_scores.cpu().numpy(), want.cpu().numpy()
+    ok_nan = bool(np.array_equal(np.isnan(a), np.isnan(b)))
+    fin = ~np.isnan(b)
+    floor = 1e-12 * float(np.abs(b[fin]).max()) if fin.any() else 0.0
+    worst = float((np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), max(floor, 1e-300))).max()) if fin.any() else 0.0
+    same = ok_nan and worst <= 1e-9
+    stats_same = bool(all(np.array_equal(st[k], st_want[k]) for k in ("ngenotyped", "nmissing", "neffect", "used", "reason")))
+    alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
+    return {"what": "the headline cohort carrying its whole-row tallies (nps_cohort_keep_tallies: counted once, one read of "
+                    "the matrix), scored with the tallies given; NOT the headline, which counts them in the pass",
+            "ms_per_pass": best, "frac_of_8TBps": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "one_time_tally_ms": keep_s * 1e3, "headline_ms_per_step": headline_ms, "nloci": int(nl),
+            "outputs_equal_headline_within_1e-9_relative": same, "outputs_max_relative_difference": worst,
+            "outputs_equal_row_statistics": stats_same,
+            "passes_after_which_it_pays": (keep_s * 1e3) / max(headline_ms - best, 1e-9) if best < headline_ms else None}
 
 
 def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=20250105):
@@ -618,7 +714,7 @@ def multi_score(capi, device, args, n, m, seed, S=8, steps=3):
     return out
 
 
-def layout_sweep(capi, device, n, m, seed, steps=3):
+def layout_sweep(capi, device, n, m, seed, steps=3, full=True):
     """The single-score pass by genotype distribution (the table-lookup kernel's time depends on
     how a wave's 64 table indices spread over the LDS banks; the matrix-core kernel's must not).  Six synthetic
     cohorts of the bench shape, each regenerated on the device; best of `steps` passes, HIP events on the
@@ -643,6 +739,9 @@ def layout_sweep(capi, device, n, m, seed, steps=3):
         ("20 % missing, --maxmis=1", hwe(np.round(rng.uniform(0.01, 0.5, m), 4), 0.2 * one), dict(maxmis=1.0), False),
         ("uniform codes, --maxmis=1", (f(2 * one / 3), f(one / 3), f(0.25 * one)), dict(maxmis=1.0), False),
     ]
+    if not full:    # the default run: the bench distribution and the table kernel's worst case (the driver's window)
+        cases = [c for c in cases if c[3]]
+        steps = 2
     alg = m * ((n + 15) // 16) * 4 + 40 * m + 8 * n
     d = torch.empty(n, dtype=torch.float64, device="cuda")
     sdef = capi.ScoreDef(capi.row_descs(beta, 0.3 * one), device=device)
@@ -650,7 +749,7 @@ def layout_sweep(capi, device, n, m, seed, steps=3):
     for name, (th, tm, tmi), kw, both in cases:
         row = {"cohort": name}
         for label, fmt in (("strip_layout_matrix_cores", capi.FMT_GT2X), ("row_layout_table_lookups", capi.FMT_GT2)):
-            if fmt == capi.FMT_GT2 and not both:
+            if fmt == capi.FMT_GT2 and (not both or (not full and name.startswith("bench"))):
                 continue
             co = capi.Cohort(n, m, fmt=fmt, device=device)
             for x in range(0, m, 1 << 15):
@@ -833,6 +932,113 @@ def config4_e2e(tmpdir, n=500_000):
     return out
 
 
+
+# ------------------------------------------------------------------------------------------------
+# output: the driver parses the LAST stdout line; round 4's 20 KB line (every secondary object inline) was not parsed.
+# The full object goes to a side file and to stderr, the last stdout line is the compact one.
+LINE_LIMIT = 4096
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _r(x, digits=6):
+    """floats of the compact line at `digits` significant digits (the full object keeps every digit)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else x
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def secondary_summary(sec):
+    """one number per leg (at most ten keys): enough to see that a leg ran and roughly what it measured"""
+    s = {}
+
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    for name, path in (("strip_worst_frac_over_distributions", ("layout_sweep", "strip_layout_worst_frac")),
+                       ("auto_layout_worst_frac_over_sizes", ("size_sweep", "auto_layout_worst_frac")),
+                       ("multi_score_ms_per_8_score_pass", ("multi_score", "ms_per_pass")),
+                       ("strip_given_tallies_frac", ("given_tallies", "frac_of_8TBps")),
+                       ("config5_ds_frac", ("config5_ds", "roofline", "frac")),
+                       ("ds16_frac_of_its_2B_per_dosage", ("config5_ds16", "roofline", "frac")),
+                       ("streaming_int8_genotypes_per_s", ("streaming", "nps_push_gt_raw int8", "genotypes_per_s")),
+                       ("config2_e2e_s", ("config2", "config2_e2e_s")),
+                       ("config4_e2e_s", ("config4", "e2e_s"))):
+        v = get(sec, *path)
+        if v is not None:
+            s[name] = v
+    bad = sorted(k for k, v in sec.items() if isinstance(v, dict) and ("error" in v or "skipped" in v))
+    if bad:
+        s["legs_failed_or_skipped"] = bad
+    return s
+
+
+def compact_line(out):
+    """the object the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the parity flags, and a summary of
+    the secondary legs; kept under LINE_LIMIT bytes whatever the legs returned"""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "rccl_ranks"))
+    cfg = out.get("config", {})
+    c["config"] = _pick(cfg, ("workload", "samples", "variants", "nloci", "mode", "parallelism"))
+    c["roofline"] = _pick(out.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                   "algorithmic_bytes_per_step", "kernel_ms_per_launch"))
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "nproc", "cpu_model"))
+        for k in ("with_binomtest", "all_cores"):
+            if k in cb:
+                c["cpu_baseline"][k] = _pick(cb[k], ("value", "cores"))
+    if "score_delta_vs_reference" in out:
+        c["score_delta_vs_reference"] = _pick(out["score_delta_vs_reference"],
+                                              ("max_abs", "max_rel", "within_1e-6_relative", "nloci_equal",
+                                               "tally_recount_equal", "samples_checked", "rows_recounted"))
+    if "secondary" in out:
+        c["secondary_summary"] = secondary_summary(out["secondary"])
+    if "multi_gpu" in out:
+        mg = out["multi_gpu"]
+        c["multi_gpu"] = ({k: _pick(v, ("value", "scaling", "n_gpus", "ms_per_pass", "scoring_ms", "exchange_ms", "nloci"))
+                           for k, v in mg.items() if isinstance(v, dict)} if "error" not in mg else _pick(mg, ("error",)))
+    for k in ("parity_failures", "full_object", "rehearsal", "rehearsal_normalised", "seconds"):
+        if k in out:
+            c[k] = out[k]
+    c = _r(c)
+    # never over the limit: shed the optional parts, longest first
+    for drop in (("secondary_summary",), ("multi_gpu",), ("cpu_baseline", "sample"), ("config", "workload")):
+        if len(json.dumps(c)) < LINE_LIMIT:
+            break
+        d = c
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return c
+
+
+def emit(out, full_path):
+    """full object -> side file (+ stderr); compact object -> the last stdout line"""
+    where = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+        with open(full_path, "w") as f:
+            json.dump(out, f)
+            f.write("\n")
+        where = os.path.relpath(full_path, ROOT)
+    except OSError:
+        pass
+    print("bench_full " + json.dumps(out), file=sys.stderr, flush=True)
+    out = dict(out, full_object=where or "stderr (line starting with bench_full)")
+    print(json.dumps(compact_line(out)), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -950,6 +1156,7 @@ def main():
         elapsed = step.seg     # chunked: the sum of the timed scoring segments (generation excluded)
     prof = sc.profile_get(reset=True)
     sc.profile_enable(False)
+    t_headline = time.perf_counter()
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -1018,6 +1225,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dominant,
                          "algorithmic_bytes_per_step": alg_bytes,
+                         "kernel_ms_per_launch": (kern_ms[dominant] / max(1, {"tally": prof.n_tally, "accumulate": prof.n_accumulate,
+                                                                              "fused": prof.n_fused}[dominant])),
                          "kernel_ms_per_step": {k: v / steps for k, v in kern_ms.items()},
                          "launches_per_step": {"tally": prof.n_tally / steps,
                                                "params": prof.n_params / steps,
@@ -1034,7 +1243,7 @@ def main():
         def give_up():
             if rank == 0:
                 out["multi_gpu"] = {"error": "the strong-scaling legs did not finish within %.0f s" % args.multi_legs_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out, args.full_out)
             else:
                 time.sleep(5.0)
             os._exit(3)
@@ -1057,6 +1266,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            t_leg = time.perf_counter()
             if not is_ds:
                 out["cpu_baseline"] = cpu_baseline(n, eaf, miss, args.seed, args.cpu_rows)
             if resident:
@@ -1067,53 +1277,78 @@ def main():
                 got, nl = sc.finish(0.0)
                 out["score_delta_vs_reference"] = score_delta(
                     stats, got, nl, args.format, beta, eaf, args.seed, n, m, t_het, t_hom, t_miss, geometry)
+            out["seconds"] = {"to_headline": t_headline - T_START, "cpu_baseline_and_check": time.perf_counter() - t_leg}
         if world == 1 and not args.no_extras and not is_ds and resident:
-            sc.close()
-            for d in sdefs:
-                d.close()
-            cohort.close()      # frees the 125 GB matrix: the DS chunks need the room
-            torch.cuda.empty_cache()
             import tempfile
+            import threading
             secondary = {}
+            out["secondary"] = secondary
+            leg_s = out.setdefault("seconds", {})
+
+            def give_up_extras():
+                # a secondary leg that hangs must not cost the headline: print what there is, end with status 3
+                secondary["deadline"] = {"error": "secondary legs unfinished %.0f s after process start" % args.extras_deadline}
+                emit(out, args.full_out)
+                os._exit(3)
+
+            watchdog = threading.Timer(max(1.0, args.extras_deadline - (time.perf_counter() - T_START)), give_up_extras)
+            watchdog.daemon = True
+            if not args.full_sweeps:
+                watchdog.start()
 
             def leg(name, fn):
-                # a failing secondary measurement never takes the headline line down, but it does fail the run
+                # a failing secondary measurement never takes the headline line down, but it does fail the run;
+                # one that no longer fits the run's window is skipped and listed (not a failure)
+                if not args.full_sweeps and time.perf_counter() - T_START > args.extras_budget:
+                    secondary[name] = {"skipped": "time budget (%.0f s since process start; --full-sweeps runs it)"
+                                                  % args.extras_budget}
+                    return
+                t0 = time.perf_counter()
                 try:
                     secondary[name] = fn()
                 except Exception as e:
                     secondary[name] = {"error": repr(e)[:300]}
                 if isinstance(secondary[name], dict) and "error" in secondary[name]:
                     failed.append(name)
+                leg_s[name] = time.perf_counter() - t0
                 torch.cuda.empty_cache()
 
-            leg("layout_sweep", lambda: layout_sweep(capi, local_rank, n, m, args.seed))
-            leg("size_sweep", lambda: size_sweep(capi, local_rank, args, args.seed))
+            # legs that use the headline's resident cohort come first
+            leg("given_tallies", lambda: given_tallies(capi, sc, cohort, sdefs[0], d_scores, n, m, elapsed / steps * 1e3))
+            sc.close()
+            for d in sdefs:
+                d.close()
+            cohort.close()      # frees the 125 GB matrix: the other legs need the room
+            torch.cuda.empty_cache()
+
+            def config2_leg():
+                with tempfile.TemporaryDirectory() as td:
+                    return config2_e2e(td)
+
+            def config4_leg():
+                with tempfile.TemporaryDirectory() as td:
+                    return config4_e2e(td)
 
             def multi_leg():
                 r = multi_score(capi, local_rank, args, n, m, args.seed)
                 r["vs_single_score_passes"] = args.steps and (elapsed / steps * 1e3) / r["ms_per_score"]
                 return r
 
-            leg("multi_score", multi_leg)
+            leg("layout_sweep", lambda: layout_sweep(capi, local_rank, n, m, args.seed, full=args.full_sweeps))
+            leg("size_sweep", lambda: size_sweep(capi, local_rank, args, args.seed, full=args.full_sweeps))
             leg("config5_ds", lambda: ds_config5(capi, local_rank, args))
+            leg("multi_score", multi_leg)
             leg("streaming", lambda: streaming_rates(capi, local_rank, n, args.seed))
-
-            def config2_leg():
-                with tempfile.TemporaryDirectory() as td:
-                    return config2_e2e(td)
-
             leg("config2", config2_leg)
-
-            def config4_leg():
-                with tempfile.TemporaryDirectory() as td:
-                    return config4_e2e(td)
-
             leg("config4", config4_leg)
-            out["secondary"] = secondary
+            watchdog.cancel()
         if multi_legs is not None:
             out["multi_gpu"] = multi_legs
-        print(json.dumps(out), flush=True)
-        failed += ["parity:" + p for p in parity_failures(out)]
+        bad = parity_failures(out)
+        if bad:
+            out["parity_failures"] = bad
+        emit(out, args.full_out)
+        failed += ["parity:" + p for p in bad]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -142,6 +142,8 @@ int nps_warmup(int device);
 /* Replaces the set-up of computePolygenicScores (nimpress.nim:623-633): zeroed scores for
  * n_samples, nloci = 0.  device = HIP device ordinal. */
 int nps_create(nps_ctx **out, int device, uint64_t n_samples, const nps_params *params);
+uint64_t nps_n_samples(const nps_ctx *ctx); /* what nps_create was given (vcf.n_samples, nimpress.nim:626) */
+int nps_device(const nps_ctx *ctx);         /* its HIP device ordinal */
 
 /* PRESENT row with FORMAT/GT.  `gts` is the buffer bcf_get_genotypes fills (what hts-nim's
  * `genotypes(variant.format, gts)` iterates, nimpress.nim:381-384): n_samples*ploidy int32,
@@ -344,7 +346,10 @@ typedef struct nps_multidef nps_multidef;
  * bits (six digits): every term of a score is then within 2^-41 of the largest weight, a typical score within 1e-10
  * relative -- but a sample whose terms cancel to 1e-5 of the typical size is only within ~1e-5 of its own value, so
  * it is NOT inside the 1e-6 relative bar for every sample and stays an option; with 5, 6 or 8 scores the pass needs
- * a quarter fewer matrix instructions for it. */
+ * a quarter fewer matrix instructions for it.
+ * One scale per score: a definition whose non-zero |beta| span more than 2^25 (2^17 with 41-bit weights) is refused
+ * with NPS_E_UNSUPPORTED -- a sample that carries only its small-beta rows would not keep 1e-6 relative -- and belongs
+ * on the single-score path (nps_scoredef_create scores such a definition in magnitude bands of 2^30). */
 int nps_multidef_create(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc);
 int nps_multidef_create_bits(nps_multidef **out, int device, const nps_row_desc *rows, int n_scores, uint64_t n_desc,
                              int weight_bits /* 49, 41; 0 = default (49) */);
@@ -380,9 +385,17 @@ void nps_multi_destroy(nps_multi *m);
 int nps_multi_timing(nps_multi *m, double *ms_params, double *ms_product, double *ms_fold);
 /* NPS_FMT_GT2 cohort (plain order) -> NPS_FMT_GT2M (with its row tallies) or NPS_FMT_GT2X cohort of the same shape */
 int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src);
-/* the whole-row tallies a NPS_FMT_GT2M cohort carries (tallyAlleles, nimpress.nim:32-47), for warnings */
+/* the whole-row tallies a NPS_FMT_GT2M cohort carries (tallyAlleles, nimpress.nim:32-47), for warnings; also those of a
+ * NPS_FMT_GT2X cohort after nps_cohort_keep_tallies */
 int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64_t nrows, uint64_t *nmissing_out,
                            uint64_t *neffect_out);
+/* Count tallyAlleles (nimpress.nim:32-47, called per row at :563) of EVERY row of a NPS_FMT_GT2X cohort once and keep the
+ * result with the cohort (one read of the matrix).  nps_score_cohort[_def] under NPS_MODE_AUTO then scores the cohort with
+ * the tallies given -- no recount, no hand-over between the strips -- which is what many score files over one cohort want
+ * (BASELINE configs[3]): the decision chain of getImputedDosages (:565-583) sees exactly the same counts.  Any call that
+ * rewrites rows (upload, synth, convert) drops the kept tallies; NPS_MODE_FUSED / NPS_MODE_TWOPASS never use them. */
+int nps_cohort_keep_tallies(nps_cohort *c);
+int nps_cohort_has_tallies(const nps_cohort *c); /* 1: the cohort carries whole-row tallies */
 
 /* ---- measurement ------------------------------------------------------------------------ */
 int nps_profile_enable(nps_ctx *ctx, int on); /* record HIP events around every launch */

@@ -79,9 +79,30 @@ def build_host(force: bool = False, verbose: bool = False) -> List[str]:
     return [LIBHOST, CLI]
 
 
+COMM_DIR = os.path.join(CSRC, "comm")
+LIBCOMM = os.path.join(PKG_DIR, "libnps_rccl.so")
+
+
+def build_comm(force: bool = False, verbose: bool = False) -> str:
+    """libnps_rccl.so (include/nps_comm.h): the RCCL exchange step for single-process hosts.  Its own library, so that
+    libnps.so keeps no RCCL dependency; links libnps.so (rpath $ORIGIN) and librccl."""
+    build_libnps(force=False, verbose=verbose)
+    src = os.path.join(COMM_DIR, "nps_comm.hip")
+    inc = os.path.join(os.path.dirname(PKG_DIR), "include")
+    deps = [src, os.path.join(inc, "nps_comm.h"), os.path.join(inc, "nps.h"), LIBNPS]
+    if force or _stale(LIBCOMM, deps):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I" + inc, "-o", LIBCOMM, src, "-L" + PKG_DIR, "-lnps", "-lrccl",
+                                          "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIBCOMM
+
+
 def build_all(force: bool = False, verbose: bool = False) -> List[str]:
-    """Everything native in this package: libnps.so (HIP), libnimpress_host.so + nimpress (C++)."""
-    return [build_libnps(force=force, verbose=verbose)] + build_host(force=force, verbose=verbose)
+    """Everything native in this package: libnps.so (HIP), libnimpress_host.so + nimpress (C++), libnps_rccl.so (HIP + RCCL)."""
+    return ([build_libnps(force=force, verbose=verbose)] + build_host(force=force, verbose=verbose)
+            + [build_comm(force=force, verbose=verbose)])
 
 
 if __name__ == "__main__":

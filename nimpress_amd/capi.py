@@ -26,6 +26,7 @@ MULTI_MAX_SCORES = 8
 MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
 
 NPS_OK = 0
+E_INVAL, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
 STATUS_NAMES = {0: "NPS_OK", -1: "NPS_E_INVAL", -2: "NPS_E_NODEVICE", -3: "NPS_E_HIP",
                 -4: "NPS_E_NOMEM", -5: "NPS_E_STATE", -6: "NPS_E_UNSUPPORTED", -7: "NPS_E_TIMEOUT"}
 
@@ -49,7 +50,7 @@ ROW_DESC_DTYPE = np.dtype([("beta", "<f8"), ("eaf", "<f8"), ("kind", "<i4"),
 
 # every symbol include/nps.h declares (tests/test_capi_symbols.py checks the two lists agree)
 SYMBOLS = [
-    "nps_abi_version", "nps_last_error", "nps_device_count", "nps_warmup", "nps_create", "nps_push_gt",
+    "nps_abi_version", "nps_last_error", "nps_device_count", "nps_warmup", "nps_create", "nps_n_samples", "nps_device", "nps_push_gt",
     "nps_push_ds", "nps_push_packed", "nps_push_locus", "nps_flush", "nps_finish",
     "nps_push_gt_raw", "nps_push_bed", "nps_cohort_upload_bed", "nps_finish_device", "nps_partial_device", "nps_normalize_device", "nps_reset", "nps_scoredef_create", "nps_scoredef_n_present",
     "nps_scoredef_destroy", "nps_score_cohort_def",
@@ -60,7 +61,7 @@ SYMBOLS = [
     "nps_score_cohort", "nps_profile_enable", "nps_profile_get", "nps_stream", "nps_fused_geometry",
     "nps_multidef_create", "nps_multidef_create_bits", "nps_multidef_destroy", "nps_multi_create", "nps_score_cohort_multi",
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
-    "nps_cohort_convert", "nps_cohort_row_tallies", "nps_multi_set_missing_weight_bits",
+    "nps_cohort_convert", "nps_cohort_row_tallies", "nps_cohort_keep_tallies", "nps_cohort_has_tallies", "nps_multi_set_missing_weight_bits",
     "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device", "nps_multi_partial",
 ]
 
@@ -133,6 +134,9 @@ def load(with_torch: bool = True):
     L.nps_last_error.restype = C.c_char_p
     L.nps_device_count.restype = C.c_int
     L.nps_create.argtypes = [C.POINTER(vp), i32, u64, C.POINTER(NpsParams)]
+    L.nps_n_samples.argtypes = [vp]
+    L.nps_n_samples.restype = u64
+    L.nps_device.argtypes = [vp]
     L.nps_push_gt.argtypes = [vp, vp, i32, i32, i32, dbl, dbl]
     L.nps_push_gt_raw.argtypes = [vp, vp, i32, i32, i32, i32, dbl, dbl]
     L.nps_push_bed.argtypes = [vp, vp, i32, i32, dbl, dbl]
@@ -192,6 +196,8 @@ def load(with_torch: bool = True):
     L.nps_multi_set_missing_weight_bits.argtypes = [vp, i32]
     L.nps_cohort_convert.argtypes = [vp, vp]
     L.nps_cohort_row_tallies.argtypes = [vp, u64, u64, vp, vp]
+    L.nps_cohort_keep_tallies.argtypes = [vp]
+    L.nps_cohort_has_tallies.argtypes = [vp]
     _lib = L
     return L
 
@@ -272,6 +278,14 @@ class Cohort:
         nm, ne = np.zeros(max(nrows, 1), dtype=np.uint64), np.zeros(max(nrows, 1), dtype=np.uint64)
         _check(load().nps_cohort_row_tallies(self._h, row0, nrows, nm.ctypes.data, ne.ctypes.data))
         return nm[:nrows], ne[:nrows]
+
+    def keep_tallies(self):
+        """count every row's tallyAlleles once and keep them with this FMT_GT2X cohort: MODE_AUTO then scores it with the
+        tallies given (nps_cohort_keep_tallies)"""
+        _check(load().nps_cohort_keep_tallies(self._h))
+
+    def has_tallies(self) -> bool:
+        return bool(load().nps_cohort_has_tallies(self._h))
 
     def optimize(self):
         """one-time layout change (nps_cohort_optimize): parity layout of the high-bit planes, fewer LDS bank

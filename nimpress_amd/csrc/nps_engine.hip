@@ -61,6 +61,10 @@ struct nps_cohort {
     bool optimized = false;
     // NPS_FMT_GT2M: whole-row tallies (nmissing << 32 | neffect) produced by whatever packed the rows
     unsigned long long *d_row_tally = nullptr;
+    // NPS_FMT_GT2X after nps_cohort_keep_tallies: the whole-row tallies (nmissing << 28 | neffect, the tally word of the
+    // strip kernel without its arrival count), one per row of every superblock; valid until rows are rewritten
+    unsigned long long *d_mx_row_tally = nullptr;
+    bool mx_row_tally_valid = false;
     // nps_cohort_push_*: rows decoded on the device straight into the cohort (a pinned ring the decode kernel reads
     // over PCIe, on a stream of the cohort's own); every call that reads the cohort waits for it (cohort_quiesce)
     hipStream_t push_stream = nullptr;
@@ -456,6 +460,8 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
 }
 
 extern "C" void nps_destroy(nps_ctx *ctx) { free_ctx(ctx); }
+extern "C" uint64_t nps_n_samples(const nps_ctx *ctx) { return ctx ? ctx->n : 0; }
+extern "C" int nps_device(const nps_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 extern "C" int nps_reset(nps_ctx *c, const nps_params *params) {
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
@@ -1021,6 +1027,7 @@ extern "C" void nps_cohort_destroy(nps_cohort *c) {
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_data);
     (void)hipFree(c->d_row_tally);
+    (void)hipFree(c->d_mx_row_tally);
     (void)hipFree(c->d_push_tally);
     for (int k = 0; k < 2; ++k) {
         (void)hipHostFree(c->h_push[k]);
@@ -1173,6 +1180,7 @@ extern "C" int nps_cohort_upload_bed(nps_cohort *c, uint64_t row0, uint64_t nrow
         if (effect_is_a1[r] > NPS_MAP_PGEN_REF) return fail(NPS_E_INVAL, "row %llu: bad code map %d", (unsigned long long)r, (int)effect_is_a1[r]);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
+    c->mx_row_tally_valid = false;
     rc = cohort_unoptimize(c);
     if (rc) return rc;
     return gt2_upload(c, row0, nrows, bed_rows, row_stride_bytes, width, effect_is_a1);
@@ -1267,6 +1275,7 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
+    c->mx_row_tally_valid = false;    // (kept tallies describe the rows as they were: nps_cohort_keep_tallies again)
     if (c->format == NPS_FMT_GT2) {
         rc = cohort_unoptimize(c);
         if (rc) return rc;
@@ -1322,6 +1331,7 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
         return fail(NPS_E_INVAL, "row0 must be a multiple of 128 for NPS_FMT_GT2M / NPS_FMT_GT2X cohorts");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
+    c->mx_row_tally_valid = false;
     rc = cohort_unoptimize(c);
     if (rc) return rc;
     uint32_t *d_t = nullptr;
@@ -1585,8 +1595,12 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
+    bool kept_tallies = false;
     if (is_mx && m && c->n) {
-        const bool two_pass = mode == NPS_MODE_TWOPASS;
+        // a cohort that carries its tallies (nps_cohort_keep_tallies) is scored with them given under NPS_MODE_AUTO: the
+        // "two-pass" plan (independent workgroups) without its tally pass
+        kept_tallies = co->mx_row_tally_valid && mode == NPS_MODE_AUTO;
+        const bool two_pass = mode == NPS_MODE_TWOPASS || kept_tallies;
         if (c->mx_plan_valid && c->mx_plan_m == m && c->mx_plan_two_pass == two_pass) {
             mxp = c->mx_plan_cache;
         } else {
@@ -1761,7 +1775,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             }
             rc = tally_ready();
             if (rc) return rc;
-            if (mxp.given) {
+            if (mxp.given && !kept_tallies) {
                 ProfScope ps(c, P_TALLY);
                 HIP_TRY(launch_mx_tally(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n,
                                         c->d_rtally));
@@ -1770,13 +1784,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             {
                 ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
                 fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                     runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
-                                     c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
+                                     runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
+                                     kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally, c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
                                      const_slots, c->d_mx_cpart, c->d_timeout);
             }
             if (fe != hipSuccess) {
                 (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
-                c->rtally_clean = !mxp.given;
+                c->rtally_clean = !mxp.given || kept_tallies;
                 return fail(NPS_E_HIP, "NPS_FMT_GT2X kernel launch failed: %s", hipGetErrorString(fe));
             }
             guard.armed = true;
@@ -1950,6 +1964,7 @@ extern "C" int nps_cohort_convert(nps_cohort *dst, const nps_cohort *src) {
     { int qrc = cohort_quiesce(src); if (qrc) return qrc; }
     HIP_TRY(hipDeviceSynchronize());
     if (src->n_rows == 0 || src->n_samples == 0) return NPS_OK;
+    dst->mx_row_tally_valid = false;
     if (dst->format == NPS_FMT_GT2X) {
         HIP_TRY(launch_gt2_to_gt2x(nullptr, (const uint32_t *)src->d_data, src->stride_bytes / 4, src->n_samples,
                                    src->n_rows, dst->d_data));
@@ -1967,16 +1982,52 @@ extern "C" int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64
                                       uint64_t *neffect_out) {
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
-    if (c->format != NPS_FMT_GT2M) return fail(NPS_E_UNSUPPORTED, "row tallies are kept with NPS_FMT_GT2M cohorts only");
+    const bool kept = c->format == NPS_FMT_GT2X && c->mx_row_tally_valid;
+    if (c->format != NPS_FMT_GT2M && !kept)
+        return fail(NPS_E_UNSUPPORTED, "row tallies are kept with NPS_FMT_GT2M cohorts, and with NPS_FMT_GT2X cohorts after "
+                                       "nps_cohort_keep_tallies");
     if (nrows == 0) return NPS_OK;
     HIP_TRY(hipSetDevice(c->device));
     std::vector<unsigned long long> t(nrows);
-    HIP_TRY(hipMemcpy(t.data(), c->d_row_tally + row0, sizeof(unsigned long long) * nrows, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.data(), (kept ? c->d_mx_row_tally : c->d_row_tally) + row0, sizeof(unsigned long long) * nrows,
+                      hipMemcpyDeviceToHost));
     for (uint64_t j = 0; j < nrows; ++j) {
-        if (nmissing_out) nmissing_out[j] = t[j] >> 32;
-        if (neffect_out) neffect_out[j] = t[j] & 0xffffffffull;
+        if (nmissing_out) nmissing_out[j] = kept ? (t[j] >> 28) & 0xfffffffull : t[j] >> 32;
+        if (neffect_out) neffect_out[j] = kept ? t[j] & 0xfffffffull : t[j] & 0xffffffffull;
     }
     return NPS_OK;
+}
+
+// Experiment B of the round-4 verdict: a NPS_FMT_GT2X cohort that carries its whole-row tallies (tallyAlleles,
+// nimpress.nim:32-47, of every row over all samples), counted ONCE by mx_tally_kernel.  nps_score_cohort[_def] with
+// NPS_MODE_AUTO then scores the cohort with the tallies given: one read of the matrix, no popcounts, no hand-over
+// between the strips, an ordinary grid.  For many score files over one cohort (BASELINE configs[3]: tally once, score
+// eight times).  Rewriting rows (upload, synth, convert) drops the tallies.
+extern "C" int nps_cohort_keep_tallies(nps_cohort *c) {
+    if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
+    if (c->format != NPS_FMT_GT2X)
+        return fail(NPS_E_UNSUPPORTED, "nps_cohort_keep_tallies is for NPS_FMT_GT2X cohorts (NPS_FMT_GT2M carries its tallies "
+                                       "from the packer; the other layouts count while they read)");
+    if (c->n_rows == 0 || c->n_samples == 0) {
+        c->mx_row_tally_valid = true;
+        return NPS_OK;
+    }
+    if (c->n_samples >= (1ull << 27)) return fail(NPS_E_UNSUPPORTED, "more than 2^27 samples");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint64_t n_sb = gt2x_superblocks(c->n_rows);
+    if (!c->d_mx_row_tally) HIP_TRY(hipMalloc(&c->d_mx_row_tally, sizeof(unsigned long long) * n_sb * 128));
+    HIP_TRY(hipMemset(c->d_mx_row_tally, 0, sizeof(unsigned long long) * n_sb * 128));
+    MxPlan mp;
+    HIP_TRY(mx_plan(c->device, c->n_samples, c->n_rows, true, &mp));
+    if (!mp.ok) return fail(NPS_E_UNSUPPORTED, "shape beyond the NPS_FMT_GT2X kernels");
+    HIP_TRY(launch_mx_tally(nullptr, mp, c->d_data, n_sb, 0, c->n_samples, c->d_mx_row_tally));
+    HIP_TRY(hipDeviceSynchronize());
+    c->mx_row_tally_valid = true;
+    return NPS_OK;
+}
+extern "C" int nps_cohort_has_tallies(const nps_cohort *c) {
+    return c && (c->format == NPS_FMT_GT2M || (c->format == NPS_FMT_GT2X && c->mx_row_tally_valid)) ? 1 : 0;
 }
 
 struct nps_multidef {
@@ -2001,7 +2052,7 @@ extern "C" int nps_multidef_create_bits(nps_multidef **out, int device, const np
     if (n_desc > 0xfffffff0ull) return fail(NPS_E_UNSUPPORTED, "too many rows");
     int F[NPS_MULTI_MAX_SCORES];
     for (int s = 0; s < n_scores; ++s) {
-        double maxb = 0.0, maxe = 0.0;
+        double maxb = 0.0, maxe = 0.0, minb = HUGE_VAL;
         for (uint64_t j = 0; j < n_desc; ++j) {
             const nps_row_desc &r = rows[(uint64_t)s * n_desc + j];
             if (r.kind < NPS_ROW_PRESENT || r.kind > NPS_ROW_NOT_IN_SCORE)
@@ -2011,8 +2062,20 @@ extern "C" int nps_multidef_create_bits(nps_multidef **out, int device, const np
                 return fail(NPS_E_UNSUPPORTED, "score %d row %llu: beta is not finite (use the single-score path)",
                             s, (unsigned long long)j);
             maxb = std::max(maxb, std::fabs(r.beta));
+            if (r.beta != 0.0) minb = std::min(minb, std::fabs(r.beta));
             if (std::isfinite(r.eaf)) maxe = std::max(maxe, std::fabs(r.eaf));
         }
+        // One fixed-point scale per score: a weight is rounded to 2^-(8 ND - 9) of the largest one (x 5 for the imputation
+        // range), so a sample that carries only the score's SMALL-beta rows keeps 1e-6 relative only while
+        // 2.5 max|beta| / min|beta| <= 1e-6 x 2^(8 ND - 9): 2^25 for seven digits, 2^17 for six.  Beyond that the
+        // definition is refused here -- the single-score path (nps_scoredef_create + nps_score_cohort_def) scores such a
+        // definition in magnitude bands -- instead of silently losing those samples.
+        const double span_limit = std::ldexp(1.0, ND == 7 ? 25 : 17);
+        if (maxb > 0.0 && maxb / minb > span_limit)
+            return fail(NPS_E_UNSUPPORTED, "score %d: |beta| spans %.3g (%.3g .. %.3g), more than the 2^%d one %d-bit "
+                        "fixed-point scale holds within 1e-6 relative; score this definition with the single-score path "
+                        "(nps_scoredef_create / nps_score_cohort_def: magnitude bands), the others in one pass",
+                        s, maxb / minb, minb, maxb, ND == 7 ? 25 : 17, 8 * ND - 7);
         // largest weight a row can have: |beta| * max(|imputed - 3|, |locus constant|)
         const double bound = maxb * (3.0 + std::max(2.0, 2.0 * maxe));
         int e = 0;

@@ -304,3 +304,37 @@ def test_multi_partial_sums_of_row_blocks_add_up():
     assert np.array_equal(total, ref_nloci.astype(np.int64))
     assert np.allclose(got, ref, rtol=0, atol=1e-12 * float(np.abs(descs["beta"]).sum()), equal_nan=True)
     co.close()
+
+
+def test_multi_beta_span_is_refused_not_mis_scored():
+    """the multi-score weights have ONE fixed-point scale per score; a definition whose |beta| span more
+    than 2^25 (2^17 with 41-bit weights) would silently lose the samples that carry only its small-beta rows.
+    nps_multidef_create refuses it and names the single-score path (which bands such a definition and holds the plain
+    1e-6 bar on exactly this span: tests/test_gpu_mx.py::test_gt2x_beta_span_plain_relative_bar); the same eight
+    definitions with the wide one narrowed are accepted, and rows with beta = 0 do not count towards the span."""
+    m, S = 256, 8
+    rng = np.random.default_rng(99)
+    d = np.zeros((S, m), dtype=capi.ROW_DESC_DTYPE)
+    for s in range(S):
+        d[s]["beta"] = np.round(rng.normal(0, 0.02, m), 4) + 1e-4
+        d[s]["eaf"] = 0.3
+    wide = d.copy()
+    wide["beta"][5] = np.concatenate([rng.uniform(0.1, 1.0, m // 2) * 10.0, rng.uniform(0.1, 1.0, m // 2) * 1e-9])
+    with pytest.raises(capi.NpsError) as e:
+        capi.MultiDef(wide)
+    assert e.value.status == capi.E_UNSUPPORTED and "score 5" in str(e.value) and "single-score path" in str(e.value)
+    ok = d.copy()
+    ok["beta"][5, : m // 2] = 0.0                       # zeros are not part of the span
+    capi.MultiDef(ok).close()
+    edge = d.copy()
+    edge["beta"][2] = 1.0
+    edge["beta"][2, 0] = 2.0 ** -25                     # exactly at the limit: accepted
+    capi.MultiDef(edge).close()
+    edge["beta"][2, 0] = 2.0 ** -26
+    with pytest.raises(capi.NpsError):
+        capi.MultiDef(edge)
+    edge["beta"][2, 0] = 2.0 ** -17                     # six digits: 2^17
+    capi.MultiDef(edge, weight_bits=41).close()
+    edge["beta"][2, 0] = 2.0 ** -18
+    with pytest.raises(capi.NpsError):
+        capi.MultiDef(edge, weight_bits=41)

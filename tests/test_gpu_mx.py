@@ -13,6 +13,7 @@ from test_gpu_parity import PARAM_GRID, assert_stats_equal, make_cohort, oracle_
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-6
+ESCAPES = []   # (samples that passed only through check_scores' 2^-50 escape, samples checked) per call
 
 
 def check_scores(scores, ref_scores, beta, nloci):
@@ -25,16 +26,23 @@ def check_scores(scores, ref_scores, beta, nloci):
     assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN positions differ"
     ok = ~np.isnan(ref)
     if not ok.any():
-        return
+        return 0
     sb = float(np.sum(np.abs(beta))) / max(2.0 * nloci, 1.0)
     d = np.abs(got[ok] - ref[ok])
-    tol = np.maximum(REL_TOL * np.maximum(np.abs(ref[ok]), 1e-12 * sb), 2.0 ** -50 * sb)
+    plain = REL_TOL * np.maximum(np.abs(ref[ok]), 1e-12 * sb)
+    tol = np.maximum(plain, 2.0 ** -50 * sb)
+    # how many samples needed the escape (a bar the builder wrote for itself is at least counted):
+    # at most 1 in 1000 of the samples (and at most 2 in cohorts below 2000 samples)
+    escaped = int(np.count_nonzero((d > plain) & (d <= tol)))
+    ESCAPES.append((escaped, int(ok.sum())))
+    assert escaped <= max(2, int(ok.sum()) // 1000), "%d of %d samples pass only through the 2^-50 escape" % (escaped, ok.sum())
     bad = np.nonzero(d > tol)[0]
     if bad.size:  # say where: strip / unit / parity of the samples that differ
         idx = np.nonzero(ok)[0][bad]
         raise AssertionError("%d samples differ (max |d| %.3g, max relative %.3g): strips %s units %s parity %s first %s" % (
             bad.size, d.max(), rel_err(got, ref, beta, max(nloci, 1)), np.unique(idx >> 11)[:20],
             np.unique((idx >> 5) & 63)[:64], np.unique(idx & 1), idx[:12]))
+    return escaped
 
 
 def score_gt2x(dev, n, kw, descs, offset, row0=0, mode=capi.MODE_AUTO):
@@ -450,3 +458,55 @@ def test_gt2x_refusals():
     assert nloci == 10 and np.all(scores == 0.0)
     sc.close()
     dev.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2049, 129), (20000, 1001), (70000, 2000), (250000, 700), (530000, 130)])
+def test_gt2x_kept_tallies_vs_oracle(shape):
+    """nps_cohort_keep_tallies (VERDICT round 4, experiment B): the cohort carries tallyAlleles of every row, counted once;
+    NPS_MODE_AUTO then scores with the tallies given (one read, no hand-over).  Equal to the oracle, row statistics
+    bit-identical to the counting pass; the kept tallies equal the recount; rewriting rows drops them; a run that starts
+    inside the cohort (row0 = 128) uses the right words."""
+    n, m = shape
+    rng = np.random.default_rng(n * 5 + m)
+    co = make_cohort(n, m, 31337, rng)
+    kw = PARAM_GRID[(n + m + 4) % len(PARAM_GRID)]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
+    assert not dev.has_tallies()
+    base, nloci0, stats0 = score_gt2x(dev, n, kw, descs, 0.25)
+    dev.keep_tallies()
+    assert dev.has_tallies()
+    nm, ne = dev.row_tallies()
+    scores, nloci, stats = score_gt2x(dev, n, kw, descs, 0.25)
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.profile_enable(True)
+    sc.score_cohort(dev, descs, 0, capi.MODE_AUTO)
+    p = sc.profile_get(reset=True)
+    assert p.n_tally == 0 and p.n_fused == 0 and p.n_accumulate >= 1      # no tally pass, the given-tallies kernel
+    sc.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.25)
+    assert nloci == ref_nloci == nloci0
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    assert_stats_equal(stats0, [tuple(s) for s in ref_stats])
+    assert np.array_equal(nm, np.array([s[1] for s in ref_stats], dtype=np.uint64))
+    assert np.array_equal(ne.astype(np.float64), np.array([s[2] for s in ref_stats]))
+    check_scores(scores, ref_scores, co["beta"], nloci)
+    if m > 200:   # a run over rows 128.. of the cohort
+        sub, nl_sub, st_sub = score_gt2x(dev, n, kw, descs[128:], 0.0, row0=128)
+        ref_sub = oracle_scores(dict(co, m=m - 128, codes=co["codes"][128:], beta=co["beta"][128:], eaf=co["eaf"][128:],
+                                     rie=co["rie"][128:]), kw, 0.0)
+        assert nl_sub == ref_sub[2]
+        assert_stats_equal(st_sub, [tuple(s) for s in ref_sub[1]])
+        check_scores(sub, ref_sub[0], co["beta"][128:], nl_sub)
+    dev.synth(0, co["seed"] + 1, co["th"], co["tm"], co["tmi"])   # rows rewritten: the tallies are gone
+    assert not dev.has_tallies()
+    dev.close()
+
+
+def test_zz_escape_count_of_this_module():
+    """runs last in this file: over every check_scores call of the module, the samples that passed only through the
+    2^-50 escape are fewer than 1 in 1000 (printed with -s)"""
+    esc, tot = sum(e for e, _ in ESCAPES), sum(t for _, t in ESCAPES)
+    print("check_scores: %d of %d samples passed through the 2^-50 escape only (%d calls)" % (esc, tot, len(ESCAPES)))
+    assert tot > 0 and esc * 1000 <= tot
