@@ -253,12 +253,14 @@ void nps_destroy(nps_ctx *ctx);
  * are scored in two reads (a tally pass, then the same accumulation with the tallies given); NPS_MODE_FUSED
  * insists on the single read and returns NPS_E_UNSUPPORTED where it cannot be had. */
 #define NPS_FMT_GT2X 3
-/* nps_cohort_create only: a 2-bit cohort in whichever of the two resident layouts is scored fastest in ONE read of the
- * matrix at this cohort size on this device -- NPS_FMT_GT2X where its grid (P = ceil(N / 2048) strips x floor(CUs / P)
- * row teams) covers at least seven tenths of the compute units (on an MI355X: N <= 262 144 but for a few sizes around
- * 180 000, and 366 593 <= N <= 522 240), NPS_FMT_GT2 otherwise (its kernel holds 14 336 samples per compute unit).  nps_cohort_format tells which
- * it became; use row offsets that are multiples of 128 (what NPS_FMT_GT2X asks for) and both behave alike towards the
- * caller (plain rows of NPS_CODE_* codes in and out). */
+/* nps_cohort_create only: "the 2-bit resident layout this library scores best at this size" -- since round 5 that is
+ * NPS_FMT_GT2X at every size (nps_cohort_format tells; use row offsets that are multiples of 128).  Under NPS_MODE_AUTO
+ * a run whose resident grid (P = ceil(N / 2048) strips x floor(CUs / P) row teams) covers at least seven tenths of the
+ * compute units counts its tallies in the pass (tallyAlleles, nimpress.nim:563, inside the one read).  Other sizes
+ * (128 < P < 180: 262 145 .. 366 592 samples on an MI355X; P > CUs: beyond 522 240) count the cohort's tallies ONCE, on the
+ * first such run, keep them with the cohort (nps_cohort_keep_tallies) and score with the tallies given: the first run reads
+ * the matrix twice, every later run once, at a speed that does not depend on the genotypes.  (Until round 4 these sizes
+ * got NPS_FMT_GT2, whose table-lookup kernel runs at 0.47 .. 0.63 of the roofline depending on the genotypes.) */
 #define NPS_FMT_GT_AUTO 4
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
@@ -309,6 +311,12 @@ void nps_cohort_destroy(nps_cohort *c);
 #define NPS_MODE_AUTO 0
 #define NPS_MODE_TWOPASS 1 /* tally kernel, then accumulate kernel (reads the matrix twice) */
 #define NPS_MODE_FUSED 2   /* persistent fused kernel (reads the matrix once) */
+/* NPS_FMT_GT2X cohorts only (elsewhere = NPS_MODE_FUSED): the second form of the single-read strip kernel -- code x beta is
+ * accumulated as a superblock arrives, only the is-missing masks wait for the row tallies, rows that turn out to be over
+ * --maxmis (nimpress.nim:565-571) are taken back by the pass's epilogue.  Same results as NPS_MODE_FUSED (scores within a
+ * few ulps of the sum's terms, statistics bit for bit); slower on MI355X at present, kept as a measured
+ * experiment and never picked by NPS_MODE_AUTO. */
+#define NPS_MODE_FUSED_EAGER 3
 int nps_score_cohort(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
                      const nps_row_desc *rows, uint64_t n_desc, int mode);
 

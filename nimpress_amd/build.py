@@ -37,16 +37,40 @@ def _stale(target: str, deps: List[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+OBJ_DIR = os.path.join(os.path.dirname(PKG_DIR), "build", "obj")
+
+
 def build_libnps(force: bool = False, verbose: bool = False) -> str:
+    """libnps.so from csrc/*.hip: one object per source (rebuilt when the source, a csrc header or include/nps.h is newer),
+    compiled in parallel, then linked.  NPS_HIPCC_EXTRA: experiment builds (e.g. -DNPS_DIAGNOSTICS) -- never set by the
+    driver or the tests; the objects of such a build live in their own directory."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = libnps_sources()
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "nps.h"))
-    if force or _stale(LIBNPS, deps):
-        # (NPS_HIPCC_EXTRA: experiment builds, e.g. -DNPS_MX_V2 -- never set by the driver or the tests)
-        cmd = [_hipcc()] + HIPCC_FLAGS + os.environ.get("NPS_HIPCC_EXTRA", "").split() + ["-o", LIBNPS] + srcs
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "nps.h"))
+    extra = os.environ.get("NPS_HIPCC_EXTRA", "").split()
+    import hashlib
+    odir = OBJ_DIR + ("_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8] if extra else "")
+    os.makedirs(odir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = []
+    objs = []
+    for src in srcs:
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([_hipcc()] + flags + extra + ["-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _stale(LIBNPS, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBNPS] + objs)
     return LIBNPS
 
 

@@ -23,7 +23,7 @@ REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMI
 FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X, FMT_GT_AUTO = 0, 1, 2, 3, 4
 ROW_NOT_IN_SCORE = 4
 MULTI_MAX_SCORES = 8
-MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
+MODE_AUTO, MODE_TWOPASS, MODE_FUSED, MODE_FUSED_EAGER = 0, 1, 2, 3
 
 NPS_OK = 0
 E_INVAL, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
@@ -557,3 +557,83 @@ def row_descs(beta, eaf, kind=None, ref_is_effect=None) -> np.ndarray:
     if ref_is_effect is not None:
         out["ref_is_effect"] = np.asarray(ref_is_effect, dtype=np.int32)
     return out
+
+
+# ---- libnps_rccl.so (include/nps_comm.h): the exchange step for single-process hosts ---------------------------------
+COMM_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnps_rccl.so")
+COMM_SYMBOLS = ["nps_comm_last_error", "nps_comm_init_all", "nps_comm_size", "nps_comm_device", "nps_comm_destroy",
+                "nps_comm_allgather_scores", "nps_comm_allreduce_partial", "nps_comm_allreduce_partial_multi"]
+_comm_lib = None
+
+
+def load_comm():
+    """libnps_rccl.so, loaded on first use (it brings in RCCL; libnps.so does not)"""
+    global _comm_lib
+    if _comm_lib is None:
+        load()
+        if not os.path.exists(COMM_LIB_PATH):
+            raise RuntimeError("libnps_rccl.so is not built (python -m nimpress_amd.build)")
+        L = C.CDLL(COMM_LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.nps_comm_last_error.restype = C.c_char_p
+        L.nps_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, vp]
+        L.nps_comm_size.argtypes = [vp]
+        L.nps_comm_device.argtypes = [vp, C.c_int]
+        L.nps_comm_destroy.argtypes = [vp]
+        L.nps_comm_destroy.restype = None
+        L.nps_comm_allgather_scores.argtypes = [vp, vp, vp, vp, vp]
+        L.nps_comm_allreduce_partial.argtypes = [vp, vp, C.c_double, vp, vp]
+        L.nps_comm_allreduce_partial_multi.argtypes = [vp, vp, C.c_int, u64, vp, vp, vp]
+        _comm_lib = L
+    return _comm_lib
+
+
+class Comm:
+    """One process, several GPUs of one node: ncclCommInitAll + the two collectives of the sharded layouts."""
+
+    def __init__(self, n_devices: int, devices=None):
+        L = load_comm()
+        h = C.c_void_p()
+        dv = None if devices is None else (C.c_int * n_devices)(*devices)
+        self._check(L.nps_comm_init_all(C.byref(h), n_devices, dv))
+        self._h = h
+        self.size = L.nps_comm_size(h)
+
+    @staticmethod
+    def _check(rc):
+        if rc != 0:
+            raise NpsError(rc, (load_comm().nps_comm_last_error() or b"").decode())
+
+    def device(self, rank: int) -> int:
+        return load_comm().nps_comm_device(self._h, rank)
+
+    def allgather_scores(self, scorers, offsets, d_matrix_ptrs) -> np.ndarray:
+        n = self.size
+        ctxs = (C.c_void_p * n)(*[s._h for s in scorers])
+        offs = (C.c_double * n)(*[float(o) for o in offsets])
+        ptrs = (C.c_void_p * n)(*d_matrix_ptrs)
+        nl = (C.c_uint64 * n)()
+        self._check(load_comm().nps_comm_allgather_scores(self._h, ctxs, offs, ptrs, nl))
+        return np.array(list(nl), dtype=np.uint64)
+
+    def allreduce_partial(self, scorers, offset: float, d_scores_ptrs) -> int:
+        n = self.size
+        ctxs = (C.c_void_p * n)(*[s._h for s in scorers])
+        ptrs = (C.c_void_p * n)(*d_scores_ptrs)
+        nl = C.c_uint64(0)
+        self._check(load_comm().nps_comm_allreduce_partial(self._h, ctxs, float(offset), ptrs, C.byref(nl)))
+        return int(nl.value)
+
+    def allreduce_partial_multi(self, multi_scorers, n_scores: int, n_samples: int, offsets, d_matrix_ptrs) -> np.ndarray:
+        n = self.size
+        ms = (C.c_void_p * n)(*[m._h for m in multi_scorers])
+        offs = (C.c_double * n_scores)(*[float(o) for o in offsets])
+        ptrs = (C.c_void_p * n)(*d_matrix_ptrs)
+        nl = (C.c_uint64 * n_scores)()
+        self._check(load_comm().nps_comm_allreduce_partial_multi(self._h, ms, n_scores, n_samples, offs, ptrs, nl))
+        return np.array(list(nl), dtype=np.uint64)
+
+    def close(self):
+        if self._h:
+            load_comm().nps_comm_destroy(self._h)
+            self._h = None

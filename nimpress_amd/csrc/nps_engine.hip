@@ -14,6 +14,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "nps_kernels.h"
@@ -65,6 +66,7 @@ struct nps_cohort {
     // strip kernel without its arrival count), one per row of every superblock; valid until rows are rewritten
     unsigned long long *d_mx_row_tally = nullptr;
     bool mx_row_tally_valid = false;
+    std::mutex tally_mutex;  // NPS_MODE_AUTO may count them lazily from whichever context scores the cohort first
     // nps_cohort_push_*: rows decoded on the device straight into the cohort (a pinned ring the decode kernel reads
     // over PCIe, on a stream of the cohort's own); every call that reads the cohort waits for it (cohort_quiesce)
     hipStream_t push_stream = nullptr;
@@ -166,6 +168,8 @@ struct nps_ctx {
     uint64_t mx_const_cap = 0;
     unsigned long long *d_mx_tally1 = nullptr;  // first-stage tally words (groups of 16 strips), zero between passes
     uint64_t mx_tally1_cap = 0;
+    uint32_t *d_mx_fix = nullptr;               // nps_mx2.hip: the run's rows over --maxmis (list, any order); its length is
+    uint64_t mx_fix_cap = 0;                    // the word d_timeout[16], zero between passes
     bool mx_plan_valid = false, mx_plan_two_pass = false;
     uint64_t mx_plan_m = 0;
     MxPlan mx_plan_cache{};
@@ -333,6 +337,7 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_mx_cpart);
     (void)hipFree(c->d_mx_const);
     (void)hipFree(c->d_mx_tally1);
+    (void)hipFree(c->d_mx_fix);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -345,7 +350,7 @@ static void free_ctx(nps_ctx *c) {
 
 static int zero_state(nps_ctx *c) {
     // d_part is not touched: chunks_used = 0 makes the first writer overwrite it
-    HIP_TRY(hipMemsetAsync(c->d_nloci, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_nloci, 0, 3 * sizeof(unsigned long long), c->stream));
     if (c->batch_rows)  // tallies of rows decoded into the open batch (the array is zero otherwise)
         HIP_TRY(hipMemsetAsync(c->d_tally, 0, sizeof(unsigned long long) * c->batch_rows, c->stream));
     c->chunks_used = 0;
@@ -427,7 +432,7 @@ extern "C" int nps_create(nps_ctx **out, int device, uint64_t n_samples, const n
         CTX_TRY(hipHostMalloc(&c->h_arena, total));
         char *p = (char *)c->h_arena;
         c->h_result = (unsigned long long *)p;
-        c->h_result[0] = c->h_result[1] = 0;
+        c->h_result[0] = c->h_result[1] = c->h_result[2] = 0;
         p += 4096;
         c->h_desc = (nps_row_desc *)p;
         p += sz_desc;
@@ -471,6 +476,8 @@ extern "C" int nps_reset(nps_ctx *c, const nps_params *params) {
         c->params = *params;
     }
     HIP_TRY(hipSetDevice(c->device));
+    if (c->broken && c->d_timeout)  // a strip-kernel pass that failed half-way may have left its list of rows behind
+        HIP_TRY(hipMemsetAsync(c->d_timeout + 16, 0, sizeof(unsigned int), c->stream));
     // no stream synchronisation: everything below is ordered on the context's stream, and no call
     // returns with a device-to-host copy still in flight
     return zero_state(c);
@@ -847,7 +854,7 @@ extern "C" int nps_push_locus(nps_ctx *c, int kind, int ref_is_effect, double be
 
 // the device's result block (used rows, status bits) -> pinned host copy; the caller synchronises
 static int fetch_result(nps_ctx *c) {
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_nloci, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_nloci, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            c->stream));
     return NPS_OK;
 }
@@ -960,20 +967,14 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     int rc = select_device(device);
     if (rc) return rc;
     if (format == NPS_FMT_GT_AUTO) {
-        // whichever 2-bit layout is scored in ONE read at this cohort size: strips (matrix cores, time independent of the
-        // genotypes) while there is a compute unit per 2048-sample strip, row groups (table lookups; 14 336 samples per
-        // compute unit) beyond that -- on an MI355X up to 522 240 samples and up to about 3.6 million samples
-        // ... and while the strips' grid fills enough of the chip: P strips x Q row teams is P x floor(CUs / P)
-        // workgroups, which leaves 128 < P < 180 (262 144 < N <= 366 592 samples on 256 CUs) with less than seven
-        // tenths of the compute units; the row kernel's 14 336-sample slices have teams to spare there (measured, ms
-        // per 1M rows, strips / rows: 300 000 samples 18.8 / 14.9, 350 000 17.9 / 17.6, 400 000 18.7 / 20.6, 450 000
-        // 21.3 / 23.1)
-        MxPlan mp;
-        HIP_TRY(mx_plan(device, n_samples, std::max<uint64_t>(n_rows, 1 << 20), false, &mp));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        const bool fills = mp.ok && !mp.given && (uint64_t)mp.P * mp.Q * 10 >= (uint64_t)prop.multiProcessorCount * 7;
-        format = (n_samples == 0 || fills) ? NPS_FMT_GT2X : NPS_FMT_GT2;
+        // The strip layout at every size (round 5).  Where the single-read kernel's grid -- P strips x floor(CUs / P) row
+        // teams, all resident -- covers the chip (up to 180 000 samples and 366 593 .. 522 240 on 256 compute units) the
+        // tallies are counted in the pass.  Elsewhere (147 strips at 300 000 samples: 147 of 256 compute units; more
+        // strips than compute units beyond 522 240) nps_score_cohort[_def] under NPS_MODE_AUTO counts the cohort's
+        // tallies ONCE, keeps them with the cohort (nps_cohort_keep_tallies) and scores with the tallies given: an
+        // ordinary grid, one read per pass from then on, time independent of the genotypes.  (Until round 4 such sizes got
+        // the row layout, whose table-lookup kernel runs at 0.47 .. 0.63 of the roofline depending on the genotypes.)
+        format = n_samples < (1ull << 27) ? NPS_FMT_GT2X : NPS_FMT_GT2;
     }
     nps_cohort *c = new (std::nothrow) nps_cohort;
     if (!c) return fail(NPS_E_NOMEM, "out of host memory");
@@ -1578,8 +1579,9 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (co->n_samples != c->n)
         return fail(NPS_E_INVAL, "cohort has %llu samples, context %llu",
                     (unsigned long long)co->n_samples, (unsigned long long)c->n);
-    if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
+    if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED && mode != NPS_MODE_FUSED_EAGER)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
+    if (mode == NPS_MODE_FUSED_EAGER && co->format != NPS_FMT_GT2X) mode = NPS_MODE_FUSED;  // (a strip-kernel variant)
     const uint64_t m = def->m;
     rc = check_range(co, cohort_row0, m);
     if (rc) return rc;
@@ -1595,11 +1597,32 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
-    bool kept_tallies = false;
+    bool kept_tallies = false, use_v2 = false;
     if (is_mx && m && c->n) {
         // a cohort that carries its tallies (nps_cohort_keep_tallies) is scored with them given under NPS_MODE_AUTO: the
         // "two-pass" plan (independent workgroups) without its tally pass
         kept_tallies = co->mx_row_tally_valid && mode == NPS_MODE_AUTO;
+        if (!kept_tallies && mode == NPS_MODE_AUTO) {
+            // does the single-read kernel's resident grid cover the chip at this size?  If not -- or if there are more
+            // strips than compute units -- count the cohort's tallies once and keep them (the cohort's own cache: rewriting
+            // rows drops it); this and every later pass then reads the matrix once with the tallies given
+            MxPlan p1;
+            HIP_TRY(mx_plan(c->device, c->n, m, false, &p1));
+            int cus = 0;
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            const bool covers = p1.ok && !p1.given && (uint64_t)p1.P * p1.Q * 10 >= (uint64_t)cus * 7;
+            // (short runs stay with the in-pass kernel: a tally pass over the whole cohort would cost more than it saves)
+            if (p1.ok && !covers && (p1.given || m >= 16384)) {
+                nps_cohort *mco = const_cast<nps_cohort *>(co);
+                std::lock_guard<std::mutex> lk(mco->tally_mutex);
+                if (!mco->mx_row_tally_valid) {
+                    rc = nps_cohort_keep_tallies(mco);
+                    if (rc) return rc;
+                    HIP_TRY(hipSetDevice(c->device));
+                }
+                kept_tallies = true;
+            }
+        }
         const bool two_pass = mode == NPS_MODE_TWOPASS || kept_tallies;
         if (c->mx_plan_valid && c->mx_plan_m == m && c->mx_plan_two_pass == two_pass) {
             mxp = c->mx_plan_cache;
@@ -1615,7 +1638,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                         (unsigned long long)c->n, (unsigned long long)m);
         // more strips than compute units: the single-read kernel cannot hold the grid resident; AUTO takes the
         // tally + accumulate pair (two reads), an explicit NPS_MODE_FUSED is refused
-        if (mxp.given && mode == NPS_MODE_FUSED)
+        if ((mxp.given && (mode == NPS_MODE_FUSED || mode == NPS_MODE_FUSED_EAGER)) || (mode == NPS_MODE_FUSED_EAGER && !mxp.v2))
             return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the persistent grid of the "
                         "single-read NPS_FMT_GT2X kernel (one 2048-sample strip per compute unit); NPS_MODE_AUTO "
                         "scores it in two reads", (unsigned long long)c->n, (unsigned long long)m);
@@ -1685,6 +1708,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             rc = grow(c, (void **)&c->d_mx_const, &c->mx_const_cap, 8 + 2ull * mxp.Q, sizeof(double));
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double) * c->mx_const_cap, c->stream));
+        }
+        // NPS_MODE_FUSED_EAGER: the second form of the strip kernel (nps_mx2.hip), on request only -- it is not faster
+        // (DESIGN.md 4.2, round 5); a shape it does not take (more strips than compute units) is refused like NPS_MODE_FUSED
+        use_v2 = mode == NPS_MODE_FUSED_EAGER;
+        if (use_v2) {
+            rc = grow(c, (void **)&c->d_mx_fix, &c->mx_fix_cap, m_pad, sizeof(uint32_t));
+            if (rc) return rc;
         }
         const uint64_t need1 = (uint64_t)((mxp.P + 15) / 16) * m_pad;
         if (need1 > c->mx_tally1_cap) {
@@ -1781,12 +1811,20 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                         c->d_rtally));
             }
             hipError_t fe;
+            unsigned int *fix_count = c->d_timeout + 16;  // (zero: context creation, or the memset behind the last fold)
             {
                 ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
-                fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                     runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
-                                     kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally, c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
-                                     const_slots, c->d_mx_cpart, c->d_timeout);
+                if (use_v2)
+                    fe = launch_fused_mx2(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
+                                          c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
+                                          const_slots, c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count);
+                else
+                    fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                         runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
+                                         kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally, c->d_mx_tally1,
+                                         b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
+                                         const_slots, c->d_mx_cpart, c->d_timeout);
             }
             if (fe != hipSuccess) {
                 (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
@@ -1798,8 +1836,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 ProfScope ps(c, P_REDUCE);
                 HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, const_slots, c->d_part,
                                        c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
-                                       (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1));
+                                       (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1,
+                                       use_v2 ? c->d_mx_fix : nullptr, use_v2 ? fix_count : nullptr, co->d_data, c->d_rlut,
+                                       gt2x_superblocks(co->n_rows), cohort_row0 >> 7));
                 HIP_TRY(hipMemsetAsync(const_slots, 0, sizeof(double) * 2 * mxp.Q, c->stream));
+                if (use_v2) HIP_TRY(hipMemsetAsync(fix_count, 0, sizeof(unsigned int), c->stream));
             }
             c->chunks_used = std::max(c->chunks_used, 1u);
             c->rtally_clean = true;
@@ -2388,10 +2429,12 @@ extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint3
     if (format == NPS_FMT_GT2X) {
         MxPlan mp;
         HIP_TRY(mx_plan(c->device, c->n, n_rows, false, &mp));
-        const bool single_read = mp.ok && !mp.given;  // (a shape with more strips than compute units is scored in two reads)
-        if (slices) *slices = single_read ? mp.P : 0;
-        if (teams) *teams = single_read ? mp.Q : 0;
-        if (samples_per_slice) *samples_per_slice = single_read ? 2048 : 0;
+        // (more strips than compute units: the grid of the accumulation with given tallies -- kept with the cohort, or from
+        //  the tally pass; its slices are still the 2048-sample strips)
+        if (mp.ok && mp.given) HIP_TRY(mx_plan(c->device, c->n, n_rows, true, &mp));
+        if (slices) *slices = mp.ok ? mp.P : 0;
+        if (teams) *teams = mp.ok ? mp.Q : 0;
+        if (samples_per_slice) *samples_per_slice = mp.ok ? 2048 : 0;
         return NPS_OK;
     }
     FusedPlan plan;

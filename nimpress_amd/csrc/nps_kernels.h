@@ -273,6 +273,7 @@ struct MxPlan {
     bool ok = false;
     bool given = false;  // the shape does not fit one cooperative grid (more strips than compute units): the row
                          // tallies come from launch_mx_tally, the accumulation runs as an ordinary grid (two reads)
+    bool v2 = false;     // the single-read run may use nps_mx2.hip (code x beta on arrival, is-missing masks parked)
     uint32_t P = 0, Q = 0, nu_last = 0, n_sb = 0, n_flush = 0;  // strips, row teams per strip (superblock k belongs to team k % Q)
     uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
 };
@@ -290,10 +291,25 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
 // plan.given only: the whole-row tallies of the run's rows into d_tally (zero on entry), one read of the matrix
 hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
                            uint64_t n_samples, unsigned long long *d_tally);
+// d_fix_count != nullptr (after launch_fused_mx2): the rows on the list had code x beta accumulated before their tally was
+// known; their products are taken back per sample (exact integers), and d_status[1] receives the list's length
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
-                          unsigned long long *d_status);
+                          unsigned long long *d_status, const uint32_t *d_fix_rows = nullptr,
+                          const unsigned int *d_fix_count = nullptr, const void *d_units = nullptr,
+                          const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0);
+hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
+                          bool sentinels);
+// nps_mx2.hip: the same pass with code x beta accumulated on arrival and only the is-missing masks parked (three steps of
+// slack for the hand-over); never for plan.given; d_fix_rows: n_rows uint32, d_fix_count: one zeroed word
+hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
+                            int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
+                            unsigned long long *d_tally1, nps_locus_stat *d_stats, unsigned long long *d_nloci,
+                            double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
+                            unsigned int *d_fix_count);
+constexpr uint64_t kMx2MaxRows = 0xffffffffull;
 // rows [row0, row0+n_rows) (row0 a multiple of 128) of a cohort of n_rows_cohort rows; rows past the end inside
 // the last superblock written become zero
 hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,

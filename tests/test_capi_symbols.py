@@ -11,8 +11,8 @@ from nimpress_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "nps.h")).read()
+def header_symbols(name="nps.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nps_[a-z_0-9]+)\s*\(", text)))
 
@@ -59,3 +59,21 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f), errors="replace").read()
                 for bad in ("import oracle", "from oracle", "librefcpu", "refcpu.h"):
                     assert bad not in src, (f, bad)
+
+
+def test_comm_library_exports_every_symbol_of_nps_comm_h():
+    """libnps_rccl.so (the RCCL exchange for single-process hosts) loads without a GPU, exports what include/nps_comm.h
+    declares, and libnps.so itself has no RCCL dependency"""
+    import subprocess
+    assert header_symbols("nps_comm.h") == sorted(capi.COMM_SYMBOLS)
+    lib = capi.load_comm()
+    for name in capi.COMM_SYMBOLS:
+        assert hasattr(lib, name), name
+    ldd = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in ldd
+    ldd = subprocess.run(["ldd", capi.COMM_LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in ldd and "libnps.so" in ldd
+    if capi.device_count() == 0:
+        with pytest.raises(capi.NpsError) as ei:
+            capi.Comm(1)
+        assert ei.value.status == capi.E_NODEVICE

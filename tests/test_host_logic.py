@@ -863,3 +863,26 @@ def test_pgen_fixed_width_reader_vs_writer_parity_unpinned(host, tmp_path):
     pgenwriter.write_pgen(str(tmp_path / "m"), names, [("2", 5, "a", "A", "C,G")], alt[:1], miss[:1])
     assert not host.nh_vcf_open(str(tmp_path / "m.pgen").encode(), None)
     assert "multi-allelic" in host.nh_last_error().decode()
+
+
+def test_score_many_shards_rows_by_default_when_the_file_has_a_locus_index(tmp_path):
+    """tools/score_many.py --shard auto (the 8-GPU default must not read the cohort file 8 times):
+    an indexed genotype file -> rows (decided before any GPU is touched; every rank sees the same files), else files"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("score_many", os.path.join(ROOT, "tools", "score_many.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    a = sm.parse_args(["x.scores", "y.scores", "c.bcf"])
+    assert a.shard == "auto" and a.gpus == 1
+    p = str(tmp_path / "c.bcf")
+    open(p, "w").close()
+    assert not sm.has_locus_index(p)
+    open(p + ".csi", "w").close()
+    assert sm.has_locus_index(p)
+    v = str(tmp_path / "c.vcf.gz")
+    open(v + ".tbi", "w").close()
+    assert sm.has_locus_index(v)
+    b = str(tmp_path / "p.bed")
+    assert not sm.has_locus_index(b)
+    open(str(tmp_path / "p.bim"), "w").close()
+    assert sm.has_locus_index(b)

@@ -31,12 +31,15 @@ def parse_args(argv=None):
                     help="this rank's score files in ONE pass over the genotypes: the union of their loci is decoded once "
                          "into a resident cohort and the definitions are applied together on the matrix cores (falls back "
                          "to the per-file loop for inputs that path does not cover, e.g. FORMAT/DS records)")
-    ap.add_argument("--shard", choices=["files", "rows"], default="files",
-                    help="what the GPUs split.  files: each GPU takes every N-th score file (the whole cohort file is read "
-                         "by every GPU).  rows: each GPU takes 1/N of the ROWS of the union of the files' loci and scores "
-                         "ALL files on it in one matrix-core pass -- 1/N of the ingest and of the cohort per GPU -- and one "
-                         "sum all-reduce of the [files, samples] sums and the per-file locus counts follows (implies "
-                         "--one-pass; inputs that path does not cover are an error)")
+    ap.add_argument("--shard", choices=["auto", "files", "rows"], default="auto",
+                    help="what the GPUs split.  files: each GPU takes every N-th score file (BASELINE.json's wording; the whole "
+                         "cohort file is read by every GPU and 697-locus files sit beside 4-locus ones).  rows: each GPU takes "
+                         "1/N of the ROWS of the union of the files' loci and scores ALL files on it in one matrix-core pass -- "
+                         "1/N of the ingest and of the cohort per GPU, equal load -- and one sum all-reduce of the [files, "
+                         "samples] sums and the per-file locus counts follows (implies --one-pass; inputs that path does not "
+                         "cover, e.g. FORMAT/DS records, are an error: pass --shard files).  auto (default): rows when there "
+                         "is more than one GPU and the genotype file can be fetched by locus (.tbi / .csi index, PLINK "
+                         "fileset), files otherwise")
     ap.add_argument("--out", default="-", help="output TSV (default: stdout)")
     ap.add_argument("--timings", action="store_true",
                     help="rank 0 prints one JSON line on stderr saying where the run's time went (imports, HIP context, "
@@ -56,6 +59,18 @@ def parse_args(argv=None):
     if len(a.files) < 2:
         ap.error("need at least one score file and the genotype file")
     return a
+
+
+def has_locus_index(path):
+    """the genotype file can be fetched locus by locus (every rank reads its block of rows only)"""
+    if any(os.path.exists(path + ext) for ext in (".tbi", ".csi")):
+        return True
+    stem, ext = os.path.splitext(path)
+    if ext == ".bed":
+        return os.path.exists(stem + ".bim")
+    if ext == ".pgen":
+        return os.path.exists(stem + ".pvar") or os.path.exists(stem + ".bim")
+    return False
 
 
 def spawn_ranks(n, timeout_s):
@@ -109,6 +124,8 @@ def main(argv=None):
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(local_rank)
     score_files, cohort = args.files[:-1], args.files[-1]
+    if args.shard == "auto":   # (every rank sees the same files: the same choice)
+        args.shard = "rows" if world > 1 and not args.one_pass and has_locus_index(cohort) else "files"
     names = host.sample_names(cohort)
     n = len(names)
     S = len(score_files)
