@@ -399,7 +399,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
             x_look = 0ull;
             if (k < n_t && row < a.n_rows)  // (an agent-scope relaxed load, as ctl_word's)
-                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(x_look) : "v"(&a.tally[row]) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(x_look) : "v"(&a.tally[row]) : "memory");  // ("+v": the load writes the pair the zeroed x_look already lives in -- no merge copy behind it)
         }
         if (is_ctl && !kUnder) ctl_tables(k);  // (given tallies: plain loads)
         MXT(0);
@@ -410,10 +410,13 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             asm volatile("" : : "v"(px.w1d), "v"(px.w3), "v"(px.w4));
             // the wave's loads return in order: once at most the NU loads front() issued after the look are
             // outstanding, the look has returned (whatever else -- an add of the last step -- is still under way)
-            if (k + 3 < n_t && n_my == NU)
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x_look) : "n"(NU) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_look) : : "memory");
+            // ONE statement holds both counts.  With a wait statement per branch (until round 5) the compiler placed a copy
+            // of x_look IN FRONT of the vmcnt(0) one -- a read of a register pair whose data might not have arrived, on
+            // the last steps of a pass and on ragged strips; tests/test_isa_checks.py found it and now guards the window.
+            asm volatile("s_cmp_lg_u32 %1, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(%2)\n2:"
+                         : "+v"(x_look)
+                         : "s"(__builtin_amdgcn_readfirstlane((k + 3 < n_t && n_my == NU) ? 1 : 0)), "n"(NU)
+                         : "scc", "memory");
             MXT(6);
             ctl_tables(k, true, x_look);
         }
@@ -522,37 +525,47 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
     const uint64_t strip = i >> 11;
     const uint32_t unit = (uint32_t)(i >> 5) & 63u, s = (uint32_t)i & 31u;
     const uint32_t e = s & 1u, ii = s >> 1;
-    double total = 0.0;
+    // The sixteen digit sums of a sample are exact integers (float32 below 2^24); they are recombined as exact integers too:
+    // value = hi 2^28 + lo with the seven low hexadecimal digits in lo, the seven high ones in hi (each below 2^52 per
+    // flush), summed over teams and flushes in int64, and rounded to float64 ONCE.  (Until round 5: Horner in float64 per
+    // flush, then a float64 sum -- 1 ulp of the largest partial sum per step.  Exact sums make the result independent of
+    // how the rows were split into teams -- kept tallies, two reads and the single read now give the same bits -- and let
+    // the rows taken back below cancel to exactly zero.)
+    long long hi = 0, lo = 0;
     bool isnan_ = false;
-    for (uint32_t tm = 0; tm < Q && tm < n_sb; ++tm) {  // fixed order: teams, then flushes
+    for (uint32_t tm = 0; tm < Q && tm < n_sb; ++tm) {
         const uint32_t n_flush = ((n_sb - tm + Q - 1) / Q + kFlushSb - 1) / kFlushSb;
         for (uint32_t f = 0; f < n_flush; ++f) {
             const float *t =
                 cpart + (((((uint64_t)f * Q + tm) * P + strip) * 64 + unit) * 2 + e) * 256 + ((ii >> 2) * 16) * 4 + (ii & 3);
-            double v = (double)t[13 * 4];
+            long long l = 0, h = 0;
 #pragma unroll
-            for (int d = 12; d >= 0; --d) v = v * 16.0 + (double)t[d * 4];
-            total += v;
+            for (int d = 0; d < 7; ++d) {
+                l += (long long)t[d * 4] * (1ll << (4 * d));
+                h += (long long)t[(d + 7) * 4] * (1ll << (4 * d));
+            }
+            lo += l;
+            hi += h;
             isnan_ = isnan_ || t[15 * 4] != 0.f;
         }
     }
     if (fix.count) {
         const unsigned int n_fix = *fix.count;
-        if (i == 0) status[1] = n_fix;  // (the host reads it with the result block: how many rows of this pass were over --maxmis)
+        if (i == 0) status[1] = n_fix;  // (how many rows of this pass were over --maxmis)
         const uint32_t nu = strip == P - 1 ? fix.nu_last : 64u;
         const unsigned long long *ubase = fix.units + (strip * 64 * fix.n_sb_cohort * 64 + unit * 64) * 2;  // (in 8-byte rows)
-        long long hi = 0, lo = 0;  // sum of value x w1 with w1 = h 2^28 + l: |h| < 2^28, 0 <= l < 2^28, value <= 4
+        // sum of value x w1 with w1 = h 2^28 + l: |h| < 2^28, 0 <= l < 2^28, value <= 4 -- the same split as above
         for (unsigned int j = 0; j < n_fix; ++j) {
             const uint32_t row = fix.rows[j];
             const unsigned long long w = ubase[((uint64_t)(fix.sb0 + (row >> 7)) * nu * 64) * 2 + (row & 127u)];
             const uint32_t code = (uint32_t)(w >> (2 * s)) & 3u;
             const long long v = (long long)((s & 1u) && code == 3u ? 4u : code);  // (odd sample of a pair: 0, 1, 2, 4)
             const long long w1r = fix.pre[row].w1, w1 = w1r == kMxDeadW1 ? 0 : w1r;  // (a non-finite beta has no digits)
-            hi += v * (w1 >> 28);
-            lo += v * (w1 & 0xFFFFFFFll);
+            hi -= v * (w1 >> 28);
+            lo -= v * (w1 & 0xFFFFFFFll);
         }
-        total -= (double)hi * 268435456.0 + (double)lo;
     }
+    const double total = (double)hi * 268435456.0 + (double)lo;
     double r = total * inv_scale + s_const;
     if (isnan_) r = __longlong_as_double(0x7ff8000000000000ll);
     part0[i] = overwrite ? r : part0[i] + r;

@@ -534,7 +534,7 @@ def test_gt2x_eager_all_imputation_modes(pk):
     rng = np.random.default_rng(1900 + pk)
     co = make_cohort(n, m, 97 + pk, rng)
     co["eaf"][5] = np.nan                      # ps imputes NaN for this row
-    co["beta"][9] = np.inf                     # a non-finite beta: every sample's sum is NaN, as in the reference
+    co["beta"][9] = np.nan                     # a NaN beta: every sample's sum is NaN, as in the reference (d * NaN)
     dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
     dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
     descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])

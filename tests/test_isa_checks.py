@@ -1,0 +1,97 @@
+"""Build-time guards for the two hand-timed memory operations of the strip kernels: a load or
+returning atomic issued through inline asm writes its destination registers LATER, when the hand-written `s_waitcnt vmcnt`
+has passed -- the compiler believes they are ready at once.  If it ever copies, spills or otherwise touches those
+registers between the two statements, the kernel computes from stale data and no build error says so (in round 5 a
+compiler-placed `v_mov` in front of one of two per-branch wait statements did exactly that to nps_mx2.hip's first draft;
+the parity tests caught it as a timeout, this test would have named the line).
+
+The check compiles the two kernels' device code to assembly (hipcc cross-compiles without a GPU) and, for every such
+operation, walks the text up to the first hand-written vmcnt wait that follows: no instruction in between may name the
+destination registers.  (Text order, not control flow: sufficient -- a window with no mention at all cannot contain a
+misplaced copy on any path -- and cheap.)"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nimpress_amd", "csrc")
+
+
+def device_asm(src, tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-parameter",
+                        "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().splitlines()
+
+
+def vgprs(text):
+    """every VGPR a line names: v7, v[4:5] -> {7}, {4, 5}"""
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", text):
+        regs.add(int(a))
+    return regs
+
+
+def check_windows(lines, issue_re, what):
+    """for every asm-issued operation matching issue_re: its destination registers are not named again before the next
+    hand-written (inside an ASM block) vmcnt wait; returns the number of operations checked"""
+    in_asm, n = False, 0
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        m = issue_re.search(ln) if in_asm else None
+        if m:
+            dest = vgprs(m.group(1))
+            assert dest, ln
+            j, asm_j, found = i + 1, True, False
+            while j < len(lines):
+                t = lines[j]
+                if "#ASMSTART" in t:
+                    asm_j = True
+                elif "#ASMEND" in t:
+                    asm_j = False
+                elif t.strip().startswith(".Lfunc_end") or t.strip().startswith(".section"):
+                    break
+                elif asm_j and re.search(r"s_waitcnt\s+vmcnt\(", t):
+                    found = True
+                    break
+                else:
+                    code = t.split(";")[0]
+                    hit = dest & vgprs(code)
+                    assert not hit, ("%s: line %d touches v%s between the asm-issued operation at line %d (%s) and its "
+                                     "hand-written wait:\n%s" % (what, j + 1, sorted(hit), i + 1, ln.strip(), t))
+                j += 1
+            assert found, "%s: no hand-written vmcnt wait follows line %d (%s)" % (what, i + 1, ln.strip())
+            n += 1
+        i += 1
+    return n
+
+
+def test_mx_look_registers_untouched_until_the_hand_written_wait(tmp_path):
+    """nps_mx.hip: the control waves' look at the row tally words (`global_load_dwordx2 ... sc1` in inline asm)"""
+    lines = device_asm(os.path.join(CSRC, "nps_mx.hip"), tmp_path)
+    n = check_windows(lines, re.compile(r"global_load_dwordx2\s+(v\[\d+:\d+\]),.*\bsc1\b"), "nps_mx.hip look")
+    assert n >= 2   # (two control-wave bodies -- full and ragged strips -- per instantiated kernel)
+
+
+def test_mx2_returning_add_registers_untouched_until_the_hand_written_wait(tmp_path):
+    """nps_mx2.hip: the returning add of the publication (`global_atomic_add_x2 ... sc0` in inline asm); its looks and
+    table fetches are LDS-DMA and have no register destination at all"""
+    lines = device_asm(os.path.join(CSRC, "nps_mx2.hip"), tmp_path)
+    n = check_windows(lines, re.compile(r"global_atomic_add_x2\s+(v\[\d+:\d+\]),.*\bsc0\b"), "nps_mx2.hip returning add")
+    assert n >= 2
+    text = "\n".join(lines)
+    assert "global_load_lds_dwordx4" in text and not re.search(r"global_load_dwordx2\s+v\[\d+:\d+\],.*\bsc1\b.*\n\s*;;#ASMEND", text)
