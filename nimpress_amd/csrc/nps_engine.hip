@@ -170,6 +170,10 @@ struct nps_ctx {
     uint64_t mx_tally1_cap = 0;
     uint32_t *d_mx_fix = nullptr;               // nps_mx2.hip: the run's rows over --maxmis (list, any order); its length is
     uint64_t mx_fix_cap = 0;                    // the word d_timeout[16], zero between passes
+    void *d_mx_ops = nullptr;                   // nps_mxg.hip (tallies given): 48 bytes of weight operands per row ...
+    uint64_t mx_ops_cap = 0;                    // (in units of 48 bytes)
+    double *d_mx_cblk = nullptr;                // ... and one partial sum of locus constants per superblock
+    uint64_t mx_cblk_cap = 0;
     bool mx_plan_valid = false, mx_plan_two_pass = false;
     uint64_t mx_plan_m = 0;
     MxPlan mx_plan_cache{};
@@ -338,6 +342,8 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_mx_const);
     (void)hipFree(c->d_mx_tally1);
     (void)hipFree(c->d_mx_fix);
+    (void)hipFree(c->d_mx_ops);
+    (void)hipFree(c->d_mx_cblk);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
     (void)hipFree(c->d_rstats);
@@ -1716,6 +1722,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             rc = grow(c, (void **)&c->d_mx_fix, &c->mx_fix_cap, m_pad, sizeof(uint32_t));
             if (rc) return rc;
         }
+        if (mxp.given) {
+            rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);
+            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_cblk, &c->mx_cblk_cap, m_pad / 128, sizeof(double));
+            if (rc) return rc;
+        }
         const uint64_t need1 = (uint64_t)((mxp.P + 15) / 16) * m_pad;
         if (need1 > c->mx_tally1_cap) {
             rc = grow(c, (void **)&c->d_mx_tally1, &c->mx_tally1_cap, need1, sizeof(unsigned long long));
@@ -1814,7 +1825,13 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             unsigned int *fix_count = c->d_timeout + 16;  // (zero: context creation, or the memset behind the last fold)
             {
                 ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
-                if (use_v2)
+                if (mxp.given)
+                    fe = launch_mx_given(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                         runs[b].d_desc, dev_params(c->params), t_maxmis, F,
+                                         kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally,
+                                         b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci, const_slots,
+                                         c->d_mx_cpart, c->d_mx_ops, c->d_mx_cblk, c->d_timeout + 17);
+                else if (use_v2)
                     fe = launch_fused_mx2(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                           runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
                                           c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,

@@ -310,6 +310,14 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
                             double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
                             unsigned int *d_fix_count);
 constexpr uint64_t kMx2MaxRows = 0xffffffffull;
+// nps_mxg.hip: the run with its row tallies GIVEN (plan.given: kept with the cohort, or from launch_mx_tally): per-row
+// decisions + operands, then an ordinary grid of P x Q workgroups.  d_ops: 48 bytes per row padded to 128 rows;
+// d_const_part: one double per superblock; d_done: one zeroed word (zero again afterwards); d_const_sum as for launch_fused_mx
+hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
+                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
+                           int64_t t_maxmis, int F, const unsigned long long *d_tally, nps_locus_stat *d_stats,
+                           unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, void *d_ops,
+                           double *d_const_part, unsigned int *d_done);
 // rows [row0, row0+n_rows) (row0 a multiple of 128) of a cohort of n_rows_cohort rows; rows past the end inside
 // the last superblock written become zero
 hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,

@@ -796,7 +796,26 @@ hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pas
     // compute units (N > 2048 x CUs): the tallies come from their own pass and the accumulation runs as an ordinary
     // grid of P x Q independent workgroups, about four per compute unit for an even tail.
     plan->given = two_pass || gm.P > (uint32_t)cus || gm.P > 255;
-    uint64_t q = plan->given ? std::max<uint64_t>(1, ((uint64_t)4 * cus + gm.P - 1) / gm.P) : (uint64_t)cus / gm.P;
+    uint64_t q = (uint64_t)cus / gm.P;
+    if (plan->given) {
+        // independent workgroups, one resident per compute unit at a time: P x Q of them run in ceil(P Q / CUs) rounds.
+        // Of the team counts that give between two and eight rounds, the one whose last round is fullest (147 strips:
+        // Q = 7 would be 1029 workgroups = four rounds and five stragglers; Q = 12 is 1764 = seven rounds, 98 % full)
+        const uint64_t lo = std::max<uint64_t>(1, ((uint64_t)2 * cus + gm.P - 1) / gm.P), hi = std::max<uint64_t>(lo, (uint64_t)8 * cus / gm.P);
+        double best = -1.0;
+        q = lo;
+        for (uint64_t t = lo; t <= hi; ++t) {
+            const uint64_t wg = (uint64_t)gm.P * t, rounds = (wg + cus - 1) / cus;
+            const double fill = (double)wg / (double)(rounds * cus);
+            if (fill > best + 1e-9) {
+                best = fill;
+                q = t;
+            }
+        }
+#ifdef NPS_DIAGNOSTICS
+        if (getenv("NPS_MXG_Q")) q = (uint64_t)std::max(1, atoi(getenv("NPS_MXG_Q")));
+#endif
+    }
     q = std::max<uint64_t>(1, std::min<uint64_t>(q, gm.n_sb));
     plan->Q = (uint32_t)q;
     const uint64_t n_t = (gm.n_sb + q - 1) / q;  // superblocks of the longest team
