@@ -101,8 +101,8 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run
 def spawn_ranks(n, timeout_s):
-    """Start the N rank processes (this process never touches a GPU), wait for them with a deadline, pass on the highest
-    exit code (nimpress_amd/launch.py; importing it loads no GPU library)."""
+    """Start the N rank processes (this process never touches a GPU), wait for them with a deadline, pass on the first
+    failing rank's exit code (nimpress_amd/launch.py; importing it loads no GPU library)."""
     sys.path.insert(0, ROOT)
     import importlib.util
     spec = importlib.util.spec_from_file_location("nps_launch", os.path.join(ROOT, "nimpress_amd", "launch.py"))

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <limits>
 #include <sstream>
@@ -43,28 +44,34 @@ struct Tick {  // adds the scope's wall time to one of the Timings fields
 static std::mutex g_warm_mutex;
 static std::thread g_warm_thread;
 static std::thread::id g_warm_owner;
-static double g_warm_seconds = 0.0;
+// the warm-up thread's elapsed time travels WITH the thread object: each launch has its own slot, moved out together with
+// the thread by the one caller that joins it (a shared global was written by a new launch while the previous joiner still
+// read it: ADVICE round 4)
+static std::shared_ptr<double> g_warm_seconds;
 void warmupStart(int device) {
     std::lock_guard<std::mutex> lock(g_warm_mutex);
     if (g_warm_thread.joinable()) return;
-    g_warm_seconds = 0.0;
+    auto slot = std::make_shared<double>(0.0);
+    g_warm_seconds = slot;
     g_warm_owner = std::this_thread::get_id();
-    g_warm_thread = std::thread([device]() {
+    g_warm_thread = std::thread([device, slot]() {
         const double t0 = nowSeconds();
         (void)nps_warmup(device);  // (an error shows up again, with its message, in the run's first libnps call)
-        g_warm_seconds = nowSeconds() - t0;
+        *slot = nowSeconds() - t0;  // (read only after join())
     });
 }
 void warmupJoin() {
     std::thread t;
+    std::shared_ptr<double> slot;
     {
         std::lock_guard<std::mutex> lock(g_warm_mutex);
         if (!g_warm_thread.joinable() || g_warm_owner != std::this_thread::get_id()) return;
         t = std::move(g_warm_thread);
+        slot = std::move(g_warm_seconds);
     }
     Tick tick(g_timings.hip_init_wait);
     t.join();
-    g_timings.hip_init += g_warm_seconds;
+    if (slot) g_timings.hip_init += *slot;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -411,8 +418,7 @@ static bool parseRecordLine(const char *L, size_t len, size_t ns, const RegionMa
             v.has_gt = false;
             v.has_ds = true;
             // two sweeps over the sample columns, no allocation per genotype: the widest value list decides the
-            // stride (Number=1 or Number=A), then every value is parsed where it lies and checked against the
-            // range of a dosage, 0 <= DS <= 2 (what the single-read DS kernel's fixed-point tallies rely on)
+            // stride (Number=1 or Number=A), then every value is parsed where it lies
             const char *const s_first = col[9];
             auto subfield = [&](const char *s0, const char *&g0, const char *&g1) -> const char * {
                 const char *t = s0;
@@ -464,8 +470,11 @@ static bool parseRecordLine(const char *L, size_t len, size_t ns, const RegionMa
                         char *ep = nullptr;
                         const float f = strtof(buf, &ep);
                         if (!ep || *ep) throw std::runtime_error(std::string("bad FORMAT/DS value '") + buf + "'");
-                        if (f == f && !(f >= 0.0f && f <= 2.0f))
-                            throw std::runtime_error(std::string("FORMAT/DS value ") + buf + " outside [0, 2] at " + v.contig +
+                        // (a dosage is 0 <= DS <= 2, but the streamed nps_push_ds rows this reader feeds take any finite
+                        //  value, and nps_cohort_upload itself marks rows outside the range for the resident single-read
+                        //  kernel: only what no kernel can score -- an infinity -- is refused here.  ADVICE round 4.)
+                        if (f == f && !(std::fabs(f) <= 3.0e38f))
+                            throw std::runtime_error(std::string("FORMAT/DS value ") + buf + " is not finite at " + v.contig +
                                                      ":" + field(1));
                         dst[k] = f;
                     }
@@ -1004,9 +1013,9 @@ static bool parseBcfRecord(const unsigned char *shared, size_t l_shared, const u
         v.ds_per_sample = (int)ds_len;
         v.ds.resize((size_t)ds_len * n_sample);
         memcpy(v.ds.data(), ds_ptr, ds_bytes);
-        for (const float x : v.ds)  // a dosage is 0 <= DS <= 2 (NaN patterns = missing / end of vector)
-            if (x == x && !(x >= 0.0f && x <= 2.0f))
-                throw std::runtime_error("FORMAT/DS value " + std::to_string(x) + " outside [0, 2] at " + v.contig + ":" +
+        for (const float x : v.ds)  // (NaN patterns = missing / end of vector; any finite value is scored: see the text reader)
+            if (x == x && !(std::fabs(x) <= 3.0e38f))
+                throw std::runtime_error("FORMAT/DS value " + std::to_string(x) + " is not finite at " + v.contig + ":" +
                                          std::to_string(v.pos));
         v.has_gt = false;
         v.gt_raw.clear();
@@ -1405,6 +1414,7 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
                 const std::vector<std::string> c = fields(ln);
                 if (c.empty()) continue;
                 if (pvar && c[0].size() >= 2 && c[0][0] == '#' && c[0][1] == '#') continue;
+                if (pvar && c[0][0] == '#' && c[0] != "#CHROM") continue;  // (any other comment line: not a record)
                 if (pvar && c[0] == "#CHROM") {
                     col_chrom = 0;
                     col_id = col_pos = col_alt = col_ref = -1;
@@ -1454,6 +1464,20 @@ bool VCF::open(const std::string &path, const std::vector<ScoreEntry> *keep) {
                     records.push_back(std::move(v));
                 }
                 ++row;
+            }
+            if (pgen) {
+                // the records are mapped to rows by line index alone: a .pvar that does not belong to this .pgen would be
+                // scored with another variant's genotypes, silently.  The header's variant count and the file's length
+                // must both agree with what was read.
+                if (row != pgen_m)
+                    throw std::runtime_error(".pgen header says " + std::to_string(pgen_m) + " variants, " + prefix +
+                                             (pvar ? ".pvar" : ".bim") + " lists " + std::to_string(row));
+                if (fseeko(f, 0, SEEK_END) != 0) throw std::runtime_error("cannot seek in the .pgen file");
+                const off_t size = ftello(f);
+                if ((uint64_t)size != (uint64_t)header_bytes + (uint64_t)pgen_m * row_bytes)
+                    throw std::runtime_error(".pgen file is " + std::to_string((long long)size) + " bytes, " +
+                                             std::to_string(pgen_m) + " fixed-width records of " + std::to_string(samples.size()) +
+                                             " samples are " + std::to_string((unsigned long long)header_bytes + (unsigned long long)pgen_m * row_bytes));
             }
             return true;
         }

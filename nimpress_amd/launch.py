@@ -13,7 +13,8 @@ import time
 
 def spawn_ranks(script, argv, n, timeout_s, name=None, inherit_stderr=False):
     """Start ranks 0..n-1 of `script argv` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
-    the environment), wait for them, exit with the highest exit code.  Rank 0 inherits stdout and stderr, so its
+    the environment), wait for them, exit with the status of the FIRST rank that failed (128 + s for a rank killed by
+    signal s; 0 if none did).  Rank 0 inherits stdout and stderr, so its
     output is this command's output.  The other ranks' stderr goes to a file each, replayed with a rank prefix when a
     rank fails or the run times out.  A rank that dies takes the others with it (they would wait in a collective for
     ever); a run that exceeds `timeout_s` is killed as a whole and exits with status 124.  inherit_stderr: every
@@ -32,6 +33,7 @@ def spawn_ranks(script, argv, n, timeout_s, name=None, inherit_stderr=False):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL, stderr=ef))
     rc = 0
+    terminated = []   # ranks this launcher stopped because another rank had failed
     deadline = time.monotonic() + timeout_s
     try:
         pending = list(procs)
@@ -42,9 +44,14 @@ def spawn_ranks(script, argv, n, timeout_s, name=None, inherit_stderr=False):
                     continue
                 pending.remove(p)
                 if code != 0:
-                    rc = rc or code
+                    # the FIRST rank that fails decides the exit status (the ranks terminated because of it end with
+                    # -SIGTERM and are not failures of their own); a rank killed by signal s reports 128 + s, as a shell does
+                    if p not in terminated:
+                        rc = rc or (128 - code if code < 0 else code)
                     for q in pending:
-                        q.terminate()
+                        if q not in terminated:
+                            terminated.append(q)
+                            q.terminate()
             if pending and time.monotonic() > deadline:
                 sys.stderr.write("%s: %d rank(s) still running after %.0f s: killing the run\n" % (name, len(pending), timeout_s))
                 rc = rc or 124
@@ -62,5 +69,6 @@ def spawn_ranks(script, argv, n, timeout_s, name=None, inherit_stderr=False):
                     ef.seek(0)
                     tail = ef.read()[-4000:]
                     if tail.strip():
-                        sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in tail.splitlines()))
+                        tag = "rank %d, stopped after another rank failed" % r if procs[r] in terminated else "rank %d" % r
+                        sys.stderr.write("".join("[%s] %s\n" % (tag, l) for l in tail.splitlines()))
     sys.exit(rc)

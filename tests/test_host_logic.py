@@ -227,14 +227,17 @@ def test_format_ds_rows_match_oracle(host, tmp_path, monkeypatch, prefer, kind):
 
 
 @pytest.mark.parametrize("kind", ["text", "bcf"])
-def test_format_ds_outside_the_dosage_range_is_refused(host, tmp_path, kind):
-    """a dosage is 0 <= DS <= 2 (the single-read DS kernel's fixed-point tallies rely on it): a record that is scored
-    from DS and holds a value outside is refused when it is read, naming the record; the same value in a DS that is
-    NOT used (the record has GT, NIMPRESS_FORMAT unset) is not even looked at"""
+def test_format_ds_outside_the_dosage_range_is_read_and_infinities_are_refused(host, tmp_path, kind):
+    """a dosage is 0 <= DS <= 2, but the readers do not police it (the streamed nps_push_ds rows they feed
+    take any finite value; nps_cohort_upload marks rows outside the range for the resident single-read kernel itself): a
+    record scored from DS that holds 2.5 opens and is handed out as it is.  Only a value no kernel can score -- an
+    infinity -- is refused when it is read, naming the record; a DS that is NOT used (the record has GT, NIMPRESS_FORMAT
+    unset) is not even looked at"""
     import bcfwriter
-    bad = DS_VCF.replace("0.25\t.\t2\t1.5", "0.25\t.\t2.5\t1.5")             # the DS-only record 1:200
-    unused = DS_VCF.replace("0/1:1.004", "0/1:7.5")                              # 1:100 has GT: its DS is not used
-    for name, text, ok in (("bad", bad, False), ("unused", unused, True)):
+    wide = DS_VCF.replace("0.25\t.\t2\t1.5", "0.25\t.\t2.5\t1.5")            # the DS-only record 1:200
+    bad = DS_VCF.replace("0.25\t.\t2\t1.5", "0.25\t.\tinf\t1.5")
+    unused = DS_VCF.replace("0/1:1.004", "0/1:inf")                              # 1:100 has GT: its DS is not used
+    for name, text, ok in (("wide", wide, True), ("bad", bad, False), ("unused", unused, True)):
         vpath = str(tmp_path / (name + ".vcf"))
         open(vpath, "w").write(text)
         path = vpath
@@ -254,7 +257,7 @@ def test_format_ds_outside_the_dosage_range_is_refused(host, tmp_path, kind):
         else:
             assert not h
             msg = host.nh_last_error().decode()
-            assert "outside [0, 2]" in msg and "1:200" in msg, msg
+            assert "not finite" in msg and "1:200" in msg, msg
 
 
 def test_vcf_reader_plain_text_phased_haploid(host, tmp_path):
@@ -767,7 +770,7 @@ def test_ingest_under_sanitizers(tmp_path, san):
     assert outs[0] == outs[1]
     # round 4: the PLINK 2 fixed-width .pgen reader and the in-place FORMAT/DS text parser under the same sanitizers, on
     # good files and on files they must refuse (truncated records, a header that lies about the samples, a .pvar line with
-    # too few columns, a dosage outside [0, 2], an over-long number): a message and status 5, never a report
+    # too few columns, an infinite dosage, an over-long number): a message and status 5, never a report
     import pgenwriter
     m = 40
     variants = [("1", 1000 + 37 * j, "v%d" % j, "A", "G") for j in range(m)]
@@ -798,6 +801,17 @@ def test_ingest_under_sanitizers(tmp_path, san):
     shutil.copy(str(tmp_path / "p.psam"), str(tmp_path / "cols.psam"))
     open(str(tmp_path / "cols.pvar"), "w").write("#CHROM\tPOS\tID\tREF\tALT\n1\t1000\tv0\n")
     assert "refused" in drive(str(tmp_path / "cols.pgen"), 5)
+    # a .pvar that does not belong to the .pgen (one record fewer / one more than the header's count), or a
+    # .pgen with bytes behind its last record, is refused instead of being scored with another variant's genotypes; a
+    # comment line in the .pvar other than '##...' and '#CHROM' is not a record
+    pv = open(str(tmp_path / "p.pvar")).read().splitlines()
+    for name, lines, data, rc in (("fewer", pv[:-1], raw, 5), ("more", pv + [pv[-1].replace("v39", "v40")], raw, 5),
+                                  ("tail", pv, raw + b"\0", 5), ("note", pv[:1] + ["#a note\tnot\ta\trecord\tat\tall"] + pv[1:], raw, 0)):
+        shutil.copy(str(tmp_path / "p.psam"), str(tmp_path / (name + ".psam")))
+        open(str(tmp_path / (name + ".pvar")), "w").write("\n".join(lines) + "\n")
+        open(str(tmp_path / (name + ".pgen")), "wb").write(data)
+        o = drive(str(tmp_path / (name + ".pgen")), rc)
+        assert ("refused" in o) == (rc == 5), (name, o[-300:])
     head = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples[:50])]
 
     def ds_vcf(name, cell):
@@ -813,7 +827,8 @@ def test_ingest_under_sanitizers(tmp_path, san):
         open(p, "w").write("\n".join(lines) + "\n")
         return p
     assert "refused" not in drive(ds_vcf("ds_ok", None), 0)
-    assert "outside [0, 2]" in drive(ds_vcf("ds_range", "2.25"), 5)
+    assert "refused" not in drive(ds_vcf("ds_range", "2.25"), 0)        # outside [0, 2]: read (the streamed rows take it)
+    assert "not finite" in drive(ds_vcf("ds_inf", "inf"), 5)
     assert "refused" in drive(ds_vcf("ds_junk", "1.5x"), 5)
     assert "refused" in drive(ds_vcf("ds_long", "0." + "1" * 80), 5)
 
