@@ -33,11 +33,27 @@
 
 namespace nps {
 
+// Seven data waves x nine units, ONE control wave with the strip's 64th unit and the per-row work of all 128 rows of a
+// superblock (two rows per lane).  With two control waves of five units each (the first draft, nps_mx.hip's split) the
+// control waves' own unit loads were in the way of every hand-timed wait: memory returns in order, the compiler counts
+// only the operations it knows, and the wave that sets the step's pace stalled for its own refills twice per step
+// (profiles/r05_mx2_timers.txt).  A control wave with one unit has one load in flight.
+#ifndef NPS_MX2_DW   // (6 x 10 + two control waves of 2 units: 25.3 ms but six spilled VGPRs and wrong NaN flags -- not shipped)
+#define NPS_MX2_DW 7
+#define NPS_MX2_UD 9
+#endif
+constexpr int k2DW = NPS_MX2_DW;                          // data waves 0..k2DW-1
+constexpr int k2UD = NPS_MX2_UD;                          // units of a data wave
+constexpr int k2NC = 8 - k2DW;                            // control waves (waves k2DW..7)
+constexpr int k2UC = (64 - k2DW * k2UD) / k2NC;           // units of a control wave
+constexpr int k2Threads = 512;
+constexpr int k2RPL = 2 / k2NC;                           // rows of a superblock per lane of a control wave
+static_assert((k2NC == 1 || k2NC == 2) && k2DW * k2UD + k2NC * k2UC == 64 && k2UC >= 1, "units of a strip");
 constexpr int k2R = 4;                                    // ring slots of parked is-missing masks
 constexpr int k2L = k2R - 1;                              // steps between a superblock's arrival and its is-missing part
 constexpr uint32_t k2Ring = 0;                            // [k2R][64 units][64 lanes x 8 bytes]
 constexpr uint32_t k2Trans = k2R * 32768u;                // [waves][2 units][1 KiB]: the code image on its way to the transposed read
-constexpr uint32_t k2Bc = k2Trans + (kDW + 2) * 2048u;    // [2][128 rows][16 bytes]: beta digits
+constexpr uint32_t k2Bc = k2Trans + (k2DW + 1) * 2048u;    // [2][128 rows][16 bytes]: beta digits
 constexpr uint32_t k2Bm = k2Bc + 2 * 2048u;               // [2][even / odd operand][128 rows][16 bytes]: is-missing weights
 constexpr uint32_t k2Tally = k2Bm + 2 * 4096u;            // [2][128] uint32: nmissing << 16 | neffect of the strip
 constexpr uint32_t k2Pre = k2Tally + 1024u;               // [128 rows][16 bytes]: (w1, wfb) of the rows whose operands are made next (LDS-DMA)
@@ -92,10 +108,8 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
     if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL && !(DBG & 128);  // (DBG 128: no control work at all -- the data path's ceiling)
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave < kBig ? wave * kUD
-                   : wave < kDW ? kBig * kUD + (wave - kBig) * kUD2
-                                : kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
-    const int crow = lane + 64 * (wave - kDW);  // control waves: the row of the superblock this lane works for
+    const int u0 = wave < k2DW ? wave * k2UD : k2DW * k2UD + (wave - k2DW) * k2UC;
+    const int cw = wave - k2DW;  // control waves: 0 .. k2NC-1; rows lane + 64 (cw k2RPL + h), h < k2RPL
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
 
@@ -236,27 +250,33 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         }
     };
 
-    // ---- control state (waves kDW, kDW + 1: 64 rows of every superblock each) --------------------------------------
+    // ---- control state (wave k2DW: all 128 rows of every superblock, rows lane and lane + 64) ------------------------
     uint32_t nloci_local = 0;
     double cst_local = 0.0;
     bool timed_out = false;
-    const int cw = wave - kDW;  // 0 / 1
-    auto row_of = [&](uint32_t k) -> uint64_t { return ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow; };
-    const uint32_t lds_bc = (uint32_t)(uintptr_t)(smem + k2Bc) + (uint32_t)cw * 1024u;      // + (k & 1) * 2048
-    const uint32_t lds_pre = (uint32_t)(uintptr_t)(smem + k2Pre) + (uint32_t)cw * 1024u;
-    const uint32_t lds_look = (uint32_t)(uintptr_t)(smem + k2Look) + (uint32_t)cw * 512u;
-    // the beta digits of this wave's 64 rows of superblock k -> table buffer k & 1 (the first 16 bytes of a row's MxPre:
-    // twelve bytes of FP6 digits, then the flags word, which the transposed 96-bit reads never see)
-    auto ctl_dma_bc = [&](uint32_t k) { mx2_dma16(a.pre + row_of(k), lds_bc + (k & 1u) * 2048u, false); };
-    // ... (w1, wfb) of the rows of superblock j, and the look at their tally words (lanes 0..31: two words each)
+    auto sb_row0 = [&](uint32_t k) -> uint64_t { return ((uint64_t)team + (uint64_t)k * a.Q) * 128; };
+    const uint32_t lds_bc = (uint32_t)(uintptr_t)(smem + k2Bc);      // + (k & 1) * 2048
+    const uint32_t lds_pre = (uint32_t)(uintptr_t)(smem + k2Pre);
+    const uint32_t lds_look = (uint32_t)(uintptr_t)(smem + k2Look);
+    // the beta digits of the 128 rows of superblock k -> table buffer k & 1 (the first 16 bytes of a row's MxPre: twelve
+    // bytes of FP6 digits, then the flags word, which the transposed 96-bit reads never see): two DMAs of 64 rows
+    auto ctl_dma_bc = [&](uint32_t k) {
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h)
+            mx2_dma16(a.pre + sb_row0(k) + 64 * (cw * k2RPL + h) + lane, lds_bc + (k & 1u) * 2048u + (uint32_t)(cw * k2RPL + h) * 1024u, false);
+    };
+    // ... (w1, wfb) of the rows of superblock j, and the look at their tally words (one DMA: two words per lane)
     auto ctl_dma_look = [&](uint32_t j) {
-        mx2_dma16(reinterpret_cast<const char *>(a.pre + row_of(j)) + 16, lds_pre, false);
-        if (lane < 32) mx2_dma16(a.tally + (row_of(j) - crow + 64 * cw) + 2 * lane, lds_look, true);
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h)
+            mx2_dma16(reinterpret_cast<const char *>(a.pre + sb_row0(j) + 64 * (cw * k2RPL + h) + lane) + 16,
+                      lds_pre + (uint32_t)(cw * k2RPL + h) * 1024u, false);
+        if (lane < 32 * k2RPL) mx2_dma16(a.tally + sb_row0(j) + 64 * k2RPL * cw + 2 * lane, lds_look + (uint32_t)(cw * k2RPL) * 512u, true);
     };
     // complete tallies of superblock j (x) -> the row's two is-missing operands in table buffer j & 1; a row over
     // --maxmis goes on the list of rows whose eager code x beta the epilogue takes back
-    auto ctl_build = [&](uint32_t j, unsigned long long x, bool valid, bool ok, const v2ul pw) {
-        const uint64_t row = row_of(j);
+    auto ctl_build = [&](uint32_t j, int crow, unsigned long long x, bool valid, bool ok, const v2ul pw) {
+        const uint64_t row = sb_row0(j) + crow;
         // pw = (w1, wfb) as mx_prep_kernel left them for this kernel: w1 = INT64_MIN stands for a non-finite beta, wfb =
         // INT64_MIN for an imputed dosage that is NaN in the reference
         MxPre tpre;
@@ -293,20 +313,27 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
     constexpr unsigned long long kLookArmed = ~0ull;
     constexpr long long kPreArmed = 0x7fffffffffffffffll;
     auto ctl_arm = [&]() {
-        *reinterpret_cast<unsigned long long *>(smem + k2Look + crow * 8) = kLookArmed;
-        *reinterpret_cast<v2ul *>(smem + k2Pre + crow * 16) = v2ul{(unsigned long long)kPreArmed, 0ull};
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) {
+            const int crow = lane + 64 * (cw * k2RPL + h);
+            *reinterpret_cast<unsigned long long *>(smem + k2Look + crow * 8) = kLookArmed;
+            *reinterpret_cast<v2ul *>(smem + k2Pre + crow * 16) = v2ul{(unsigned long long)kPreArmed, 0ull};
+        }
     };
     auto ctl_tables = [&](uint32_t j) {  // (j < n_t)
-        const uint64_t row = row_of(j);
-        const bool valid = row < a.n_rows;
-        unsigned long long x;
-        v2ul pw;
+        unsigned long long x[k2RPL];
+        v2ul pw[k2RPL];
         uint32_t spins = 0;
         for (;;) {
             asm volatile("" ::: "memory");
-            x = *reinterpret_cast<const unsigned long long *>(smem + k2Look + crow * 8);
-            pw = *reinterpret_cast<const v2ul *>(smem + k2Pre + crow * 16);
-            const bool landed = x != kLookArmed && (long long)pw[0] != kPreArmed;
+            bool landed = true;
+#pragma unroll
+            for (int h = 0; h < k2RPL; ++h) {
+                const int crow = lane + 64 * (cw * k2RPL + h);
+                x[h] = *reinterpret_cast<const unsigned long long *>(smem + k2Look + crow * 8);
+                pw[h] = *reinterpret_cast<const v2ul *>(smem + k2Pre + crow * 16);
+                landed = landed && x[h] != kLookArmed && (long long)pw[h][0] != kPreArmed;
+            }
             if (__all(landed) || timed_out) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0 && spins >= kMxSpinLimit) {
@@ -318,14 +345,26 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         if (dbg_counts) { dbg_counts[0] += spins; dbg_counts[2] += 1; }
 #endif
         ctl_arm();  // (for the next look: the DMAs that overwrite it are issued after this wave's next barrier)
-        if (!valid) x = 0ull;
-        bool ok = !valid || (uint32_t)(x >> 56) == a.P || (DBG & 4);
+        bool valid[k2RPL], ok[k2RPL];
+        bool all_ok = true;
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) {
+            valid[h] = sb_row0(j) + lane + 64 * (cw * k2RPL + h) < a.n_rows;
+            if (!valid[h]) x[h] = 0ull;
+            ok[h] = !valid[h] || (uint32_t)(x[h] >> 56) == a.P || (DBG & 4);
+            all_ok = all_ok && ok[h];
+        }
         spins = 0;
-        while (!__all(ok) && !timed_out) {  // (rare: a strip that is more than two steps behind)
+        while (!__all(all_ok) && !timed_out) {  // (a strip that is more than two steps behind: the others wait here)
             __builtin_amdgcn_s_sleep(1);
-            if (!ok) {
-                x = __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (uint32_t)(x >> 56) == a.P;
+            all_ok = true;
+#pragma unroll
+            for (int h = 0; h < k2RPL; ++h) {
+                if (!ok[h]) {
+                    x[h] = __hip_atomic_load(&a.tally[sb_row0(j) + lane + 64 * (cw * k2RPL + h)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok[h] = (uint32_t)(x[h] >> 56) == a.P;
+                }
+                all_ok = all_ok && ok[h];
             }
             if ((++spins & 255u) == 0) {
                 const unsigned int t = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -338,7 +377,8 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
 #ifdef NPS_MX_TIMERS
         if (dbg_counts) dbg_counts[1] += spins;
 #endif
-        ctl_build(j, x, valid, ok, pw);
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) ctl_build(j, lane + 64 * (cw * k2RPL + h), x[h], valid[h], ok[h], pw[h]);
     };
     // the two-stage publication of nps_mx.hip: the strips arrive in groups on a word of their group; the strip whose add
     // completes a group (told by the value its add returned) adds the group's sum to the row's word
@@ -365,18 +405,18 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         MXT(8);
         const uint32_t jd = k - (uint32_t)k2L;      // the superblock whose is-missing part is accumulated in this step
         const bool due = k >= (uint32_t)k2L && jd < n_t;
-        const uint32_t jt = jd + 1;                  // ... and the one whose operands the control waves make (for the next step)
+        const uint32_t jt = jd + 1;                  // ... and the one whose operands the control wave makes (for the next step)
         const bool due_t = k + 1 >= (uint32_t)k2L && jt < n_t;
         if (is_ctl) {
-            // The compiler counts only the memory operations it knows: its waits for this wave's unit loads (issued a
-            // step ago) would also wait for every DMA issued since -- so all of them are waited for HERE, before the look
-            // goes out (memory returns in order: the units have had a whole step, the digits' DMA most of one) ...
+            // The compiler counts only the memory operations it knows: its wait for this wave's unit load (issued a step
+            // ago) would also wait for every DMA issued since -- so everything is waited for HERE, before the look goes out
+            // (the unit has had a whole step, the digits' DMA most of one) ...
             if (k < n_t && n_my != 0) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(b[u]));
             }
             mx2_wait_vm<0>();
-            // ... and the look is issued BEFORE this step's loads: waiting for it later waits for nothing younger
+            // ... and the look is issued BEFORE this step's load
             if (due_t) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the staging areas were re-armed with LDS writes)
                 ctl_dma_look(jt);
@@ -388,24 +428,33 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         MXT(6);  // (the beta digits of k + 1, a DMA of the last step, have landed: the wait at the top of the step)
         __syncthreads();
         MXT(2);
-        unsigned long long pub_old = 0ull, pub_add = 0ull;
-        bool pub_live = false;
+        unsigned long long pub_old[k2RPL], pub_add[k2RPL];
+        bool pub_live[k2RPL];
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) {
+            pub_old[h] = pub_add[h] = 0ull;
+            pub_live[h] = false;
+        }
         if (is_ctl) {
-            // publication of the strip's tallies of superblock k (complete in LDS: barrier passed): a returning add,
-            // asm so that ITS wait is counted by hand too (the compiler would wait for the unit loads in flight)
+            // publication of the strip's tallies of superblock k (complete in LDS: barrier passed): returning adds,
+            // asm so that THEIR wait is placed by hand (the compiler would wait where it first reads the result)
             uint32_t *T = reinterpret_cast<uint32_t *>(smem + k2Tally) + (k & 1) * 128;
-            const uint32_t v = T[crow];
-            T[crow] = 0u;
-            const uint64_t row = row_of(k);
-            pub_live = k < n_t && row < a.n_rows && !(DBG & 4);
-            pub_add = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
-            // ("+v" on the zeroed pub_old: the add writes the register pair the merge after this branch already lives in,
-            //  so no copy of a value that has not arrived yet can be placed behind the instruction)
-            if (pub_live)
-                asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
-                             : "+v"(pub_old)
-                             : "v"(&a.tally1[(uint64_t)grp * a.n_sb * 128 + row]), "v"(pub_add)
-                             : "memory");
+#pragma unroll
+            for (int h = 0; h < k2RPL; ++h) {
+                const int crow = lane + 64 * (cw * k2RPL + h);
+                const uint32_t v = T[crow];
+                T[crow] = 0u;
+                const uint64_t row = sb_row0(k) + crow;
+                pub_live[h] = k < n_t && row < a.n_rows && !(DBG & 4);
+                pub_add[h] = (1ull << 56) | ((unsigned long long)(v >> 16) << 28) | (v & 0xFFFFu);
+                // ("+v" on the zeroed pub_old: the add writes the register pair the merge after this branch already
+                //  lives in, so no copy of a value that has not arrived yet can be placed behind the instruction)
+                if (pub_live[h])
+                    asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
+                                 : "+v"(pub_old[h])
+                                 : "v"(&a.tally1[(uint64_t)grp * a.n_sb * 128 + row]), "v"(pub_add[h])
+                                 : "memory");
+            }
             if (k + 2 < n_t) ctl_dma_bc(k + 2);  // (buffer k & 1: every wave has read the digits of k before this barrier)
         }
         MXT(3);
@@ -414,15 +463,20 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         if (is_ctl) {
             if (due_t) ctl_tables(jt);
             MXT(7);
-            // the returning add is back.  vmcnt(0) also waits for this step's unit loads -- which the top of the next step,
-            // a moment from here, waits for anyway.  ONE statement: with a wait per branch the compiler once placed a copy
-            // of pub_old IN FRONT of one of them (a read of registers whose data had not arrived).
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pub_old) : : "memory");
-            if (pub_live) {
-                const unsigned long long tot = pub_old + pub_add;
-                if ((uint32_t)(tot >> 56) == grp_size)
-                    __hip_atomic_fetch_add(&a.tally[row_of(k)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // the returning adds are back.  vmcnt(0) also waits for this step's unit load -- which the top of the next step,
+            // a moment from here, waits for anyway.  ONE statement for both results: with a wait per branch the compiler
+            // once placed a copy of the result IN FRONT of one of them (a read of registers whose data had not arrived).
+            if (k2RPL == 2)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pub_old[0]), "+v"(pub_old[k2RPL - 1]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pub_old[0]) : : "memory");
+#pragma unroll
+            for (int h = 0; h < k2RPL; ++h)
+                if (pub_live[h]) {
+                    const unsigned long long tot = pub_old[h] + pub_add[h];
+                    if ((uint32_t)(tot >> 56) == grp_size)
+                        __hip_atomic_fetch_add(&a.tally[sb_row0(k) + lane + 64 * (cw * k2RPL + h)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
         }
         MXT(5);
         if (((k + 1) & (kFlushSb - 1)) == 0 && k + 1 < n_t) store_c(k / kFlushSb, true);
@@ -453,46 +507,40 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         for (int o = 32; o > 0; o >>= 1) cst_local += __shfl_down(cst_local, o, 64);
         if (lane == 0) {
             if (nloci_local) atomicAdd(a.nloci, (unsigned long long)nloci_local);
-            if (cst_local != 0.0) a.const_sum[2 * team + (wave - kDW)] = cst_local;  // (NaN != 0 is true)
+            if (cst_local != 0.0) a.const_sum[2 * team + cw] = cst_local;  // (NaN != 0 is true)
         }
     }
 }
 
 template <int DBG>
-__global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx2_kernel(const MxArgs a) {
+__global__ __launch_bounds__(k2Threads, k2Threads / 256) void fused_mx2_kernel(const MxArgs a) {
     extern __shared__ char smem[];
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave < kBig ? wave * kUD : kBig * kUD + (wave - kBig) * kUD2;  // (data waves)
 #ifdef NPS_MX2_PROBE  // (register probes: one body per build)
 #if NPS_MX2_PROBE == 1
-    mx2_body<kUD, false, false, DBG>(a, smem);
+    mx2_body<k2UD, false, false, DBG>(a, smem);
 #elif NPS_MX2_PROBE == 2
-    mx2_body<kUC, false, true, DBG>(a, smem);
+    mx2_body<k2UC, false, true, DBG>(a, smem);
 #elif NPS_MX2_PROBE == 3
-    mx2_body<kUD, true, false, DBG>(a, smem);
+    mx2_body<k2UD, true, false, DBG>(a, smem);
 #else
-    mx2_body<kUC, true, true, DBG>(a, smem);
+    mx2_body<k2UC, true, true, DBG>(a, smem);
 #endif
     return;
 #endif
-    if (wave >= kDW) {
+    // both bodies pass the same barriers; which one a wave runs is wave-uniform
+    if (wave >= k2DW) {
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
-        const int uc0 = kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
-        if (kUC > 0 && nu - uc0 >= kUC)
-            mx2_body<(kUC > 0 ? kUC : 1), false, true, DBG>(a, smem);
+        if (nu - (k2DW * k2UD + (wave - k2DW) * k2UC) >= k2UC)
+            mx2_body<k2UC, false, true, DBG>(a, smem);
         else
-            mx2_body<(kUC > 0 ? kUC : 1), true, true, DBG>(a, smem);
-    } else if (wave < kBig) {
-        if (nu - u0 >= kUD)
-            mx2_body<kUD, false, false, DBG>(a, smem);
-        else
-            mx2_body<kUD, true, false, DBG>(a, smem);
+            mx2_body<k2UC, true, true, DBG>(a, smem);  // (a ragged last strip without its 64th unit: the per-row work alone)
     } else {
-        if (nu - u0 >= kUD2)
-            mx2_body<kUD2, false, false, DBG>(a, smem);
+        if (nu - wave * k2UD >= k2UD)
+            mx2_body<k2UD, false, false, DBG>(a, smem);
         else
-            mx2_body<kUD2, true, false, DBG>(a, smem);
+            mx2_body<k2UD, true, false, DBG>(a, smem);
     }
 }
 
@@ -549,7 +597,7 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
     a.const_sum = d_const_sum;
     a.cpart = d_cpart;
     a.timeout = d_timeout;
-    a.ctl_prio = plan.P <= 208 ? 1u : 0u;
+    a.ctl_prio = 1u;  // (the control wave's per-row work is the step's longest path: 29.9 -> 28.5 ms at 245 strips)
     a.grp_strips = 48u;
     a.fix_rows = d_fix_rows;
     a.fix_count = d_fix_count;
@@ -561,17 +609,17 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
     void *args[] = {&a};
 #ifdef NPS_MX_TIMERS
     {
-        hipError_t e = hipLaunchCooperativeKernel(fn, grid, dim3(kMxThreads), args, k2LdsBytes, st);
+        hipError_t e = hipLaunchCooperativeKernel(fn, grid, dim3(k2Threads), args, k2LdsBytes, st);
         if (e != hipSuccess) return e;
         (void)hipStreamSynchronize(st);
         unsigned long long h[16][16];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mx2_timers), sizeof(h));
         static const char *nm[16] = {"bc+look-issue", "front", "barrier", "publish-begin", "deferred", "publish-end", "look-wait",
                                      "tables", "loop/flush", "-", "-", "-", "-", "-", "-", "-"};
-        for (int w : {0, 3, kDW, kDW + 1}) {
+        for (int w : {0, 3, k2DW - 1, k2DW}) {
             fprintf(stderr, "mx2 timers wave %d (cycles per step):", w);
             for (int i = 0; i < 9; ++i) fprintf(stderr, "  %s %.0f", nm[i], (double)h[w][i] / (plan.n_sb / plan.Q));
-            if (w >= kDW)
+            if (w >= k2DW)
                 fprintf(stderr, "  | landing polls %.2f and row-word polls %.3f per step (%llu steps)", (double)h[w][10] / (double)h[w][12],
                         (double)h[w][11] / (double)h[w][12], h[w][12]);
             fprintf(stderr, "\n");
@@ -579,7 +627,7 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
         return hipSuccess;
     }
 #endif
-    return hipLaunchCooperativeKernel(fn, grid, dim3(kMxThreads), args, k2LdsBytes, st);
+    return hipLaunchCooperativeKernel(fn, grid, dim3(k2Threads), args, k2LdsBytes, st);
 }
 
 }  // namespace nps
