@@ -369,7 +369,9 @@ int nps_multi_create(nps_multi **out, int device, uint64_t n_samples, const nps_
  * multiplies byte prefixes of four packed genotypes, so a weight is known to 2^-24 of the largest one at worst) --
  * per sample an error of at most (its missing genotypes) x 2^-24 x B before the division by 2 nloci,
  * B = max|beta| x (3 + max(2, 2 max|eaf|)) of the score, typically the square root of that count -- and with more
- * than 4 scores the pass needs up to a quarter fewer matrix instructions.  NaN imputation values
+ * than 4 scores the pass needs up to a quarter fewer matrix instructions.  40: five leading digits, 2^-32 x B per missing
+ * genotype, an eighth fewer matrix instructions with 7 or 8 scores (round 5; like 32 an option, not the default: a sample
+ * whose terms cancel is not within 1e-6 of its own score over a million rows).  NaN imputation values
  * (imp-sample fail / int_fail below --mincs) are exact in both modes.  Applies to the following calls. */
 int nps_multi_set_missing_weight_bits(nps_multi *m, int bits);
 /* cohort_row0 must be a multiple of 128; calls accumulate (chunks of a larger matrix) until nps_multi_reset.

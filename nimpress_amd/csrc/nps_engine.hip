@@ -2196,7 +2196,7 @@ struct nps_multi {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms[3] = {0.0, 0.0, 0.0};  // params, product, fold of all calls since the last reset
     bool timed = false;
-    bool coarse_missing = false;     // nps_multi_set_missing_weight_bits(32)
+    int coarse_missing = 0;          // nps_multi_set_missing_weight_bits: leading base-256 digits kept (4 = 32 bits, 5 = 40; 0 = all)
     bool broken = false;             // a HIP call failed between the first and the last launch of a pass
 };
 
@@ -2271,8 +2271,9 @@ extern "C" void nps_multi_destroy(nps_multi *m) { free_multi(m); }
 
 extern "C" int nps_multi_set_missing_weight_bits(nps_multi *m, int bits) {
     if (!m) return fail(NPS_E_INVAL, "ctx is NULL");
-    if (bits != 0 && bits != 32 && bits != 56) return fail(NPS_E_INVAL, "bits must be 32 or 56 (0 = default 56), not %d", bits);
-    m->coarse_missing = bits == 32;
+    if (bits != 0 && bits != 32 && bits != 40 && bits != 56)
+        return fail(NPS_E_INVAL, "bits must be 32, 40 or 56 (0 = default 56), not %d", bits);
+    m->coarse_missing = bits == 32 ? 4 : bits == 40 ? 5 : 0;
     return NPS_OK;
 }
 
@@ -2336,7 +2337,7 @@ extern "C" int nps_score_cohort_multi(nps_multi *m, const nps_cohort *co, uint64
         hipError_t e = hipEventRecord(m->ev[0], m->stream);
         if (e != hipSuccess) return e;
         e = launch_multi_params(m->stream, co->d_row_tally + cohort_row0, def->d_desc, def->n_desc, m->S, pl, m->n,
-                                dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing ? 1 : 0);
+                                dev_params(m->params), def->d_F, m->d_table, m->d_state, m->coarse_missing);
         if (e != hipSuccess) return e;
         e = hipEventRecord(m->ev[1], m->stream);
         if (e != hipSuccess) return e;

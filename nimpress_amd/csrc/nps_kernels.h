@@ -229,7 +229,7 @@ struct MultiPlan {
     uint64_t flag_bytes() const { return (uint64_t)n_sb * 4; }  // one word per superblock, behind the tables
     uint64_t partial_elems() const { return (uint64_t)n_chunks * n_groups * 32 * T * 16; }
 };
-MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, bool coarse_missing, int cus);
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, int coarse_missing /* leading base-256 digits of the is-missing weights kept: 4, 5; 0 = all */, int cus);
 size_t multi_state_bytes();
 hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally, const nps_row_desc *d_desc,
                                uint64_t n_desc, int S, const MultiPlan &pl, uint64_t n_samples, DevParams p,

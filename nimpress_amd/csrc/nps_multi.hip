@@ -288,9 +288,9 @@ static __host__ __device__ constexpr __forceinline__ int multi_col(int S, int ND
 }
 
 // the signed base-256 digits of a coefficient (already scaled: see above; |V| < 2^(8 ND - 1))
-static __device__ __forceinline__ void weight_digits(long long V, int ND, bool coarse, int (&d)[8]) {
-    if (coarse) {  // nearest multiple of 256^(ND-4): only the four leading digits remain
-        const int sh = 8 * (ND - 4);
+static __device__ __forceinline__ void weight_digits(long long V, int ND, int keep, int (&d)[8]) {
+    if (keep > 0 && keep < ND) {  // nearest multiple of 256^(ND-keep): only the `keep` leading digits remain
+        const int sh = 8 * (ND - keep);
         V = ((V + (1ll << (sh - 1))) >> sh) << sh;
     }
 #pragma unroll
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void multi_params_kernel(
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             int dd[8], dmm[8];
-            weight_digits(cD[f], ND, false, dd);
-            weight_digits(cM[f], ND, coarse_missing != 0, dmm);
+            weight_digits(cD[f], ND, 0, dd);
+            weight_digits(cM[f], ND, coarse_missing, dmm);
             dmm[7] = cF[f];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -735,12 +735,12 @@ hipError_t launch_multi_params(hipStream_t st, const unsigned long long *d_tally
     return hipGetLastError();
 }
 
-MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, bool coarse_missing, int cus) {
+MultiPlan multi_plan(uint64_t n_samples, uint64_t n_rows, int S, int ND, int coarse_missing /* leading digits kept, 0 = all */, int cus) {
     MultiPlan pl;
     pl.ND = ND;
     pl.T = ((ND + 1) * S + 15) / 16;
     pl.TD = (ND * S + 15) / 16;
-    pl.TM = coarse_missing ? (4 * S + 15) / 16 : pl.TD;
+    pl.TM = coarse_missing > 0 && coarse_missing < ND ? std::min(pl.TD, (coarse_missing * S + 15) / 16) : pl.TD;
     pl.TF0 = (ND * S) / 16;
     pl.GW = NPS_MULTI_GW;
     pl.n_groups = (n_samples + 31) / 32;
@@ -802,6 +802,7 @@ hipError_t launch_multi_mfma(hipStream_t st, const MultiPlan &pl, const void *d_
         NPS_MFMA_CASE(3, 2, 2, 1)
         NPS_MFMA_CASE(4, 4, 4, 3)
         NPS_MFMA_CASE(4, 4, 2, 3)
+        NPS_MFMA_CASE(4, 4, 3, 3)
         NPS_MFMA_CASE(4, 3, 3, 2)
         NPS_MFMA_CASE(4, 3, 2, 2)
         NPS_MFMA_CASE(4, 3, 3, 3)

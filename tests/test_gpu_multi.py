@@ -73,7 +73,7 @@ def oracle_scores(codes, n, descs, params_kw, offsets):
 
 
 @pytest.mark.parametrize("wbits", [0, 41])
-@pytest.mark.parametrize("bits", [56, 32])
+@pytest.mark.parametrize("bits", [56, 40, 32])
 @pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
 @pytest.mark.parametrize("shape", [(1, 1, 1), (17, 33, 2), (6, 7, 3), (33, 129, 4), (257, 300, 5), (65, 130, 6),
                                    (40, 260, 7), (1000, 1025, 8), (4099, 64, 8)])
@@ -106,17 +106,17 @@ def test_multi_vs_oracle_converted_cohort(shape, pk, bits, wbits):
     assert np.array_equal(nloci.astype(np.int64), ref_nloci)
     for s in range(S):
         keep = descs[s]["kind"] != capi.ROW_NOT_IN_SCORE
-        if bits == 32 or wbits == 41:
+        if bits in (32, 40) or wbits == 41:
             # the documented bounds (include/nps.h), after the division by 2 nloci: 32-bit is-missing weights:
             # (missing genotypes of the sample) x 2^-24 x B; 41-bit weights: every term within 3 x 2^-41 of the
             # largest weight the fixed point holds (< 2 B)
             d = descs[s][keep]
             B = float(np.max(np.abs(d["beta"])) * (3.0 + max(2.0, 2.0 * float(np.max(np.abs(np.nan_to_num(d["eaf"])))))))
             bound = np.zeros(n)
-            if bits == 32:
-                # (NPS_CODE_MISSING = 2; 16 codes per word)
+            if bits in (32, 40):
+                # (NPS_CODE_MISSING = 2; 16 codes per word); five digits instead of four: 2^-32 instead of 2^-24
                 plain = ((np.asarray(codes)[keep][:, :, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(keep.sum(), -1)
-                bound += (plain[:, :n] == 2).sum(axis=0) * 2.0 ** -24 * B
+                bound += (plain[:, :n] == 2).sum(axis=0) * 2.0 ** (-24 if bits == 32 else -32) * B
             if wbits == 41:
                 bound += keep.sum() * 6.0 * 2.0 ** -40 * B
             bound /= max(2.0 * int(ref_nloci[s]), 1)
