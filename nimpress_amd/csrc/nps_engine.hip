@@ -170,6 +170,8 @@ struct nps_ctx {
     uint64_t mx_tally1_cap = 0;
     uint32_t *d_mx_fix = nullptr;               // nps_mx2.hip: the run's rows over --maxmis (list, any order); its length is
     uint64_t mx_fix_cap = 0;                    // the word d_timeout[16], zero between passes
+    uint32_t *d_mx_part = nullptr;              // nps_mx3.hip: the strips' partial tallies on their way to the reducers
+    uint64_t mx_part_cap = 0;
     void *d_mx_ops = nullptr;                   // nps_mxg.hip (tallies given): 48 bytes of weight operands per row ...
     uint64_t mx_ops_cap = 0;                    // (in units of 48 bytes)
     double *d_mx_cblk = nullptr;                // ... and one partial sum of locus constants per superblock
@@ -343,6 +345,7 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_mx_tally1);
     (void)hipFree(c->d_mx_fix);
     (void)hipFree(c->d_mx_ops);
+    (void)hipFree(c->d_mx_part);
     (void)hipFree(c->d_mx_cblk);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
@@ -1604,6 +1607,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
     bool kept_tallies = false, use_v2 = false;
+    uint32_t mx3_R = 0;
     if (is_mx && m && c->n) {
         // a cohort that carries its tallies (nps_cohort_keep_tallies) is scored with them given under NPS_MODE_AUTO: the
         // "two-pass" plan (independent workgroups) without its tally pass
@@ -1718,6 +1722,17 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         // NPS_MODE_FUSED_EAGER: the second form of the strip kernel (nps_mx2.hip), on request only -- it is not faster
         // (DESIGN.md 4.2, round 5); a shape it does not take (more strips than compute units) is refused like NPS_MODE_FUSED
         use_v2 = mode == NPS_MODE_FUSED_EAGER;
+#if defined(NPS_WITH_MX3) && defined(NPS_DIAGNOSTICS)
+        // experiment builds only (tools/mkexp.sh NAME -DNPS_WITH_MX3 -DNPS_DIAGNOSTICS): the third form, nps_mx3.hip -- a
+        // measured negative (profiles/r05_mx3_timers.txt), not part of the library
+        if (use_v2 && getenv("NPS_MX_FORM") && atoi(getenv("NPS_MX_FORM")) == 3) mx3_R = mx3_reducers(c->device, mxp);
+#endif
+        if (mx3_R) {
+            rc = grow(c, (void **)&c->d_mx_part, &c->mx_part_cap, (uint64_t)mxp.Q * 8 * mxp.P * 128, sizeof(uint32_t));
+            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);  // (32 bytes per row used)
+            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_cblk, &c->mx_cblk_cap, m_pad / 128, sizeof(double));
+            if (rc) return rc;
+        }
         if (use_v2) {
             rc = grow(c, (void **)&c->d_mx_fix, &c->mx_fix_cap, m_pad, sizeof(uint32_t));
             if (rc) return rc;
@@ -1831,6 +1846,19 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                          kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally,
                                          b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci, const_slots,
                                          c->d_mx_cpart, c->d_mx_ops, c->d_mx_cblk, c->d_timeout + 17);
+#ifdef NPS_WITH_MX3
+                else if (use_v2 && mx3_R) {
+                    // (no row of the tables may carry a superblock's number, no word of the partial tallies a step's tag,
+                    //  from an earlier pass)
+                    HIP_TRY(hipMemsetAsync(c->d_mx_part, 0xFF, sizeof(uint32_t) * (uint64_t)mxp.Q * 8 * mxp.P * 128, c->stream));
+                    HIP_TRY(hipMemsetAsync(c->d_mx_ops, 0, 32ull * m_pad, c->stream));
+                    fe = launch_fused_mx3(c->stream, mxp, mx3_R, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
+                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
+                                          b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci, const_slots,
+                                          c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count, c->d_mx_part, c->d_mx_ops,
+                                          c->d_mx_cblk, c->d_timeout + 17);
+                }
+#endif
                 else if (use_v2)
                     fe = launch_fused_mx2(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                           runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,

@@ -300,7 +300,7 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
                           const unsigned int *d_fix_count = nullptr, const void *d_units = nullptr,
                           const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0);
 hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          bool sentinels);
+                          int sentinels /* 0 flags; 1 flags + sentinels in (w1, wfb); 2 sentinels, flags word = superblock + 1 */);
 // nps_mx2.hip: the same pass with code x beta accumulated on arrival and only the is-missing masks parked (three steps of
 // slack for the hand-over); never for plan.given; d_fix_rows: n_rows uint32, d_fix_count: one zeroed word
 hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
@@ -310,6 +310,15 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
                             double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
                             unsigned int *d_fix_count);
 constexpr uint64_t kMx2MaxRows = 0xffffffffull;
+// nps_mx3.hip: the same pass with the row tallies completed and the rows' operands made ONCE, by R reducer workgroups on
+// the compute units the strips leave idle.  mx3_reducers: how many a plan leaves room for (0: this form does not apply).
+uint32_t mx3_reducers(int device, const MxPlan &plan);
+hipError_t launch_fused_mx3(hipStream_t st, const MxPlan &plan, uint32_t R, const void *d_units, uint64_t n_sb_cohort,
+                            uint64_t sb0, uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
+                            int64_t t_maxmis, int F, void *d_pre, nps_locus_stat *d_stats, unsigned long long *d_nloci,
+                            double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
+                            unsigned int *d_fix_count, uint32_t *d_part, void *d_ops, double *d_const_part,
+                            unsigned int *d_done);
 // nps_mxg.hip: the run with its row tallies GIVEN (plan.given: kept with the cohort, or from launch_mx_tally): per-row
 // decisions + operands, then an ordinary grid of P x Q workgroups.  d_ops: 48 bytes per row padded to 128 rows;
 // d_const_part: one double per superblock; d_done: one zeroed word (zero again afterwards); d_const_sum as for launch_fused_mx

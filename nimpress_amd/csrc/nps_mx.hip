@@ -47,6 +47,8 @@ __device__ unsigned long long g_mx_timers[16][16];  // [wave][phase]: cycles sum
 // (their digits are fetched with the last superblock's)
 __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows, uint64_t n_pad,
                                                       DevParams prm, double scale, int sentinels, MxPre *__restrict__ pre) {
+    // (sentinels == 2, nps_mx3.hip: the flags word is replaced by the row's superblock + 1 -- the mark by which a strip
+    //  sees that its LDS-DMA of the beta digits has landed; the flags travel as sentinels)
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_pad) return;
     MxPre o;
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
     o.flags = 0u;
     o.w1 = o.wfb = 0;
     if (j >= n_rows) {
+        if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
         pre[j] = o;
         return;
     }
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
             o.wfb = __double2ll_rn(t * scale);
         }
     }
+    if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
     pre[j] = o;
 }
 
@@ -456,7 +460,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 
 template <int DBG, bool GIVEN>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
-    extern __shared__ char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
@@ -840,11 +844,11 @@ hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_uni
 }
 
 hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          bool sentinels) {
+                          int sentinels) {
     (void)hipGetLastError();
     const uint64_t n_pad = (n_rows + 127) / 128 * 128;
     hipLaunchKernelGGL(mx_prep_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, st, d_desc, n_rows, n_pad, prm,
-                       std::ldexp(1.0, F), sentinels ? 1 : 0, (MxPre *)d_pre);
+                       std::ldexp(1.0, F), sentinels, (MxPre *)d_pre);
     return hipGetLastError();
 }
 
@@ -854,7 +858,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                            unsigned long long *d_tally1, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout) {
     {
-        hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, false);
+        hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 0);
         if (pe != hipSuccess) return pe;
     }
     const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true> : (const void *)fused_mx_kernel<0, false>;
@@ -909,6 +913,11 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.grp_strips = 48u;
     a.fix_rows = nullptr;
     a.fix_count = nullptr;
+    a.part = nullptr;
+    a.ops = nullptr;
+    a.const_part = nullptr;
+    a.done = nullptr;
+    a.R = 0;
 #ifdef NPS_MX_GRP_ENV
     if (getenv("NPS_MX_GRP")) {  // (experiment builds) 0 = balanced groups of at most 64
         const int g = atoi(getenv("NPS_MX_GRP"));

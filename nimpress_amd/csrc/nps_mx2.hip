@@ -514,7 +514,7 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
 
 template <int DBG>
 __global__ __launch_bounds__(k2Threads, k2Threads / 256) void fused_mx2_kernel(const MxArgs a) {
-    extern __shared__ char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
 #ifdef NPS_MX2_PROBE  // (register probes: one body per build)
@@ -551,7 +551,7 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
                             double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
                             unsigned int *d_fix_count) {
     if (plan.given || n_rows > 0xffffffffull) return hipErrorInvalidValue;
-    hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, true);
+    hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 1);
     if (pe != hipSuccess) return pe;
     const void *fn = (const void *)fused_mx2_kernel<0>;
 #ifdef NPS_DIAGNOSTICS
@@ -601,6 +601,11 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
     a.grp_strips = 48u;
     a.fix_rows = d_fix_rows;
     a.fix_count = d_fix_count;
+    a.part = nullptr;
+    a.ops = nullptr;
+    a.const_part = nullptr;
+    a.done = nullptr;
+    a.R = 0;
 #ifdef NPS_DIAGNOSTICS
     if (getenv("NPS_MX_PRIO")) a.ctl_prio = (uint32_t)atoi(getenv("NPS_MX_PRIO"));
     if (getenv("NPS_MX_GRP")) a.grp_strips = (uint32_t)std::max(16, atoi(getenv("NPS_MX_GRP")));

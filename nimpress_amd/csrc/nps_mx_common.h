@@ -74,7 +74,15 @@ struct MxArgs {
     // of the row's team; fix_count zero on entry)
     uint32_t *fix_rows;
     unsigned int *fix_count;
+    // nps_mx3.hip only: the strips' partial tallies on their way to the reducer workgroups, the finished is-missing
+    // operands on their way back, the reducers' partial sums of locus constants
+    uint32_t *part;          // [Q][kMx3PartRing][P][128]: tag << 25 | nmissing << 13 | neffect of one strip and row
+    v4u *ops;                // [n_sb][2 operands][128 rows in mx3 table order] x 16 bytes; fourth dword = superblock + 1
+    double *const_part;      // [n_sb]
+    unsigned int *done;      // one zeroed word: reducers that have finished
+    uint32_t R;              // reducer workgroups (blocks P Q .. P Q + R - 1 of the grid)
 };
+constexpr uint32_t kMx3PartRing = 8;  // steps of partial tallies a team may have in flight
 
 static __device__ __forceinline__ v2i tr4(const char *p) {
     return __builtin_amdgcn_ds_read_tr4_b64_v2i32((NPS_LDS v2i *)p);

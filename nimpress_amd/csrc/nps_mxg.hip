@@ -291,7 +291,7 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
 }
 
 __global__ __launch_bounds__(kGW * 64, kGW / 4) void mx_given_kernel(const MxgArgs a) {
-    extern __shared__ char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     if (nu - wave * kGU >= kGU)
@@ -335,6 +335,11 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
     ra.grp_strips = 0;
     ra.fix_rows = nullptr;
     ra.fix_count = nullptr;
+    ra.part = nullptr;
+    ra.ops = nullptr;
+    ra.const_part = nullptr;
+    ra.done = nullptr;
+    ra.R = 0;
     hipLaunchKernelGGL(mx_ops_kernel, dim3(plan.n_sb), dim3(128), 0, st, d_desc, n_rows, d_tally, ra, (v4u *)d_ops,
                        d_const_part, d_done);
     hipError_t e = hipGetLastError();
