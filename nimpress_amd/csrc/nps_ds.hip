@@ -140,9 +140,12 @@ __global__ __launch_bounds__(256) void ds_params_kernel(const DsTally *__restric
     if (threadIdx.x == 0 && cnt) atomicAdd(nloci, (unsigned long long)cnt);
 }
 
-// one thread = one sample x one chunk of rows, rows in order: score += dosage * beta (nim:639-641).
-// grid.y row chunks add into separate partial-score planes (combined in fixed order by
-// finish_kernel), so that a 200 000-sample cohort still fills the chip.
+// one thread = FOUR neighbouring samples x one chunk of rows, rows in order: score += dosage * beta (nim:639-641) -- a
+// 16-byte non-temporal load per row and lane (the rows are read once here and are zero padded to 64 floats, so the load of a
+// row's last lanes stays inside it), eight rows in flight.  grid.y row chunks add into separate partial-score planes (combined
+// in fixed order by finish_kernel), so that a 200 000-sample cohort still fills the chip.
+// (Until round 5: one sample and a 4-byte load per lane -- 2.6 TB/s over the two passes)
+typedef float ds_v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restrict__ ds,
                                                             uint64_t stride_f, uint64_t n,
                                                             const DsRowP *__restrict__ rowp_all,
@@ -150,36 +153,45 @@ __global__ __launch_bounds__(256) void ds_accumulate_kernel(const float *__restr
                                                             uint64_t rows_per_chunk,
                                                             double *__restrict__ part,
                                                             uint64_t part_chunk_stride) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const uint64_t r_begin = (uint64_t)blockIdx.y * rows_per_chunk;
     if (i >= n || r_begin >= n_rows_all) return;
     const uint64_t n_rows = min(rows_per_chunk, n_rows_all - r_begin);
     const DsRowP *rowp = rowp_all + r_begin;
-    double *part0 = part + (uint64_t)blockIdx.y * part_chunk_stride;
-    double s = part0[i];
+    double *part0 = part + (uint64_t)blockIdx.y * part_chunk_stride + i;
+    const int live = (int)min((uint64_t)4, n - i);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < live) s[k] = part0[k];
     const float *p = ds + r_begin * stride_f + i;
-    auto apply = [&](const DsRowP &r, const float e) {
+    auto apply = [&](const DsRowP &r, const ds_v4f e) {
         if (r.mode == 0) return;
-        double d;
-        if (r.mode == 2)
-            d = r.cst;
-        else if (isnan(e))
-            d = r.imp;
-        else
-            d = r.rie ? 2.0 - (double)e : (double)e;
-        s += d * r.beta;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double d;
+            if (r.mode == 2)
+                d = r.cst;
+            else if (isnan(e[k]))
+                d = r.imp;
+            else
+                d = r.rie ? 2.0 - (double)e[k] : (double)e[k];
+            s[k] += d * r.beta;
+        }
     };
-    // 16 rows of loads in flight per thread; the adds stay in row order
+    auto load = [&](uint64_t row) { return __builtin_nontemporal_load(reinterpret_cast<const ds_v4f *>(p + row * stride_f)); };
     uint64_t row = 0;
-    for (; row + 16 <= n_rows; row += 16) {
-        float q[16];
+    for (; row + 8 <= n_rows; row += 8) {
+        ds_v4f q[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = p[(row + u) * stride_f];
+        for (int u = 0; u < 8; ++u) q[u] = load(row + u);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) apply(rowp[row + u], q[u]);
+        for (int u = 0; u < 8; ++u) apply(rowp[row + u], q[u]);
     }
-    for (; row < n_rows; ++row) apply(rowp[row], p[row * stride_f]);
-    part0[i] = s;
+    for (; row < n_rows; ++row) apply(rowp[row], load(row));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < live) part0[k] = s[k];
 }
 
 // FORMAT/GT with ploidy > 2 (dosage can exceed 2, nimpress.nim:385-390): decoded to a float dosage
@@ -286,7 +298,7 @@ hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stri
     if (n_chunks == 0 || n_chunks > 65535 || part_chunk_stride < n) return hipErrorInvalidValue;
     const uint64_t rows_per_chunk = std::max<uint64_t>(16, (n_rows + n_chunks - 1) / n_chunks);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ds_accumulate_kernel, dim3((uint32_t)((n + 255) / 256), n_chunks), dim3(256), 0,
+    hipLaunchKernelGGL(ds_accumulate_kernel, dim3((uint32_t)((n + 1023) / 1024), n_chunks), dim3(256), 0,
                        st, d_ds, stride_f, n, d_rowp, n_rows, rows_per_chunk, d_part,
                        part_chunk_stride);
     return hipGetLastError();
