@@ -399,6 +399,11 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         // parity test of tests/test_gpu_mx.py would fail, the tables would be made of stale words).  Before round 4's last change the look was issued, waited for and turned into tables BEFORE front():
         // 24.3 -> 22.5-23.2 ms at 245 strips.
         constexpr bool kUnder = !GIVEN;
+        // which of the two counts the look's wait will use, made a scalar HERE: asked for at the wait itself (a
+        // v_readfirstlane between front() and the wait, on the control wave's critical path) the pass takes 23.23 ms,
+        // this way 22.80 (same box, three alternating runs each)
+        int steady = (is_ctl && kUnder) ? __builtin_amdgcn_readfirstlane((k + 3 < n_t && n_my == NU) ? 1 : 0) : 0;
+        asm volatile("" : "+s"(steady));
         if (is_ctl && kUnder) {
             const uint64_t row = ((uint64_t)team + (uint64_t)k * a.Q) * 128 + crow;
             x_look = 0ull;
@@ -419,7 +424,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             // the last steps of a pass and on ragged strips; tests/test_isa_checks.py found it and now guards the window.
             asm volatile("s_cmp_lg_u32 %1, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(%2)\n2:"
                          : "+v"(x_look)
-                         : "s"(__builtin_amdgcn_readfirstlane((k + 3 < n_t && n_my == NU) ? 1 : 0)), "n"(NU)
+                         : "s"(steady), "n"(NU)
                          : "scc", "memory");
             MXT(6);
             ctl_tables(k, true, x_look);

@@ -35,7 +35,8 @@
 // masks) for publish -> poll -> 125 KB read -> operands -> table -> DMA, five dependent trips through memory between
 // XCDs; the first form does the same with two.  Parity: the statistics and nloci are exact at every shape tried, the
 // scores at 6 of the 12 shapes of test_gt2x_eager_mode_vs_oracle (the (16385, 47) case differs in its NaN positions);
-// not pursued further.  One finding kept: a static __shared__ variable in a kernel that also has a dynamic block moves
+// not pursued further (a likely cause, found afterwards in nps_mxg.hip: LDS rows left by an earlier launch carry the numbers
+// this launch waits for -- the landing marks of a launch must be cleared before its first DMA).  One finding kept: a static __shared__ variable in a kernel that also has a dynamic block moves
 // the dynamic block off its 16-byte alignment, and ds_read_b96_tr_b6 from a misaligned row returns OTHER bits (plain LDS
 // reads do not care) -- every extern __shared__ block of the strip kernels is now declared aligned(16).
 #ifdef NPS_WITH_MX3

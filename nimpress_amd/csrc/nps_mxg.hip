@@ -251,6 +251,15 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
     };
 
     // ---- prologue
+    // LDS keeps what the compute unit's previous workgroup left in it -- possibly this kernel's tables of an EARLIER launch,
+    // whose rows carry the very superblock numbers this launch waits for (another score file's weights: seen once in round 5
+    // as 125 samples of one strip off by 5e-4 relative).  No row of either buffer may carry a number before the first DMA
+    // is issued: zero is nobody's (the numbers start at 1), and the stores are done before the DMA leaves.
+    if (wave < 6) {
+        *reinterpret_cast<uint32_t *>(smem + kGTab + wave * 1024 + lane * 16 + 12) = 0u;
+        *reinterpret_cast<uint32_t *>(smem + kGTab + 6144u + wave * 1024 + lane * 16 + 12) = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     dma_tables(0);
     load_sb(0, bank[0]);
     if (kBanks > 1) load_sb(1, bank[kBanks - 1]);

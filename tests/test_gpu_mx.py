@@ -131,6 +131,28 @@ def test_gt2x_two_pass_mode_vs_oracle(shape):
     assert np.allclose(one[both], scores[both], rtol=1e-12, atol=1e-15)
 
 
+def test_gt2x_given_tables_are_this_launch_s_own():
+    """the accumulation with given tallies (nps_mxg.hip) fetches its operand tables by LDS-DMA and knows a table has landed by
+    the superblock number every row carries.  LDS outlives a launch: the tables of the PREVIOUS launch carry the same numbers
+    (round 5: 125 samples of one strip scored with the other score file's weights, once in many runs).  Two score files
+    alternate over one cohort; every launch must reproduce its file's first result bit for bit."""
+    n, m = 70000, 2000
+    rng = np.random.default_rng(4242)
+    co = make_cohort(n, m, 515, rng)
+    kw = PARAM_GRID[0]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    files = [capi.row_descs(co["beta"], co["eaf"], None, co["rie"]),
+             capi.row_descs(co["beta"][::-1] * 3.0, co["eaf"], None, co["rie"])]
+    first = [score_gt2x(dev, n, kw, d, 0.0, mode=capi.MODE_TWOPASS)[0] for d in files]
+    assert not np.array_equal(first[0][~np.isnan(first[0])], first[1][~np.isnan(first[1])])
+    for rep in range(6):
+        for f, d in enumerate(files):
+            again = score_gt2x(dev, n, kw, d, 0.0, mode=capi.MODE_TWOPASS)[0]
+            assert np.array_equal(again.view(np.int64), first[f].view(np.int64)), "launch %d of file %d" % (rep, f)
+    dev.close()
+
+
 @pytest.mark.parametrize("shape,mode", [((70000, 4000), capi.MODE_FUSED), ((3000, 60000), capi.MODE_FUSED),
                                         ((70000, 4000), capi.MODE_TWOPASS)])
 def test_gt2x_row_teams_bit_reproducible(shape, mode):

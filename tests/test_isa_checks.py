@@ -42,41 +42,56 @@ def vgprs(text):
 
 
 def check_windows(lines, issue_re, what):
-    """for every asm-issued operation matching issue_re: its destination registers are not named again before the next
-    hand-written (inside an ASM block) vmcnt wait; returns the number of operations checked"""
-    in_asm, n = False, 0
-    i = 0
-    while i < len(lines):
-        ln = lines[i]
+    """for every asm-issued operation matching issue_re: its destination registers are not named again until the
+    hand-written (inside an ASM block) vmcnt wait that follows has gone by -- and, where the source has one wait statement
+    per branch, until the second one has: the compiler lays the two blocks out one behind the other with nothing but
+    exec-mask bookkeeping between them, so a wait block that starts within a dozen lines of the previous one belongs to the
+    same site and the walk goes on through it.  Returns the number of operations checked."""
+    def is_wait_block(k):     # lines[k] is an ASMSTART line: does the block hold a vmcnt wait?  -> (yes, index of its ASMEND)
+        e = k + 1
+        hit = False
+        while e < len(lines) and "#ASMEND" not in lines[e]:
+            hit = hit or re.search(r"s_waitcnt\s+vmcnt\(", lines[e]) is not None
+            e += 1
+        return hit, e
+
+    n = 0
+    in_asm = False
+    for i, ln in enumerate(lines):
         if "#ASMSTART" in ln:
             in_asm = True
         elif "#ASMEND" in ln:
             in_asm = False
         m = issue_re.search(ln) if in_asm else None
-        if m:
-            dest = vgprs(m.group(1))
-            assert dest, ln
-            j, asm_j, found = i + 1, True, False
-            while j < len(lines):
-                t = lines[j]
-                if "#ASMSTART" in t:
-                    asm_j = True
-                elif "#ASMEND" in t:
-                    asm_j = False
-                elif t.strip().startswith(".Lfunc_end") or t.strip().startswith(".section"):
-                    break
-                elif asm_j and re.search(r"s_waitcnt\s+vmcnt\(", t):
-                    found = True
-                    break
-                else:
-                    code = t.split(";")[0]
-                    hit = dest & vgprs(code)
-                    assert not hit, ("%s: line %d touches v%s between the asm-issued operation at line %d (%s) and its "
-                                     "hand-written wait:\n%s" % (what, j + 1, sorted(hit), i + 1, ln.strip(), t))
-                j += 1
-            assert found, "%s: no hand-written vmcnt wait follows line %d (%s)" % (what, i + 1, ln.strip())
-            n += 1
-        i += 1
+        if not m:
+            continue
+        dest = vgprs(m.group(1))
+        assert dest, ln
+        j, waits = i + 1, 0
+        while j < len(lines) and "#ASMEND" not in lines[j]:   # (the rest of the issuing block)
+            j += 1
+        j += 1
+        while j < len(lines):
+            t = lines[j]
+            if t.strip().startswith(".Lfunc_end") or t.strip().startswith(".section"):
+                break
+            if "#ASMSTART" in t:
+                hit, e = is_wait_block(j)
+                if hit:
+                    waits += 1
+                    # another wait block of the same site right behind this one?
+                    nxt = [k for k in range(e + 1, min(e + 14, len(lines))) if "#ASMSTART" in lines[k] and is_wait_block(k)[0]]
+                    if not nxt:
+                        break
+                j = e + 1
+                continue
+            code = t.split(";")[0]
+            hit = dest & vgprs(code)
+            assert not hit, ("%s: line %d touches v%s between the asm-issued operation at line %d (%s) and its hand-written "
+                             "wait(s):\n%s" % (what, j + 1, sorted(hit), i + 1, ln.strip(), t))
+            j += 1
+        assert waits, "%s: no hand-written vmcnt wait follows line %d (%s)" % (what, i + 1, ln.strip())
+        n += 1
     return n
 
 
