@@ -224,7 +224,7 @@ def score_delta(stats, got, nloci, fmt, beta, eaf, seed, n, m, th, tm, tmi, geom
         (ref_score_subset: decode, the maxmis decision, imputeLocus/SampleDosages, accumulate in row
         order), fed with each row's whole-row tally."""
     from oracle import refcpu
-    is_ds = fmt == "ds"
+    is_ds = 2 if fmt == "ds16" else (1 if fmt == "ds" else 0)   # (2: the NPS_FMT_DS16 generator of the oracle)
     slices, teams, sps = geometry
     samples, n_slices, n_cols = cover_columns(8 if is_ds else 16, n, sps if sps else (960 * 16))
     rng = np.random.default_rng(seed + 7)
@@ -491,7 +491,7 @@ def given_tallies(capi, sc, cohort, sdef, d_scores, n, m, headline_ms, steps=5):
             "passes_after_which_it_pays": (keep_s * 1e3) / max(headline_ms - best, 1e-9) if best < headline_ms else None}
 
 
-def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=20250105):
+def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=20250105, half=False):
     """BASELINE.json configs[4] at its stated size on ONE GPU: 2 000 000 x 200 000 float32 dosages are
     1.6 TB, so the rows are scored in resident chunks; each chunk is regenerated on the device (outside the
     timed segments), the partial scores and nloci carry across chunks inside the context, the timed
@@ -499,9 +499,10 @@ def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=2
     beta, eaf, miss = synth_score(m, seed, "ds")
     th, tm, tmi = hwe_thresholds(eaf, miss)
     chunk = min(chunk, m)
-    co = capi.Cohort(n, chunk, fmt=capi.FMT_DS32, device=device)
+    fmt = capi.FMT_DS16 if half else capi.FMT_DS32
+    co = capi.Cohort(n, chunk, fmt=fmt, device=device)
     sc = capi.Scorer(n, capi.make_params(imp_locus="ps"), device=device)
-    geo = sc.fused_geometry(chunk, capi.FMT_DS32)
+    geo = sc.fused_geometry(chunk, fmt)
     sc.profile_enable(True)
     sc.profile_get(reset=True)
     wall = 0.0
@@ -526,10 +527,13 @@ def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=2
     sc.close()
     co.close()
     hot_ms = prof.ms_tally + prof.ms_params + prof.ms_accumulate + prof.ms_fused
-    alg = 4 * m * n + 40 * m + 8 * n
-    out = {"workload": "synthetic %d-variant PRS on %d-sample float32 FORMAT/DS matrix (BASELINE.json "
-                       "configs[4], 1.6 TB) in %d resident chunks of %d rows, 5 %% mean missingness, "
-                       "--imp-locus=ps" % (m, n, (m + chunk - 1) // chunk, chunk),
+    alg = (2 if half else 4) * m * n + 40 * m + 8 * n
+    out = {"workload": ("synthetic %d-variant PRS on %d-sample FORMAT/DS matrix held as NPS_FMT_DS16 (2 bytes per dosage: "
+                        "three-decimal values, lossless; a NEW configuration beside configs[4], which stays float32) in %d "
+                        "resident chunk(s) of %d rows, 5 %% mean missingness, --imp-locus=ps" if half else
+                        "synthetic %d-variant PRS on %d-sample float32 FORMAT/DS matrix (BASELINE.json "
+                        "configs[4], 1.6 TB) in %d resident chunks of %d rows, 5 %% mean missingness, "
+                        "--imp-locus=ps") % (m, n, (m + chunk - 1) // chunk, chunk),
            "value": n * m / wall, "unit": "genotype-dosage accumulations/s", "wall_s_scoring": wall,
            "kernel_ms": hot_ms, "nloci": int(nloci),
            "roofline": {"bound": "hbm", "achieved": alg / (hot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -540,7 +544,7 @@ def ds_config5(capi, device, args, n=200_000, m=2_000_000, chunk=300_000, seed=2
         # the last chunk's rows stand for the matrix in the full-width recount (its generator rows are
         # the global row numbers, so any row can be recounted); all rows are scored for the subset
         from oracle import refcpu
-        out["score_delta_vs_reference"] = score_delta(st, got, nloci, "ds", beta, eaf, seed, n, m, th, tm, tmi,
+        out["score_delta_vs_reference"] = score_delta(st, got, nloci, "ds16" if half else "ds", beta, eaf, seed, n, m, th, tm, tmi,
                                                       geo, recount=300, params=refcpu.make_params("ps"))
     return out
 
@@ -1347,6 +1351,8 @@ def main():
             leg("layout_sweep", lambda: layout_sweep(capi, local_rank, n, m, args.seed, full=args.full_sweeps))
             leg("size_sweep", lambda: size_sweep(capi, local_rank, args, args.seed, full=args.full_sweeps))
             leg("config5_ds", lambda: ds_config5(capi, local_rank, args))
+            # the same cohort shape at 2 bytes per dosage, one resident chunk of 600 000 rows (240 GB of float32 in 120 GB)
+            leg("config5_ds16", lambda: ds_config5(capi, local_rank, args, m=600_000, chunk=600_000, half=True))
             leg("multi_score", multi_leg)
             leg("streaming", lambda: streaming_rates(capi, local_rank, n, args.seed))
             leg("config2", config2_leg)

@@ -262,6 +262,17 @@ void nps_destroy(nps_ctx *ctx);
  * the matrix twice, every later run once, at a speed that does not depend on the genotypes.  (Until round 4 these sizes
  * got NPS_FMT_GT2, whose table-lookup kernel runs at 0.47 .. 0.63 of the roofline depending on the genotypes.) */
 #define NPS_FMT_GT_AUTO 4
+/* Dosages in 2 bytes per genotype (round 5): k = dosage x 10^4 as uint16, 0 <= k <= 20 000, 0xFFFF = missing.  FORMAT/DS
+ * values are decimal text with one to four places (Beagle, minimac, IMPUTE): for every such value in [0, 2] the float32 a
+ * parser makes of the text is float32(double(k) x 1e-4), so the format is LOSSLESS for them and the kernel computes with
+ * exactly the numbers a NPS_FMT_DS32 cohort of the same file would hold -- at half the bytes.  Towards the host the format
+ * looks like NPS_FMT_DS32: nps_cohort_upload takes float32 rows (NaN = missing) and returns NPS_E_UNSUPPORTED, naming the
+ * row, if a row holds a value no k stands for (the rows of the call's range are undefined after that: use NPS_FMT_DS32);
+ * nps_cohort_download gives float32 rows back; nps_cohort_synth[_rows] fills rows with three-decimal values.  Scored by
+ * nps_score_cohort[_def] under NPS_MODE_AUTO / NPS_MODE_FUSED with the single-read kernel only: a shape beyond its resident
+ * grid, or NPS_MODE_TWOPASS, returns NPS_E_UNSUPPORTED.  Like all of FORMAT/DS a build-defined extension (the reference
+ * decodes GT only). */
+#define NPS_FMT_DS16 5
 
 int nps_cohort_create(nps_cohort **out, int device, uint64_t n_samples, uint64_t n_rows,
                       int format);

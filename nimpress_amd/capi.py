@@ -20,7 +20,7 @@ MISSING = {"homref": 0, "ignore": 1}
 SAMPLE = {"ps": 0, "homref": 1, "fail": 2, "int_ps": 3, "int_fail": 4}
 ROW_PRESENT, ROW_UNCOVERED, ROW_ABSENT, ROW_FILTERED = 0, 1, 2, 3
 REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMIS = range(5)
-FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X, FMT_GT_AUTO = 0, 1, 2, 3, 4
+FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X, FMT_GT_AUTO, FMT_DS16 = 0, 1, 2, 3, 4, 5
 ROW_NOT_IN_SCORE = 4
 MULTI_MAX_SCORES = 8
 MODE_AUTO, MODE_TWOPASS, MODE_FUSED, MODE_FUSED_EAGER = 0, 1, 2, 3
@@ -220,7 +220,7 @@ def device_count() -> int:
 
 class Cohort:
     """A genotype matrix resident in HBM, variant-major / sample-minor: 2-bit GT codes (FMT_GT2) or
-    float32 dosages with NaN = missing (FMT_DS32)."""
+    float32 dosages with NaN = missing (FMT_DS32; FMT_DS16 holds them as 16-bit decimals and looks the same from here)."""
 
     def __init__(self, n_samples: int, n_rows: int, device: int = 0, fmt: int = FMT_GT2):
         self._h = C.c_void_p()
@@ -235,8 +235,11 @@ class Cohort:
     def upload(self, row0: int, rows: np.ndarray):
         rows = np.ascontiguousarray(rows)
         assert rows.ndim == 2
-        _check(load().nps_cohort_upload(self._h, row0, rows.shape[0], rows.ctypes.data,
-                                        rows.strides[0]))
+        if self.fmt in (FMT_DS32, FMT_DS16):
+            assert rows.dtype == np.float32
+        # (a leading axis of length 1 made by rows[None, :] has stride 0: the row's own width is what is meant)
+        stride = rows.strides[0] if rows.shape[0] > 1 else rows.shape[1] * rows.itemsize
+        _check(load().nps_cohort_upload(self._h, row0, rows.shape[0], rows.ctypes.data, stride))
 
     def upload_bed(self, row0: int, bed_rows: np.ndarray, effect_is_a1):
         """rows of a PLINK .bed file ([k, ceil(n/4)] uint8, e.g. a view of the mmap'ed file)"""
@@ -247,7 +250,7 @@ class Cohort:
                                             bed_rows.strides[0], flags.ctypes.data))
 
     def download(self, row0: int, nrows: int) -> np.ndarray:
-        if self.fmt == FMT_DS32:
+        if self.fmt in (FMT_DS32, FMT_DS16):
             width, dtype = self.n_samples, np.float32
         else:
             width, dtype = (self.n_samples + 15) // 16, np.uint32

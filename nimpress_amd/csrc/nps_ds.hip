@@ -270,6 +270,98 @@ __global__ __launch_bounds__(256) void synth_ds_kernel(float *__restrict__ ds, u
     ds[(row0 + r) * stride_f + i] = d;
 }
 
+// ---- NPS_FMT_DS16 ----------------------------------------------------------------------------
+// k <-> float32: the value of code k is float32(k / 10^4), correctly rounded -- what strtof gives for the decimal text -- for
+// every k in 0 .. 20 000; 0xFFFF is a missing dosage.
+// (ds16_value: nps_kernels.h)
+
+// device copy of ref_synth_ds16 (oracle/refcpu.c): the genotype's dosage plus a decimal "imputation noise" of up to
+// +-0.508 in steps of 0.004, clipped to [0, 2] -- values with at most three decimals, as an imputation tool prints them
+__global__ __launch_bounds__(256) void synth_ds16_kernel(uint16_t *__restrict__ ds, uint64_t stride_e, uint64_t n, uint64_t row0,
+                                                         uint64_t gen_row0, uint64_t seed, const uint32_t *__restrict__ t_het,
+                                                         const uint32_t *__restrict__ t_hom,
+                                                         const uint32_t *__restrict__ t_miss) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r = blockIdx.y;
+    if (i >= n) return;
+    const uint64_t h = mix64(mix64(seed ^ ((gen_row0 + r) * 0xD1B54A32D192ED03ull)) + i);
+    const uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
+    uint32_t k;
+    if (ms < t_miss[r]) {
+        k = 0xffffu;
+    } else {
+        const int c = g < t_hom[r] ? 2 : (g < t_het[r] ? 1 : 0);
+        const int noise = (int)((ms >> 8) & 255u) - 128;
+        const int v = c * 10000 + noise * 40;
+        k = (uint32_t)(v < 0 ? 0 : (v > 20000 ? 20000 : v));
+    }
+    ds[(row0 + r) * stride_e + i] = (uint16_t)k;
+}
+
+// one workgroup per row: float32 -> k; a value that is neither NaN nor the value of some k marks the row
+__global__ __launch_bounds__(256) void ds16_pack_kernel(const float *__restrict__ src, uint64_t src_stride_f, uint64_t n,
+                                                        uint16_t *__restrict__ dst, uint64_t dst_stride_e,
+                                                        unsigned char *__restrict__ bad) {
+    const float *in = src + (uint64_t)blockIdx.x * src_stride_f;
+    uint16_t *out = dst + (uint64_t)blockIdx.x * dst_stride_e;
+    bool b = false;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = in[i];
+        uint32_t k = 0xffffu;
+        if (v == v) {
+            const double x = (double)v * 1e4;
+            k = x >= 0.0 && x <= 20000.5 ? (uint32_t)__double2ll_rn(x) : 0xfffeu;
+            if (k > 20000u || __float_as_uint(ds16_value(k)) != __float_as_uint(v)) {  // (-0.0 is refused too: its bits differ)
+                b = true;
+                k = 0u;
+            }
+        }
+        out[i] = (uint16_t)k;
+    }
+    const int any = __syncthreads_or(b ? 1 : 0);
+    if (threadIdx.x == 0) bad[blockIdx.x] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ds16_unpack_kernel(const uint16_t *__restrict__ src, uint64_t src_stride_e, uint64_t n,
+                                                          float *__restrict__ dst, uint64_t dst_stride_f) {
+    const uint16_t *in = src + (uint64_t)blockIdx.x * src_stride_e;
+    float *out = dst + (uint64_t)blockIdx.x * dst_stride_f;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t k = in[i];
+        out[i] = k == 0xffffu ? __int_as_float(0x7fc00000) : ds16_value(k);
+    }
+}
+
+hipError_t launch_synth_ds16(hipStream_t st, uint16_t *d_ds, uint64_t stride_e, uint64_t n, uint64_t row0, uint64_t gen_row0,
+                             uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                             const uint32_t *d_t_miss) {
+    if (n_rows == 0 || n == 0) return hipSuccess;
+    if (n_rows > 65535) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_ds16_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)n_rows), dim3(256), 0, st, d_ds,
+                       stride_e, n, row0, gen_row0, seed, d_t_het, d_t_hom, d_t_miss);
+    return hipGetLastError();
+}
+
+hipError_t launch_ds16_pack(hipStream_t st, const float *d_src, uint64_t src_stride_f, uint64_t n, uint64_t n_rows,
+                            uint16_t *d_dst, uint64_t dst_stride_e, unsigned char *d_bad) {
+    if (n_rows == 0) return hipSuccess;
+    if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ds16_pack_kernel, dim3((uint32_t)n_rows), dim3(256), 0, st, d_src, src_stride_f, n, d_dst, dst_stride_e,
+                       d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_ds16_unpack(hipStream_t st, const uint16_t *d_src, uint64_t src_stride_e, uint64_t n, uint64_t n_rows,
+                              float *d_dst, uint64_t dst_stride_f) {
+    if (n_rows == 0) return hipSuccess;
+    if (n_rows > 0x7fffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ds16_unpack_kernel, dim3((uint32_t)n_rows), dim3(256), 0, st, d_src, src_stride_e, n, d_dst, dst_stride_f);
+    return hipGetLastError();
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 hipError_t launch_ds_tally(hipStream_t st, const float *d_ds, uint64_t stride_f, uint64_t n,
                            const nps_row_desc *d_desc, uint64_t n_rows, DsTally *d_tally) {

@@ -32,12 +32,15 @@
 // from the oracle's sequential sum in the last bits only (test bar 1e-9 relative).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "nps_kernels.h"
 
 namespace nps {
 
-constexpr int kDsRows = 2;     // rows per batch
+constexpr int kDsRows = 2;     // rows per batch (float32 rows)
+constexpr int kDsRows16 = 2;   // ... of 16-bit rows (four would halve the hand-overs per row; the ring of 6 x 4 rows does not fit 128 VGPRs: 292 bytes spilled)
+constexpr int kDsRowsMax = 4;
 constexpr int kDsPerThread = 8;
 constexpr int kDsRing = 6;     // batches held per data thread: one accumulated, four tallied and waiting for the hand-over, one on its way
 // workgroup size T: wave 0 is the control wave, T/64 - 1 data waves of 512 samples each
@@ -45,8 +48,8 @@ static constexpr uint32_t ds_slice_samples(int threads) { return (uint32_t)(thre
 constexpr uint32_t kDsSpinLimit = 1u << 20;
 
 struct DsFusedArgs {
-    const float *ds;
-    uint64_t stride_f;
+    const void *ds;         // float32 rows, or (H) uint16 rows of NPS_FMT_DS16
+    uint64_t stride_bytes;  // bytes from one row to the next
     uint64_t n_rows;
     uint64_t n_samples;
     uint32_t n_batches;
@@ -68,9 +71,9 @@ struct DsRowLds {
     int32_t flip;      // dosage = 2 - DS
 };
 struct __attribute__((aligned(16))) DsFusedLds {
-    double wsum[2][kDsRows][16];
-    uint32_t wcnt[2][kDsRows][16];
-    DsRowLds rowp[2][kDsRows];
+    double wsum[2][kDsRowsMax][16];
+    uint32_t wcnt[2][kDsRowsMax][16];
+    DsRowLds rowp[2][kDsRowsMax];
 };
 
 // wave sum by DPP (row_shr 1,2,4,8, then row_bcast15 / row_bcast31): fixed order, total in lane 63.
@@ -106,10 +109,14 @@ __device__ unsigned long long g_ds_timers[2][8];
 #else
 #define DST(i) do { } while (0)
 #endif
-template <int T>
+// H: a NPS_FMT_DS16 cohort -- 2 bytes per genotype: k = dosage x 10^4 (0 .. 20 000), 0xFFFF = missing.  A thread holds
+// eight NEIGHBOURING samples (one 16-byte load per row) and turns k back into the float32 a decimal parser gives for the
+// text -- ds16_value(k), nps_kernels.h -- wherever the float32
+// kernel reads a value: the arithmetic after that is the float32 kernel's, operation for operation.
+template <int T, bool H>
 __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     constexpr uint32_t kDsSliceSamples = ds_slice_samples(T);
-    constexpr int R = kDsRows, D = kDsRing;
+    constexpr int R = H ? kDsRows16 : kDsRows, D = kDsRing;
     __shared__ DsFusedLds lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -309,54 +316,94 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     }
 
     // ---------------------------------------------------------------------- data waves
-    // samples of this thread: s0 + 0..3 and s0 + 256 + 0..3
-    const uint32_t s0 = slice * kDsSliceSamples + (uint32_t)(wave - 1) * 512u + (uint32_t)lane * 4u;
-    const uint32_t voff = s0 * 4u;
+    // samples of this thread: s0 + 0..3 and s0 + 256 + 0..3 (H: s0 + 0..7)
+    const uint32_t s0 = slice * kDsSliceSamples + (uint32_t)(wave - 1) * 512u + (uint32_t)lane * (H ? 8u : 4u);
+    const uint32_t voff = s0 * (H ? 2u : 4u);
     // clamp so that the descriptor range (bytes of one row) stays below 4 GiB
-    const uint32_t row_bytes = (uint32_t)min(a.n_samples * 4ull, 0xfffffff0ull);
-    const uint64_t stride_bytes = a.stride_f * 4ull;
+    // (the range is checked dword by dword: an odd number of 16-bit codes is rounded up -- the row is zero padded)
+    const uint32_t row_bytes = (uint32_t)min(H ? (a.n_samples * 2ull + 3ull) & ~3ull : a.n_samples * 4ull, 0xfffffff0ull);
+    const uint64_t stride_bytes = a.stride_bytes;
 
     double acc[kDsPerThread];
 #pragma unroll
     for (int s = 0; s < kDsPerThread; ++s) acc[s] = 0.0;
-    float ring[D][R * kDsPerThread];
+    constexpr int kRW = H ? 4 : 8;  // ring words per row and thread
+    // (the float32 kernel sits at exactly 128 VGPRs without a spill: its ring stays an array of floats and its expressions
+    //  stay what they were before the 16-bit variant existed -- kept as uint32 with casts at the uses it spilled 80 bytes
+    //  per lane and took 61 ms instead of 38)
+    typedef typename std::conditional<H, uint32_t, float>::type RingE;
+    typedef RingE RingT[R * kRW];
+    RingT ring[D];
 
-    // row r of batch k -> dst[8r .. 8r+7]; rows past the end of the matrix read as zeros (range 0)
-    auto load_row = [&](uint32_t k, int r, float(&dst)[R * kDsPerThread]) {
+    // row r of batch k -> dst[kRW r ..]; rows past the end of the matrix read as zeros (range 0: dosage 0, not missing)
+    auto load_row = [&](uint32_t k, int r, RingT &dst) {
         const uint64_t row = batch_row0(k) + r;
         const bool in = k < n_local && row < a.n_rows;
         const char *p = reinterpret_cast<const char *>(a.ds) + (in ? row : 0) * stride_bytes;
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, in ? row_bytes : 0u, 0x00020000);
         const auto qa = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 2);
-        const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 2);
+        if constexpr (H) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            dst[r * 8 + s] = __uint_as_float(qa[s]);
-            dst[r * 8 + 4 + s] = __uint_as_float(qb[s]);
+            for (int s = 0; s < 4; ++s) dst[r * kRW + s] = qa[s];
+        } else {
+            const auto qb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024u, 0, 2);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                dst[r * 8 + s] = __uint_as_float(qa[s]);
+                dst[r * 8 + 4 + s] = __uint_as_float(qb[s]);
+            }
         }
     };
-    auto load_batch = [&](uint32_t k, float(&dst)[R * kDsPerThread]) {
+    auto load_batch = [&](uint32_t k, RingT &dst) {
 #pragma unroll
         for (int r = 0; r < R; ++r) load_row(k, r, dst);
     };
+    // (H) elements 2p, 2p + 1 of row r of a ring slot -- the two halves of one word: whether they are missing, and their
+    // float32 values (meaningless if they are): ds16_value of nps_kernels.h on a pair (v_pk_mul_f32 / v_pk_fma_f32)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto pair = [&](const RingT &src, int r, int p, f2 &v, bool &nan0, bool &nan1) {
+        const uint32_t w = (uint32_t)src[r * kRW + p];
+        const uint32_t k0 = w & 0xffffu, k1 = w >> 16;
+        nan0 = k0 == 0xffffu;
+        nan1 = k1 == 0xffffu;
+        const f2 a = {(float)k0, (float)k1};
+        const f2 c1 = {9.999999747378752e-05f, 9.999999747378752e-05f}, c2 = {2.5262125290942405e-12f, 2.5262125290942405e-12f};
+        v = __builtin_elementwise_fma(a, c1, a * c2);
+    };
 
     // partial tally of a batch: NaN count of the wave by ballot (SALU), dosage sum by a fixed tree
-    auto tally = [&](uint32_t k, const float(&src)[R * kDsPerThread]) {
+    auto tally = [&](uint32_t k, const RingT &src) {
         const int par = k & 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t cnt = 0;
             double s = 0.0;
+            if constexpr (H) {
 #pragma unroll
-            for (int e = 0; e < kDsPerThread; ++e) {
-                const float v = src[r * 8 + e];
-                const bool nan = v != v;
-                cnt += (uint32_t)__popcll(__ballot(nan));
-                s += (double)(nan ? 0.0f : v);
-                if ((e & 3) == 3) {
-                    asm volatile("" : "+v"(s));
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int p = 0; p < 4; ++p) {
+                    f2 v;
+                    bool n0, n1;
+                    pair(src, r, p, v, n0, n1);
+                    cnt += (uint32_t)__popcll(__ballot(n0)) + (uint32_t)__popcll(__ballot(n1));
+                    s += (double)(n0 ? 0.0f : v[0]);
+                    s += (double)(n1 ? 0.0f : v[1]);
+                    if (p & 1) {
+                        asm volatile("" : "+v"(s));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < kDsPerThread; ++e) {
+                    const float v = src[r * 8 + e];
+                    const bool nan = v != v;
+                    cnt += (uint32_t)__popcll(__ballot(nan));
+                    s += (double)(nan ? 0.0f : v);
+                    if ((e & 3) == 3) {
+                        asm volatile("" : "+v"(s));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             s = wave_dpp_sum(s);
@@ -371,7 +418,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     // score += dosage * beta, row after row (nimpress.nim:639-641).  Branch-free: dosage =
     // c0 + sgn * DS with (c0, sgn) = (0, 1) or (2, -1) -- one rounding, equal to DS and 2 - DS -- and
     // the row's `all` flag (locus constant, or dropped row with beta = imp = 0) ORed into the NaN mask.
-    auto accumulate = [&](uint32_t k, const float(&cur)[R * kDsPerThread]) {
+    auto accumulate = [&](uint32_t k, const RingT &cur) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const DsRowLds &rp = lds.rowp[k & 1][r];
@@ -379,20 +426,37 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
             const bool all = __builtin_amdgcn_readfirstlane(rp.mode) != 1;
             const bool flip = __builtin_amdgcn_readfirstlane(rp.flip) != 0;
             const double c0 = flip ? 2.0 : 0.0, sgn = flip ? -1.0 : 1.0;
+            if constexpr (H) {
+                // (a wave-uniform branch per row instead of the fma -- seven rows in ten need no dosage instruction -- and the
+                //  decode on pairs changed nothing: 45 ms either way; see DESIGN.md 4.4 for what bounds this variant)
 #pragma unroll
-            for (int e = 0; e < kDsPerThread; ++e) {
-                const float v = cur[r * 8 + e];
-                const double d = (v != v) || all ? imp : __fma_rn((double)v, sgn, c0);
-                acc[e] += d * beta;
-                if (e & 1) {  // two elements at a time: keeps the converted values out of the ring's way
-                    asm volatile("" : "+v"(acc[e - 1]), "+v"(acc[e]));
+                for (int p = 0; p < 4; ++p) {
+                    f2 v;
+                    bool n0, n1;
+                    pair(cur, r, p, v, n0, n1);
+                    const double d0 = n0 || all ? imp : __fma_rn((double)v[0], sgn, c0);
+                    const double d1 = n1 || all ? imp : __fma_rn((double)v[1], sgn, c0);
+                    acc[2 * p] += d0 * beta;
+                    acc[2 * p + 1] += d1 * beta;
+                    asm volatile("" : "+v"(acc[2 * p]), "+v"(acc[2 * p + 1]));
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < kDsPerThread; ++e) {
+                    const float v = cur[r * 8 + e];
+                    const double d = (v != v) || all ? imp : __fma_rn((double)v, sgn, c0);
+                    acc[e] += d * beta;
+                    if (e & 1) {  // two elements at a time: keeps the converted values out of the ring's way
+                        asm volatile("" : "+v"(acc[e - 1]), "+v"(acc[e]));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
     };
 
-    auto step = [&](uint32_t k, float(&r_cur)[R * kDsPerThread], const float(&r_tal)[R * kDsPerThread]) {
+    auto step = [&](uint32_t k, RingT &r_cur, const RingT &r_tal) {
         DST(7);
         accumulate(k, r_cur);
         DST(0);
@@ -437,7 +501,7 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
     double *dst = a.part + (uint64_t)team * a.part_team_stride;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const uint64_t s = (uint64_t)s0 + 256u * h;
+        const uint64_t s = (uint64_t)s0 + (H ? 4u : 256u) * h;
         if (s < a.n_samples) {  // part_team_stride is padded: whole groups of 4 can be written
             *reinterpret_cast<double2 *>(dst + s) = make_double2(acc[4 * h], acc[4 * h + 1]);
             *reinterpret_cast<double2 *>(dst + s + 2) = make_double2(acc[4 * h + 2], acc[4 * h + 3]);
@@ -450,7 +514,7 @@ template <int T>
 static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, int max_q, FusedPlan *plan) {
     *plan = FusedPlan{};
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel<T>, T, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ds_fused_kernel<T, false>, T, 0);
     if (e != hipSuccess) return e;
     if (per_cu < 1) return hipSuccess;
     const uint64_t slice = ds_slice_samples(T);
@@ -469,7 +533,7 @@ static hipError_t ds_plan_for(int cus, uint64_t n_samples, uint64_t n_batches, i
 }
 
 hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want, int max_q,
-                         FusedPlan *plan) {
+                         FusedPlan *plan, int elem_bytes) {
     *plan = FusedPlan{};
     if (n_samples == 0 || n_rows == 0 || n_samples >= (1ull << 27)) return hipSuccess;  // 28-bit tally fields
     hipDeviceProp_t prop;
@@ -477,7 +541,8 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int wa
     if (e != hipSuccess) return e;
     const int cus = prop.multiProcessorCount;
     if (cus < 1) return hipSuccess;
-    const uint64_t n_batches = (n_rows + kDsRows - 1) / kDsRows;
+    const uint64_t rows_per_batch = elem_bytes == 2 ? kDsRows16 : kDsRows;
+    const uint64_t n_batches = (n_rows + rows_per_batch - 1) / rows_per_batch;
     if (n_batches > 0xfffffff0ull) return hipSuccess;
     // as for the GT kernel: the most teams first, then the smallest workgroup that still gives that many
     const int candidates[3] = {1024, 960, 896};
@@ -493,14 +558,16 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int wa
     return hipSuccess;
 }
 
-hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
+hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const void *d_ds, uint64_t stride_bytes, int elem_bytes,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
                            DevParams prm, unsigned long long *d_tally,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout) {
+    if (elem_bytes != 4 && elem_bytes != 2) return hipErrorInvalidValue;
+    const bool half = elem_bytes == 2;
     DsFusedArgs a;
     a.ds = d_ds;
-    a.stride_f = stride_f;
+    a.stride_bytes = stride_bytes;
     a.n_rows = n_rows;
     a.n_samples = n_samples;
     a.n_batches = plan.n_batches;
@@ -522,9 +589,12 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d
     a.timeout = d_timeout;
     void *args[] = {&a};
     // cooperative launch: the runtime rejects a grid that cannot be fully resident
-    const void *fn = plan.threads == 1024  ? (const void *)ds_fused_kernel<1024>
-                     : plan.threads == 960 ? (const void *)ds_fused_kernel<960>
-                                           : (const void *)ds_fused_kernel<896>;
+    const void *fn = half ? (plan.threads == 1024  ? (const void *)ds_fused_kernel<1024, true>
+                             : plan.threads == 960 ? (const void *)ds_fused_kernel<960, true>
+                                                   : (const void *)ds_fused_kernel<896, true>)
+                          : (plan.threads == 1024  ? (const void *)ds_fused_kernel<1024, false>
+                             : plan.threads == 960 ? (const void *)ds_fused_kernel<960, false>
+                                                   : (const void *)ds_fused_kernel<896, false>);
 #ifdef NPS_DS_TIMERS
     {
         hipError_t e = hipLaunchCooperativeKernel(fn, dim3(plan.P, plan.Q), dim3(plan.threads), args, 0, st);

@@ -970,7 +970,7 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     if (!out) return fail(NPS_E_INVAL, "out is NULL");
     *out = nullptr;
     if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2M && format != NPS_FMT_GT2X &&
-        format != NPS_FMT_GT_AUTO)
+        format != NPS_FMT_GT_AUTO && format != NPS_FMT_DS16)
         return fail(NPS_E_INVAL, "unknown cohort format %d", format);
     if (n_samples > 0x7fffffffull) return fail(NPS_E_UNSUPPORTED, "n_samples too large");
     int rc = select_device(device);
@@ -991,8 +991,9 @@ extern "C" int nps_cohort_create(nps_cohort **out, int device, uint64_t n_sample
     c->format = format;
     c->n_samples = n_samples;
     c->n_rows = n_rows;
-    c->stride_bytes = format == NPS_FMT_DS32 ? ds_stride_floats(n_samples) * 4
-                                              : stride_words_for(n_samples) * 4;
+    c->stride_bytes = format == NPS_FMT_DS32   ? ds_stride_floats(n_samples) * 4
+                      : format == NPS_FMT_DS16 ? ds_stride_floats(n_samples) * 2  // (a multiple of 128 bytes)
+                                               : stride_words_for(n_samples) * 4;
     const uint64_t rows_alloc = format == NPS_FMT_GT2 ? (n_rows + 3) / 4 * 4 : n_rows;
     uint64_t bytes = std::max<uint64_t>(c->stride_bytes * rows_alloc, 256);
     if (format == NPS_FMT_GT2M) {
@@ -1273,6 +1274,50 @@ extern "C" int nps_cohort_push_bed(nps_cohort *c, uint64_t row, const uint8_t *b
     return NPS_OK;
 }
 
+// NPS_FMT_DS16 <-> float32 rows of the host, through a float32 staging buffer of at most 256 MiB.  Upload: a row that holds
+// a value which is not the value of a code (a decimal with at most four places in [0, 2], as float32) is REFUSED -- the
+// format is lossless or it is not used; the rows of the range are undefined after a refusal.
+static int ds16_transfer(nps_cohort *c, uint64_t row0, uint64_t nrows, void *host_rows, size_t host_stride, bool upload) {
+    const uint64_t stride_f = ds_stride_floats(c->n_samples), stride_e = c->stride_bytes / 2;
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nrows, (256ull << 20) / (stride_f * 4)));
+    float *d_stage = nullptr;
+    unsigned char *d_bad = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, chunk * stride_f * 4));
+    if (hipMalloc(&d_bad, chunk) != hipSuccess) {
+        (void)hipFree(d_stage);
+        return fail(NPS_E_NOMEM, "hipMalloc failed");
+    }
+    std::vector<unsigned char> bad(chunk);
+    hipError_t e = hipSuccess;
+    long long first_bad = -1;
+    for (uint64_t r = 0; r < nrows && e == hipSuccess && first_bad < 0; r += chunk) {
+        const uint64_t k = std::min(chunk, nrows - r);
+        uint16_t *rows = (uint16_t *)c->d_data + (row0 + r) * stride_e;
+        char *host = (char *)host_rows + r * host_stride;
+        if (upload) {
+            e = hipMemcpy2D(d_stage, stride_f * 4, host, host_stride, c->n_samples * 4, k, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = launch_ds16_pack(nullptr, d_stage, stride_f, c->n_samples, k, rows, stride_e, d_bad);
+            if (e == hipSuccess) e = hipMemcpy(bad.data(), d_bad, k, hipMemcpyDeviceToHost);
+            for (uint64_t j = 0; j < k && e == hipSuccess; ++j)
+                if (bad[j]) {
+                    first_bad = (long long)(row0 + r + j);
+                    break;
+                }
+        } else {
+            e = launch_ds16_unpack(nullptr, rows, stride_e, c->n_samples, k, d_stage, stride_f);
+            if (e == hipSuccess)
+                e = hipMemcpy2D(host, host_stride, d_stage, stride_f * 4, c->n_samples * 4, k, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_stage);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(NPS_E_HIP, "NPS_FMT_DS16 transfer failed: %s", hipGetErrorString(e));
+    if (first_bad >= 0)
+        return fail(NPS_E_UNSUPPORTED, "row %lld holds a FORMAT/DS value that is not a decimal with at most four places in "
+                    "[0, 2]: NPS_FMT_DS16 stores such values only (losslessly); use a NPS_FMT_DS32 cohort", first_bad);
+    return NPS_OK;
+}
+
 extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, const void *host_rows,
                                  size_t host_stride) {
     int rc = check_range(c, row0, nrows);
@@ -1280,12 +1325,14 @@ extern "C" int nps_cohort_upload(nps_cohort *c, uint64_t row0, uint64_t nrows, c
     if (c->format == NPS_FMT_GT2M)
         return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are filled by nps_cohort_convert (from a "
                                        "NPS_FMT_GT2 cohort) or by the synthetic generator");
-    const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
+    const bool ds_any = c->format == NPS_FMT_DS32 || c->format == NPS_FMT_DS16;  // (both take and give float32 rows)
+    const size_t width = ds_any ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());  // no scoring kernel may still be reading the rows replaced here
     c->mx_row_tally_valid = false;    // (kept tallies describe the rows as they were: nps_cohort_keep_tallies again)
+    if (c->format == NPS_FMT_DS16) return ds16_transfer(c, row0, nrows, const_cast<void *>(host_rows), host_stride, true);
     if (c->format == NPS_FMT_GT2) {
         rc = cohort_unoptimize(c);
         if (rc) return rc;
@@ -1316,11 +1363,12 @@ extern "C" int nps_cohort_download(const nps_cohort *c, uint64_t row0, uint64_t 
     int rc = check_range(c, row0, nrows);
     if (rc) return rc;
     if (c->format == NPS_FMT_GT2M) return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts cannot be downloaded");
-    const size_t width = c->format == NPS_FMT_DS32 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
+    const size_t width = c->format == NPS_FMT_DS32 || c->format == NPS_FMT_DS16 ? c->n_samples * 4 : words_for(c->n_samples) * 4;
     if (nrows == 0 || width == 0) return NPS_OK;
     if (!host_rows || host_stride < width) return fail(NPS_E_INVAL, "bad host buffer / stride");
     HIP_TRY(hipSetDevice(c->device));
     { int qrc = cohort_quiesce(c); if (qrc) return qrc; }
+    if (c->format == NPS_FMT_DS16) return ds16_transfer(const_cast<nps_cohort *>(c), row0, nrows, host_rows, host_stride, false);
     if (c->format == NPS_FMT_GT2) return gt2_transfer(c, row0, nrows, host_rows, host_stride, false);
     if (c->format == NPS_FMT_GT2X) return gt2x_transfer(c, row0, nrows, host_rows, host_stride, false);
     HIP_TRY(hipMemcpy2D(host_rows, host_stride, (const char *)c->d_data + row0 * c->stride_bytes,
@@ -1358,6 +1406,9 @@ extern "C" int nps_cohort_synth_rows(nps_cohort *c, uint64_t row0, uint64_t nrow
         else if (c->format == NPS_FMT_GT2X)
             e = launch_synth_gt2x(nullptr, c->d_data, c->n_samples, c->n_rows, row0 + r, gen_row0 + r, k, seed, d_t + r,
                                   d_t + nrows + r, d_t + 2 * nrows + r);
+        else if (c->format == NPS_FMT_DS16)
+            e = launch_synth_ds16(nullptr, (uint16_t *)c->d_data, c->stride_bytes / 2, c->n_samples, row0 + r, gen_row0 + r, k,
+                                  seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
         else if (c->format == NPS_FMT_DS32)
             e = launch_synth_ds(nullptr, (float *)c->d_data, c->stride_bytes / 4, c->n_samples,
                                 row0 + r, gen_row0 + r, k, seed, d_t + r, d_t + nrows + r, d_t + 2 * nrows + r);
@@ -1598,8 +1649,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_UNSUPPORTED, "NPS_FMT_GT2M cohorts are scored with nps_score_cohort_multi");
     rc = cohort_quiesce(co);  // rows pushed into the cohort (nps_cohort_push_*) are complete
     if (rc) return rc;
-    const bool is_ds = co->format == NPS_FMT_DS32;
+    const bool is_ds16 = co->format == NPS_FMT_DS16;
+    const bool is_ds = co->format == NPS_FMT_DS32 || is_ds16;
     const bool is_mx = co->format == NPS_FMT_GT2X;
+    if (is_ds16 && mode == NPS_MODE_TWOPASS)
+        return fail(NPS_E_UNSUPPORTED, "NPS_FMT_DS16 cohorts are scored by the single-read kernel only");
     if (is_mx && (cohort_row0 & 127))
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 128 for NPS_FMT_GT2X cohorts");
     if (!is_ds && (cohort_row0 & 3))
@@ -1660,7 +1714,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         } else {
             const int want = (int)env_u64("NPS_FUSED_THREADS", 0), max_q = (int)env_u64("NPS_FUSED_MAXQ", 0);
             if (is_ds)
-                HIP_TRY(ds_fused_plan(c->device, c->n, m, want, max_q, &plan));
+                HIP_TRY(ds_fused_plan(c->device, c->n, m, want, max_q, &plan, is_ds16 ? 2 : 4));
             else
                 HIP_TRY(fused_plan(c->device, c->n, m, want, max_q, &plan));
             c->plan_cache = plan;
@@ -1676,9 +1730,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                             "NPS_MODE_TWOPASS score such a cohort in two reads)", (unsigned long long)co->ds_bad_rows);
             plan.ok = false;
         }
-        if (!plan.ok && mode == NPS_MODE_FUSED)
+        if (!plan.ok && (mode == NPS_MODE_FUSED || is_ds16))
             return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the fused "
-                        "persistent grid", (unsigned long long)c->n, (unsigned long long)m);
+                        "persistent grid%s", (unsigned long long)c->n, (unsigned long long)m,
+                        is_ds16 ? " (NPS_FMT_DS16 has no two-read kernels: use NPS_FMT_DS32)" : "");
     }
 
     rc = run_batch(c);  // keep push order: finish whatever was streamed before
@@ -1894,15 +1949,15 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     }
 
     if (is_ds) {
-        const uint64_t stride_f = co->stride_bytes / 4;
-        const float *ds = (const float *)co->d_data + cohort_row0 * stride_f;
+        const uint64_t stride_f = co->stride_bytes / 4;  // (NPS_FMT_DS32 only below the fused branch)
+        const float *ds = (const float *)((const char *)co->d_data + cohort_row0 * co->stride_bytes);
         if (fused) {
             rc = tally_ready();
             if (rc) return rc;
             hipError_t fe;
             {
                 ProfScope ps(c, P_FUSED);
-                fe = launch_ds_fused(c->stream, plan, ds, stride_f, c->n, m, def->d_desc,
+                fe = launch_ds_fused(c->stream, plan, ds, co->stride_bytes, is_ds16 ? 2 : 4, c->n, m, def->d_desc,
                                      dev_params(c->params), c->d_rtally, c->d_rstats,
                                      c->d_nloci, c->d_part_fused, c->d_timeout);
             }
@@ -1914,9 +1969,10 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             }
             (void)hipGetLastError();  // the runtime refused the cooperative grid: nothing ran
             c->rtally_clean = true;   // (zeroed above, untouched)
-            if (mode == NPS_MODE_FUSED || fe != hipErrorCooperativeLaunchTooLarge)
+            if (mode == NPS_MODE_FUSED || is_ds16 || fe != hipErrorCooperativeLaunchTooLarge)
                 return fail(NPS_E_HIP, "fused DS kernel launch failed: %s", hipGetErrorString(fe));
         }
+        if (is_ds16) return fail(NPS_E_UNSUPPORTED, "NPS_FMT_DS16 cohorts are scored by the single-read kernel only");
         // launches of >= 2048 rows keep every CU busy in both kernels (one workgroup per row in the
         // tally; samples x row chunks in the accumulation)
         uint64_t block_rows = env_u64("NPS_BLOCK_ROWS", 0);
@@ -2469,6 +2525,8 @@ extern "C" void *nps_stream(nps_ctx *c) { return c ? (void *)c->stream : nullptr
 extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint32_t *slices,
                                   uint32_t *teams, uint32_t *samples_per_slice) {
     if (!c) return fail(NPS_E_INVAL, "ctx is NULL");
+    const int ds_elem = format == NPS_FMT_DS16 ? 2 : 4;
+    if (format == NPS_FMT_DS16) format = NPS_FMT_DS32;  // (the same kernel and slices; four rows per batch)
     if (format != NPS_FMT_GT2 && format != NPS_FMT_DS32 && format != NPS_FMT_GT2X)
         return fail(NPS_E_INVAL, "unknown format %d", format);
     HIP_TRY(hipSetDevice(c->device));
@@ -2485,7 +2543,7 @@ extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint3
     }
     FusedPlan plan;
     if (format == NPS_FMT_DS32)
-        HIP_TRY(ds_fused_plan(c->device, c->n, n_rows, 0, 0, &plan));
+        HIP_TRY(ds_fused_plan(c->device, c->n, n_rows, 0, 0, &plan, ds_elem));
     else
         HIP_TRY(fused_plan(c->device, c->n, n_rows, 0, 0, &plan));
     if (slices) *slices = plan.ok ? plan.P : 0;

@@ -188,9 +188,9 @@ hipError_t launch_ds_accumulate(hipStream_t st, const float *d_ds, uint64_t stri
 // single-read kernel for a resident DS cohort (nps_ds_fused.hip); plan.threads/P/Q as for the GT kernel.
 // d_tally: [n_rows] zeroed; d_psum: [n_rows * plan.P]; d_part: [Q*part_team_stride]
 hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int want_threads, int max_q,
-                         FusedPlan *plan);
-hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const float *d_ds, uint64_t stride_f,
-                           uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
+                         FusedPlan *plan, int elem_bytes = 4 /* 2: NPS_FMT_DS16 (four rows per batch) */);
+hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const void *d_ds, uint64_t stride_bytes,
+                           int elem_bytes /* 4: float32 rows; 2: NPS_FMT_DS16 rows */, uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
                            DevParams prm, unsigned long long *d_tally /* [n_rows][2], zero */,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout);
@@ -202,6 +202,28 @@ hipError_t launch_decode_gt_to_ds(hipStream_t st, const void *d_gts, int elem_by
 hipError_t launch_synth_ds(hipStream_t st, float *d_ds, uint64_t stride_f, uint64_t n, uint64_t row0,
                            uint64_t gen_row0, uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het,
                            const uint32_t *d_t_hom, const uint32_t *d_t_miss);
+// The float32 value of code k of a NPS_FMT_DS16 cohort, 0 <= k <= 20 000: float32(k / 10^4) correctly rounded -- the float32
+// a decimal parser gives for the text -- in three float32 operations: with c1 = float32(1e-4) and c2 = float32(1e-4 - c1),
+// fma(k, c1, float32(k c2)) equals the correctly rounded quotient for EVERY such k (checked exhaustively with exact
+// rationals when this was written, and on the device by tests/test_gpu_parity.py::test_ds16_every_code_round_trips; the
+// oracle computes float32(double(k) * 1e-4), which tests/test_host_logic.py checks against strtof for every k).  The
+// obvious float64 form costs three quarter-rate conversions and a float64 multiply per genotype: 57 ms instead of 38 for a
+// pass the float32 kernel does in 38.
+#ifdef __HIPCC__
+static __device__ __forceinline__ float ds16_value(uint32_t k) {
+    const float a = (float)k;
+    return __fmaf_rn(a, 9.999999747378752e-05f, a * 2.5262125290942405e-12f);
+}
+#endif
+// NPS_FMT_DS16 (2 bytes per genotype: k = dosage x 10^4, 0xFFFF = missing): the generator (device copy of ref_synth_ds16),
+// float32 rows -> k with a per-row flag for rows that hold a value no k stands for, and k -> float32 rows
+hipError_t launch_synth_ds16(hipStream_t st, uint16_t *d_ds, uint64_t stride_e, uint64_t n, uint64_t row0, uint64_t gen_row0,
+                             uint64_t n_rows, uint64_t seed, const uint32_t *d_t_het, const uint32_t *d_t_hom,
+                             const uint32_t *d_t_miss);
+hipError_t launch_ds16_pack(hipStream_t st, const float *d_src, uint64_t src_stride_f, uint64_t n, uint64_t n_rows,
+                            uint16_t *d_dst, uint64_t dst_stride_e, unsigned char *d_bad);
+hipError_t launch_ds16_unpack(hipStream_t st, const uint16_t *d_src, uint64_t src_stride_e, uint64_t n, uint64_t n_rows,
+                              float *d_dst, uint64_t dst_stride_f);
 
 // ---- several scores in one pass on the matrix cores (nps_multi.hip) -----------------------------
 // NPS_FMT_GT2M cohort: ceil(rows/128) superblocks x ceil(samples/32) groups x 1 KiB units

@@ -456,6 +456,32 @@ float ref_synth_ds(uint64_t seed, uint64_t row, uint64_t sample, uint32_t t_het,
     return d;
 }
 
+/* NPS_FMT_DS16 cohorts (round 5): the same draw, with a DECIMAL noise -- dosage = genotype + noise * 0.004, clipped to
+ * [0, 2], i.e. k / 10^4 with k = clamp(10000 c + 40 noise, 0, 20000) -- as the float32 a parser makes of that decimal
+ * text: (float)((double)k * 1e-4) (tests/test_host_logic.py checks that against strtof for every k). */
+float ref_ds16_value(uint32_t k) { return k == 0xffffu ? NAN : (float)((double)k * 1e-4); }
+uint32_t ref_synth_ds16_code(uint64_t seed, uint64_t row, uint64_t sample, uint32_t t_het, uint32_t t_hom,
+                             uint32_t t_miss) {
+    uint64_t h = ref_mix64(ref_mix64(seed ^ (row * 0xD1B54A32D192ED03ull)) + sample);
+    uint32_t g = (uint32_t)h, ms = (uint32_t)(h >> 32);
+    if (ms < t_miss) return 0xffffu;
+    int c = g < t_hom ? 2 : (g < t_het ? 1 : 0);
+    int noise = (int)((ms >> 8) & 255u) - 128;
+    int v = c * 10000 + noise * 40;
+    return (uint32_t)(v < 0 ? 0 : (v > 20000 ? 20000 : v));
+}
+static float synth_ds_kind(int kind, uint64_t seed, uint64_t row, uint64_t sample, uint32_t t_het, uint32_t t_hom,
+                           uint32_t t_miss) { /* kind 1: ref_synth_ds; 2: the NPS_FMT_DS16 generator */
+    return kind == 2 ? ref_ds16_value(ref_synth_ds16_code(seed, row, sample, t_het, t_hom, t_miss))
+                     : ref_synth_ds(seed, row, sample, t_het, t_hom, t_miss);
+}
+void ref_synth_rows_ds16(float *ds, size_t stride, size_t n, size_t row0, size_t nrows, uint64_t seed,
+                         const uint32_t *t_het, const uint32_t *t_hom, const uint32_t *t_miss) {
+    for (size_t r = 0; r < nrows; ++r)
+        for (size_t i = 0; i < n; ++i)
+            ds[r * stride + i] = synth_ds_kind(2, seed, row0 + r, i, t_het[r], t_hom[r], t_miss[r]);
+}
+
 void ref_synth_rows_ds(float *ds, size_t stride, size_t n, size_t row0, size_t nrows,
                        uint64_t seed, const uint32_t *t_het, const uint32_t *t_hom,
                        const uint32_t *t_miss) {
@@ -528,7 +554,7 @@ void ref_score_subset(int is_ds, const uint64_t *samples, size_t k, size_t n_tot
             for (size_t j = 0; j < m; ++j) {
                 if (is_ds) {
                     for (size_t i = 0; i < kk; ++i)
-                        ds[i] = ref_synth_ds(seed, row0 + j, samples[i0 + i], t_het[j], t_hom[j], t_miss[j]);
+                        ds[i] = synth_ds_kind(is_ds, seed, row0 + j, samples[i0 + i], t_het[j], t_hom[j], t_miss[j]);
                     ref_raw_dosages_ds(dos, ds, kk, rie[j]);
                 } else {
                     subset_row_gt(dos, gts, samples + i0, kk, seed, row0 + j, t_het[j], t_hom[j], t_miss[j]);
@@ -560,7 +586,7 @@ void ref_tally_synth_rows(int is_ds, const uint64_t *rows, size_t nr, size_t n, 
 #pragma omp for schedule(dynamic, 1)
         for (size_t r = 0; r < nr; ++r) {
             if (is_ds) {
-                for (size_t i = 0; i < n; ++i) ds[i] = ref_synth_ds(seed, rows[r], i, t_het[r], t_hom[r], t_miss[r]);
+                for (size_t i = 0; i < n; ++i) ds[i] = synth_ds_kind(is_ds, seed, rows[r], i, t_het[r], t_hom[r], t_miss[r]);
                 ref_raw_dosages_ds(dos, ds, n, rie[r]);
             } else {
                 subset_row_gt(dos, gts, ids, n, seed, rows[r], t_het[r], t_hom[r], t_miss[r]);

@@ -109,6 +109,11 @@ def lib():
     L.ref_synth_rows_ds.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                     C.c_uint64, u32p, u32p, u32p]
     L.ref_synth_rows_ds.restype = None
+    L.ref_synth_rows_ds16.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                    C.c_uint64, u32p, u32p, u32p]
+    L.ref_synth_rows_ds16.restype = None
+    L.ref_ds16_value.argtypes = [C.c_uint32]
+    L.ref_ds16_value.restype = C.c_float
     L.ref_codes_to_gt.argtypes = [u32p, C.c_size_t, i32p]
     L.ref_codes_to_gt.restype = None
     L.ref_bench_gt.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp,
@@ -269,8 +274,23 @@ def synth_rows_ds(n: int, row0: int, nrows: int, seed: int, t_het, t_hom, t_miss
     return out[:, :n]
 
 
+def synth_rows_ds16(n: int, row0: int, nrows: int, seed: int, t_het, t_hom, t_miss) -> np.ndarray:
+    """the generator of NPS_FMT_DS16 cohorts: three-decimal dosages as the float32 a parser makes of them (NaN = missing)"""
+    out = np.zeros((nrows, max(n, 1)), dtype=np.float32)
+    th, tm, tmi = (np.ascontiguousarray(a, dtype=np.uint32) for a in (t_het, t_hom, t_miss))
+    if nrows and n:
+        lib().ref_synth_rows_ds16(_p(out, C.c_float), max(n, 1), n, row0, nrows, seed,
+                                  _p(th, C.c_uint32), _p(tm, C.c_uint32), _p(tmi, C.c_uint32))
+    return out[:, :n]
+
+
+def ds16_value(k: int) -> np.float32:
+    """the float32 value of code k of a NPS_FMT_DS16 cohort (0xFFFF: NaN)"""
+    return np.float32(lib().ref_ds16_value(int(k)))
+
+
 def score_subset(samples, n_total: int, row0: int, seed: int, t_het, t_hom, t_miss, beta, eaf, rie,
-                 row_ngen, row_nmiss, row_neff, params: RefParams, is_ds: bool = False):
+                 row_ngen, row_nmiss, row_neff, params: RefParams, is_ds=False):  # is_ds: False / True / 2 (the NPS_FMT_DS16 generator)
     """The chosen samples of a synthetic cohort scored over rows [row0, row0 + m) with the restated procs,
     given every row's whole-row tally (see refcpu.c "Full-size checks").  Returns (un-normalised sums,
     nloci): the state of the reference's loop at nimpress.nim:641."""

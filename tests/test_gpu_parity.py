@@ -622,6 +622,108 @@ def test_ds_resident_vs_oracle(shape, mode):
     assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
 
 
+# ---- NPS_FMT_DS16: the same dosages in 2 bytes per genotype (lossless for decimals with at most four places)
+def make_ds16_cohort(n, m, seed, rng):
+    co = make_ds_cohort(n, m, seed, rng)
+    co["ds"] = refcpu.synth_rows_ds16(n, 0, m, seed, co["th"], co["tm"], co["tmi"])
+    return co
+
+
+def same_floats(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a, nan=-1.0).view(np.uint32),
+                                                                        np.nan_to_num(b, nan=-1.0).view(np.uint32))
+
+
+@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
+@pytest.mark.parametrize("shape", [(1, 1), (100, 3), (4099, 129), (7681, 11), (30000, 500), (15361, 2001)])
+def test_ds16_resident_vs_oracle(shape, pk):
+    """a NPS_FMT_DS16 cohort filled by the generator: the rows that come back are the oracle generator's float32 values bit
+    for bit (the format is lossless), and the single-read kernel scores them as the oracle scores those floats -- same
+    bars as the float32 cohort (statistics exact but for the float64 dosage sum, scores 1e-6 relative)"""
+    n, m = shape
+    if pk and shape not in ((4099, 129), (30000, 500)):
+        pytest.skip("all imputation modes on two shapes")
+    rng = np.random.default_rng(n + 5 * m + pk)
+    co = make_ds16_cohort(n, m, 2026, rng)
+    kw = PARAM_GRID[pk] if pk else dict(imp_locus="ps", imp_missing="homref", imp_sample="int_ps", maxmis=0.05, mincs=100)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_DS16)
+    assert dev.fmt == capi.FMT_DS16 and dev.row_stride % 128 == 0 and dev.row_stride < 2 * n + 256
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    assert same_floats(dev.download(0, m), co["ds"])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(dev, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, capi.MODE_AUTO)
+    stats = sc.flush()
+    scores, nloci = sc.finish(0.25)
+    sc.close()
+    ref_scores, ref_stats, ref_nloci = oracle_ds(co, kw, 0.25)
+    assert nloci == ref_nloci
+    assert_ds_stats(stats, ref_stats)
+    assert np.array_equal(np.isnan(scores), np.isnan(ref_scores))
+    assert rel_err(scores, ref_scores, co["beta"], max(nloci, 1)) <= REL_TOL
+    # the float32 cohort holding the very same values gives the same scores (same kernel, same arithmetic; the samples of a
+    # thread are laid out differently, so the dosage sums -- and with them an imputed value -- may differ in the last bits)
+    d32 = capi.Cohort(n, m, fmt=capi.FMT_DS32)
+    d32.upload(0, co["ds"])
+    sc = capi.Scorer(n, capi.make_params(**kw))
+    sc.score_cohort(d32, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, capi.MODE_FUSED)
+    s32, n32 = sc.finish(0.25)
+    sc.close()
+    d32.close()
+    dev.close()
+    assert n32 == nloci
+    ok = ~np.isnan(s32)
+    assert np.allclose(scores[ok], s32[ok], rtol=1e-11, atol=1e-15)
+
+
+def test_ds16_every_code_round_trips():
+    """the device's value of code k (ds16_value: three float32 operations) is the parser's float32 of k / 10^4 for EVERY k:
+    one row holding all 20 001 decimals goes up (the packer compares its own value of k with the float it was given, bit for
+    bit, and would refuse the row) and comes back (the unpacker writes its value of k) unchanged; a cohort of that row is
+    scored by the single-read kernel with beta = 1 and must give each sample its own dosage back"""
+    n = 20001
+    row = np.array(["%.4f" % (k / 10000.0) for k in range(n)], dtype=np.float32)[None, :]
+    dev = capi.Cohort(n, 1, fmt=capi.FMT_DS16)
+    dev.upload(0, row)
+    assert same_floats(dev.download(0, 1), row)
+    sc = capi.Scorer(n, capi.make_params())
+    sc.score_cohort(dev, capi.row_descs(np.ones(1), np.full(1, 0.2)), 0, capi.MODE_FUSED)
+    s, nl = sc.finish(0.0)
+    sc.close()
+    dev.close()
+    assert nl == 1 and np.array_equal(s, row[0].astype(np.float64) / 2.0)
+
+
+def test_ds16_upload_is_lossless_or_refused():
+    """float32 rows of decimals with one to four places round-trip bit for bit; a row with any other value (a binary
+    fraction that is no such decimal, a value above 2, a negative zero) is refused and named, never rounded"""
+    n, m = 5000, 12
+    rng = np.random.default_rng(16)
+    rows = np.empty((m, n), dtype=np.float32)
+    for j in range(m):
+        d = 1 + j % 4
+        k = rng.integers(0, 2 * 10 ** d + 1, n)
+        rows[j] = np.array(["%.*f" % (d, v / 10 ** d) for v in k], dtype=np.float32)   # (what a VCF parser makes of the text)
+    rows[rng.uniform(size=rows.shape) < 0.05] = np.nan
+    dev = capi.Cohort(n, m, fmt=capi.FMT_DS16)
+    dev.upload(0, rows)
+    assert same_floats(dev.download(0, m), rows)
+    for bad in (np.float32(1.0) / np.float32(3.0), np.float32(2.0001), np.float32(-0.0), np.float32(0.12345)):
+        r2 = rows[3:5].copy()
+        r2[1, 777] = bad
+        with pytest.raises(capi.NpsError) as ei:
+            dev.upload(3, r2)
+        assert ei.value.status == capi.E_UNSUPPORTED and "row 4" in str(ei.value)
+    dev.upload(3, rows[3:5])
+    assert same_floats(dev.download(0, m), rows)
+    # scoring such a cohort in two reads is refused, not done by another path
+    sc = capi.Scorer(n, capi.make_params())
+    with pytest.raises(capi.NpsError) as ei:
+        sc.score_cohort(dev, capi.row_descs(np.ones(m), np.full(m, 0.2)), 0, capi.MODE_TWOPASS)
+    assert ei.value.status == capi.E_UNSUPPORTED
+    sc.close()
+    dev.close()
+
+
 def test_ds_and_gt_rows_mixed_in_one_score():
     n = 777
     rng = np.random.default_rng(4)

@@ -901,3 +901,17 @@ def test_score_many_shards_rows_by_default_when_the_file_has_a_locus_index(tmp_p
     assert not sm.has_locus_index(b)
     open(str(tmp_path / "p.bim"), "w").close()
     assert sm.has_locus_index(b)
+
+
+def test_ds16_codes_are_the_parser_s_float32_for_every_decimal():
+    """NPS_FMT_DS16 (include/nps.h): code k stands for float32(double(k) * 1e-4).  That is the float32 a text parser makes
+    of the decimal k / 10^4 written with one to four places -- for EVERY k in 0 .. 20 000 and every such spelling: the
+    format loses nothing on FORMAT/DS values as imputation tools print them."""
+    from oracle import refcpu
+    for k in range(20001):
+        v = refcpu.ds16_value(k)
+        assert v == np.float32("%.4f" % (k / 10000.0)), k
+        for d in (1, 2, 3):
+            if k % 10 ** (4 - d) == 0:
+                assert v == np.float32("%.*f" % (d, k / 10000.0)), (k, d)
+    assert np.isnan(refcpu.ds16_value(0xffff))
