@@ -56,6 +56,7 @@ struct DsFusedArgs {
     uint32_t P, Q;
     const nps_row_desc *desc;
     DevParams prm;
+    int64_t t_maxmis;  // the largest nmissing for which nmissing / N > --maxmis is false (-1: none), found with that division
     unsigned long long *tally;  // [n_rows][2], zeroed: arrivals << 56 | sum_hi << 28 | nmissing ; arrivals << 56 | sum_lo
     double scale, inv_scale;    // 2^F, 2^-F: the slices' dosage sums travel as round(sum * 2^F)
     nps_locus_stat *stats;
@@ -238,8 +239,9 @@ __global__ __launch_bounds__(T, 4) void ds_fused_kernel(const DsFusedArgs a) {
                     const double neff = rp.flip ? 2.0 * (double)ngen - mysum : mysum;
                     const double nan = __longlong_as_double(0x7ff8000000000000ll);
                     int reason;
-                    const double missingrate = (double)nmiss / (double)a.n_samples;
-                    if (missingrate > a.prm.max_missing_rate) {  // nim:565-571
+                    // nim:565-571: nmissing / N > --maxmis, as an integer comparison (the host found the threshold with the
+                    // division itself; a float64 division here is ~400 cycles of the control wave's phase)
+                    if ((int64_t)nmiss > a.t_maxmis) {
                         reason = NPS_REASON_MAXMIS;
                         if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
                             rp.imp = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
@@ -560,7 +562,7 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int wa
 
 hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const void *d_ds, uint64_t stride_bytes, int elem_bytes,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
-                           DevParams prm, unsigned long long *d_tally,
+                           DevParams prm, int64_t t_maxmis, unsigned long long *d_tally,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout) {
     if (elem_bytes != 4 && elem_bytes != 2) return hipErrorInvalidValue;
@@ -575,6 +577,7 @@ hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const void *d_
     a.Q = plan.Q;
     a.desc = d_desc;
     a.prm = prm;
+    a.t_maxmis = t_maxmis;
     a.tally = d_tally;
     // total < 2 N 2^F must leave its high part (>> 32) inside 28 bits, a slice's sum (< 2^14) inside 63
     int lg = 0;

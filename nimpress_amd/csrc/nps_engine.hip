@@ -1595,6 +1595,21 @@ static int materialize_resident_stats(nps_ctx *c) {
 }
 
 // (re)allocation helper: *p holds at least `need` elements of `elem` bytes afterwards
+// the reference's test `nmissing / N > --maxmis` (double division, nimpress.nim:565) is monotone in nmissing: the largest
+// count that is NOT over the rate (-1: none), found with that very expression -- the kernels compare integers
+static int64_t maxmis_threshold(uint64_t n, double rate) {
+    if (n == 0 || (double)0 / (double)n > rate) return -1;
+    uint64_t lo = 0, hi = n;  // pred(lo) holds
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (!((double)mid / (double)n > rate))
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return (int64_t)lo;
+}
+
 static int grow(nps_ctx *c, void **p, uint64_t *cap, uint64_t need, size_t elem) {
     if (need <= *cap) return NPS_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1849,21 +1864,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
 
     if (is_mx) {
         if (c->n == 0) return done();
-        // the reference's test `nmissing / N > --maxmis` (double division, nimpress.nim:565) is monotone in
-        // nmissing: the largest count that is NOT over the rate, found with that very expression
-        const double rate = c->params.max_missing_rate;
-        int64_t t_maxmis = -1;
-        if (!((double)0 / (double)c->n > rate)) {
-            uint64_t lo = 0, hi = c->n;  // pred(lo) holds
-            while (lo < hi) {
-                const uint64_t mid = lo + (hi - lo + 1) / 2;
-                if (!((double)mid / (double)c->n > rate))
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            t_maxmis = (int64_t)lo;
-        }
+        const int64_t t_maxmis = maxmis_threshold(c->n, c->params.max_missing_rate);
         // one pass per magnitude band of the definition (normally one): band 0 counts nloci and writes the statistics
         struct Run {
             const nps_row_desc *d_desc;
@@ -1958,7 +1959,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             {
                 ProfScope ps(c, P_FUSED);
                 fe = launch_ds_fused(c->stream, plan, ds, co->stride_bytes, is_ds16 ? 2 : 4, c->n, m, def->d_desc,
-                                     dev_params(c->params), c->d_rtally, c->d_rstats,
+                                     dev_params(c->params), maxmis_threshold(c->n, c->params.max_missing_rate), c->d_rtally, c->d_rstats,
                                      c->d_nloci, c->d_part_fused, c->d_timeout);
             }
             if (fe == hipSuccess) {

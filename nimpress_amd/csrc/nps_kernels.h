@@ -191,7 +191,8 @@ hipError_t ds_fused_plan(int device, uint64_t n_samples, uint64_t n_rows, int wa
                          FusedPlan *plan, int elem_bytes = 4 /* 2: NPS_FMT_DS16 (four rows per batch) */);
 hipError_t launch_ds_fused(hipStream_t st, const FusedPlan &plan, const void *d_ds, uint64_t stride_bytes,
                            int elem_bytes /* 4: float32 rows; 2: NPS_FMT_DS16 rows */, uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc,
-                           DevParams prm, unsigned long long *d_tally /* [n_rows][2], zero */,
+                           DevParams prm, int64_t t_maxmis /* largest nmissing not over --maxmis, -1: none */,
+                           unsigned long long *d_tally /* [n_rows][2], zero */,
                            nps_locus_stat *d_stats, unsigned long long *d_nloci, double *d_part,
                            unsigned int *d_timeout);
 // per row of a float32 dosage matrix: d_bad[r] = 1 when a value that is not NaN lies outside [0, 2]
