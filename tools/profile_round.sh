@@ -11,7 +11,10 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 1 $EXTRA"
-python3 "$R/bench.py" $ARGS > "$O/bench.json" 2> "$O/bench.err" || exit 1
+# the line as the driver reads it (compact, last stdout line) and the full object with every secondary beside it;
+# NPS_PROFILE_SWEEPS=1: all eighteen size x distribution cases and six layout cohorts (minutes longer)
+SWEEP=""; [ -n "$NPS_PROFILE_SWEEPS" ] && SWEEP="--full-sweeps --extras-budget 900 --extras-deadline 1000"
+python3 "$R/bench.py" $ARGS $SWEEP --full-out "$O/bench_full.json" > "$O/bench.json" 2> "$O/bench.err" || exit 1
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o stats --output-format csv -- python3 "$R/bench.py" $ARGS --no-cpu-baseline --no-extras > "$O/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/fetch" -o fetch --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras $EXTRA > "$O/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/write" -o write --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras $EXTRA > "$O/write.log" 2>&1

@@ -18,8 +18,11 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-bench = json.loads(open(os.path.join(out_dir, "bench.json")).read().strip().splitlines()[-1])
+line = json.loads(open(os.path.join(out_dir, "bench.json")).read().strip().splitlines()[-1])   # the compact line
+full_path = os.path.join(out_dir, "bench_full.json")
+bench = json.load(open(full_path)) if os.path.exists(full_path) else line                       # every secondary
 json.dump(bench, open(os.path.join(dst, "%s_bench_full.json" % tag), "w"))
+json.dump(line, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"))
 st = find("stats/**/*kernel_stats.csv")
 if st:
     open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w").write(open(st).read())
