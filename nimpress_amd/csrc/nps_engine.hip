@@ -1805,6 +1805,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         }
         if (use_v2) {
             rc = grow(c, (void **)&c->d_mx_fix, &c->mx_fix_cap, m_pad, sizeof(uint32_t));
+            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);  // (32 bytes per row used)
             if (rc) return rc;
         }
         if (mxp.given) {
@@ -1919,7 +1920,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                     fe = launch_fused_mx2(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                           runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
                                           c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
-                                          const_slots, c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count);
+                                          const_slots, c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count, c->d_mx_ops);
                 else
                     fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,

@@ -323,7 +323,8 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
                           const unsigned int *d_fix_count = nullptr, const void *d_units = nullptr,
                           const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0);
 hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          int sentinels /* 0 flags; 1 flags + sentinels in (w1, wfb); 2 sentinels, flags word = superblock + 1 */);
+                          int sentinels /* 0 flags; 1 flags + sentinels in (w1, wfb); 2 sentinels, flags word = superblock + 1 */,
+                          void *d_ops = nullptr /* 32 bytes per padded row: the rows' is-missing operands ready made (nps_mx2.hip) */);
 // nps_mx2.hip: the same pass with code x beta accumulated on arrival and only the is-missing masks parked (three steps of
 // slack for the hand-over); never for plan.given; d_fix_rows: n_rows uint32, d_fix_count: one zeroed word
 hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
@@ -331,7 +332,8 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
                             int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
                             unsigned long long *d_tally1, nps_locus_stat *d_stats, unsigned long long *d_nloci,
                             double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
-                            unsigned int *d_fix_count);
+                            unsigned int *d_fix_count,
+                            void *d_ops /* 32 bytes per padded row (or nullptr): used unless --imp-sample is int_* */);
 constexpr uint64_t kMx2MaxRows = 0xffffffffull;
 // nps_mx3.hip: the same pass with the row tallies completed and the rows' operands made ONCE, by R reducer workgroups on
 // the compute units the strips leave idle.  mx3_reducers: how many a plan leaves room for (0: this form does not apply).

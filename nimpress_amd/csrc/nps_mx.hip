@@ -46,7 +46,8 @@ __device__ unsigned long long g_mx_timers[16][16];  // [wave][phase]: cycles sum
 // control waves read only those sixteen bytes of a row when they make its operands; rows [n_rows, n_pad) are zeroed
 // (their digits are fetched with the last superblock's)
 __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows, uint64_t n_pad,
-                                                      DevParams prm, double scale, int sentinels, MxPre *__restrict__ pre) {
+                                                      DevParams prm, double scale, int sentinels, MxPre *__restrict__ pre,
+                                                      v4u *__restrict__ ops) {
     // (sentinels == 2, nps_mx3.hip: the flags word is replaced by the row's superblock + 1 -- the mark by which a strip
     //  sees that its LDS-DMA of the beta digits has landed; the flags travel as sentinels)
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -55,11 +56,17 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
     o.c[0] = o.c[1] = o.c[2] = 0u;
     o.flags = 0u;
     o.w1 = o.wfb = 0;
+    // ops (nps_mx2.hip with --imp-sample ps / homref / fail, where the weight of a missing genotype does not depend on the
+    // row's tally): the row's two is-missing operands ready made, [superblock][even | odd operand][128 rows in mx_perm
+    // order] x 16 bytes -- the layout of the kernel's Bm table, which it fills by LDS-DMA; dword 3 of the even row = flags
+    const uint64_t ops_at = (j >> 7) * 256 + (uint64_t)mx_perm((int)(j & 127));
     if (j >= n_rows) {
         if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
         pre[j] = o;
+        if (ops) ops[ops_at] = ops[ops_at + 128] = v4u{0u, 0u, 0u, 0u};
         return;
     }
+    uint32_t me[3] = {0u, 0u, 0u}, mo[3] = {0u, 0u, 0u};
     const double beta = desc[j].beta, eaf = desc[j].eaf;
     const bool rie = desc[j].ref_is_effect != 0;
     const double inf = __builtin_huge_val(), nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -73,12 +80,21 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
                            : (prm.imp_sample == NPS_SAMPLE_FAIL || prm.imp_sample == NPS_SAMPLE_INT_FAIL) ? nan
                                                                                                           : eaf * 2.0;
         const double t = imp * beta;  // the product the reference adds for a missing sample (nimpress.nim:639)
+        long long wfb;
         if (!(fabs(t) < inf)) {
             o.flags = 2u;
-            o.wfb = sentinels ? kMxNanWfb : 3 * o.w1;
+            wfb = 3 * o.w1;
+            o.wfb = sentinels ? kMxNanWfb : wfb;
         } else {
-            o.wfb = __double2ll_rn(t * scale);
+            o.wfb = wfb = __double2ll_rn(t * scale);
         }
+        // (as mx_row makes them from (w1, wfb, flags) when the imputed dosage does not come from the row's tally)
+        mx_codes(wfb - 3 * o.w1, o.flags >> 1, me);
+        mx_codes(wfb - 4 * o.w1, o.flags >> 1, mo);
+    }
+    if (ops) {
+        ops[ops_at] = v4u{me[0], me[1], me[2], o.flags};
+        ops[ops_at + 128] = v4u{mo[0], mo[1], mo[2], 0u};
     }
     if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
     pre[j] = o;
@@ -849,11 +865,11 @@ hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_uni
 }
 
 hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          int sentinels) {
+                          int sentinels, void *d_ops) {
     (void)hipGetLastError();
     const uint64_t n_pad = (n_rows + 127) / 128 * 128;
     hipLaunchKernelGGL(mx_prep_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, st, d_desc, n_rows, n_pad, prm,
-                       std::ldexp(1.0, F), sentinels, (MxPre *)d_pre);
+                       std::ldexp(1.0, F), sentinels, (MxPre *)d_pre, (v4u *)d_ops);
     return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ static_assert(k2LdsBytes <= 160u * 1024u, "LDS of a compute unit");
 
 // where row r's is-missing operands live in a Bm table: inside a block of 32 rows the even rows first, then the odd ones
 // (a parked mask word holds rows 2l and 2l+1 bit-interleaved: the transposed read hands a lane 16 even rows, then 16 odd)
-static __device__ __forceinline__ int mx2_perm(int r) { return (r & 96) | ((r & 1) << 4) | ((r >> 1) & 15); }
+// (mx_perm: nps_mx_common.h)
 
 #ifdef NPS_MX_TIMERS
 __device__ unsigned long long g_mx2_timers[16][16];
@@ -254,6 +254,17 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
     uint32_t nloci_local = 0;
     double cst_local = 0.0;
     bool timed_out = false;
+    // READY-MADE operands (a.ops != nullptr: --imp-sample ps / homref / fail, where the weight of a missing genotype does not
+    // depend on the row's tally; mx_prep_kernel made both operands of every row): the Bm table of a superblock arrives by
+    // LDS-DMA as it is, and all that is left to do per row once its tally word is complete is the --maxmis comparison, the
+    // statistics and -- for the rare row over --maxmis -- zeroing its two table rows.  The control wave's 4 900 cycles of
+    // operand arithmetic per step (profiles/r05_mx2_timers.txt) were what this form waited for.
+    const bool ready = a.ops != nullptr;  // (uniform over the launch)
+    bool rd_over[k2RPL], rd_used[k2RPL];  // of the superblock whose table is on its way: decided in ctl_tables, applied a step later
+#pragma unroll
+    for (int h = 0; h < k2RPL; ++h) rd_over[h] = rd_used[h] = false;
+    bool rd_pending = false;
+    uint32_t rd_j = 0;
     auto sb_row0 = [&](uint32_t k) -> uint64_t { return ((uint64_t)team + (uint64_t)k * a.Q) * 128; };
     const uint32_t lds_bc = (uint32_t)(uintptr_t)(smem + k2Bc);      // + (k & 1) * 2048
     const uint32_t lds_pre = (uint32_t)(uintptr_t)(smem + k2Pre);
@@ -267,11 +278,23 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
     };
     // ... (w1, wfb) of the rows of superblock j, and the look at their tally words (one DMA: two words per lane)
     auto ctl_dma_look = [&](uint32_t j) {
+        if (!ready) {
 #pragma unroll
-        for (int h = 0; h < k2RPL; ++h)
-            mx2_dma16(reinterpret_cast<const char *>(a.pre + sb_row0(j) + 64 * (cw * k2RPL + h) + lane) + 16,
-                      lds_pre + (uint32_t)(cw * k2RPL + h) * 1024u, false);
+            for (int h = 0; h < k2RPL; ++h)
+                mx2_dma16(reinterpret_cast<const char *>(a.pre + sb_row0(j) + 64 * (cw * k2RPL + h) + lane) + 16,
+                          lds_pre + (uint32_t)(cw * k2RPL + h) * 1024u, false);
+        }
         if (lane < 32 * k2RPL) mx2_dma16(a.tally + sb_row0(j) + 64 * k2RPL * cw + 2 * lane, lds_look + (uint32_t)(cw * k2RPL) * 512u, true);
+    };
+    // ready-made operands of superblock j -> table buffer j & 1 (4 KiB: this wave's share in pieces of 64 table rows).  Issued
+    // behind the barrier after which no wave reads that buffer any more; landed at the vmcnt(0) on top of the next step.
+    const uint32_t lds_bm = (uint32_t)(uintptr_t)(smem + k2Bm);
+    auto ctl_dma_bm = [&](uint32_t j) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4 / k2NC; ++q4) {
+            const uint32_t piece = (uint32_t)(cw * (4 / k2NC) + q4);
+            mx2_dma16(a.ops + ((uint64_t)team + (uint64_t)j * a.Q) * 256 + piece * 64 + lane, lds_bm + (j & 1u) * 4096u + piece * 1024u, false);
+        }
     };
     // complete tallies of superblock j (x) -> the row's two is-missing operands in table buffer j & 1; a row over
     // --maxmis goes on the list of rows whose eager code x beta the epilogue takes back
@@ -294,7 +317,7 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
         double cst;
         const bool live = valid && ok;
         mx_row(a, x, live, row, tpre, px, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
-        char *p = smem + k2Bm + (j & 1) * 4096 + mx2_perm(crow) * 16;
+        char *p = smem + k2Bm + (j & 1) * 4096 + mx_perm(crow) * 16;
         *reinterpret_cast<v4u *>(p) = v4u{wme[0], wme[1], wme[2], 0u};
         *reinterpret_cast<v4u *>(p + 2048) = v4u{wmo[0], wmo[1], wmo[2], 0u};
         nloci_local += (uint32_t)__popcll(__ballot(used != 0));
@@ -332,7 +355,7 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
                 const int crow = lane + 64 * (cw * k2RPL + h);
                 x[h] = *reinterpret_cast<const unsigned long long *>(smem + k2Look + crow * 8);
                 pw[h] = *reinterpret_cast<const v2ul *>(smem + k2Pre + crow * 16);
-                landed = landed && x[h] != kLookArmed && (long long)pw[h][0] != kPreArmed;
+                landed = landed && x[h] != kLookArmed && (ready || (long long)pw[h][0] != kPreArmed);
             }
             if (__all(landed) || timed_out) break;
             __builtin_amdgcn_s_sleep(1);
@@ -377,8 +400,69 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
 #ifdef NPS_MX_TIMERS
         if (dbg_counts) dbg_counts[1] += spins;
 #endif
+        if (!ready) {
 #pragma unroll
-        for (int h = 0; h < k2RPL; ++h) ctl_build(j, lane + 64 * (cw * k2RPL + h), x[h], valid[h], ok[h], pw[h]);
+            for (int h = 0; h < k2RPL; ++h) ctl_build(j, lane + 64 * (cw * k2RPL + h), x[h], valid[h], ok[h], pw[h]);
+            return;
+        }
+        // ready-made operands: the decisions of getImputedDosages (nimpress.nim:565-571) from the complete tally word, the
+        // row's statistics, and what the table rows -- on their way by DMA -- will need once they have landed
+        rd_j = j;
+        rd_pending = true;
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) {
+            const int crow = lane + 64 * (cw * k2RPL + h);
+            const uint64_t row = sb_row0(j) + crow;
+            const bool live = valid[h] && ok[h];
+            const uint32_t nmiss = (uint32_t)(x[h] >> 28) & 0xFFFFFFFu, neff = (uint32_t)x[h] & 0xFFFFFFFu;
+            const bool over = live && (int64_t)nmiss > a.t_maxmis;
+            int used = live ? 1 : 0, reason = NPS_REASON_GENOTYPED;
+            double cst = 0.0;
+            if (over) {  // (rare: the row's score entry is fetched here)
+                reason = NPS_REASON_MAXMIS;
+                used = 0;
+                if (a.prm.imp_locus != NPS_LOCUS_IGNORE) {
+                    const double beta = a.desc[row].beta, eaf = a.desc[row].eaf;
+                    const bool rie = a.desc[row].ref_is_effect != 0;
+                    const double c = a.prm.imp_locus == NPS_LOCUS_PS       ? eaf * 2.0
+                                     : a.prm.imp_locus == NPS_LOCUS_HOMREF ? (rie ? 2.0 : 0.0)
+                                                                           : __longlong_as_double(0x7ff8000000000000ll);
+                    used = 1;
+                    cst = c * beta;
+                }
+                if (strip == 0) a.fix_rows[atomicAdd(a.fix_count, 1u)] = (uint32_t)row;
+            }
+            rd_over[h] = over;
+            rd_used[h] = live && !over;  // (a non-finite beta of such a row makes the sums NaN: told by the landed table's flags)
+            if (live && strip == 0 && a.stats != nullptr) {
+                nps_locus_stat st;
+                st.ngenotyped = (uint32_t)a.n_samples - nmiss;
+                st.nmissing = nmiss;
+                st.neffect = (double)neff;
+                st.used = used;
+                st.reason = reason;
+                a.stats[row] = st;
+            }
+            nloci_local += (uint32_t)__popcll(__ballot(used != 0));
+            cst_local += cst;
+        }
+    };
+    // the table of superblock rd_j has landed (vmcnt(0) on top of the step that consumes it, before its barrier): rows over
+    // --maxmis lose their operands; a used row whose beta is not finite makes every sum NaN through the locus constants
+    auto ctl_ready_apply = [&]() {
+        if (!rd_pending) return;
+        rd_pending = false;
+#pragma unroll
+        for (int h = 0; h < k2RPL; ++h) {
+            const int crow = lane + 64 * (cw * k2RPL + h);
+            char *p = smem + k2Bm + (rd_j & 1u) * 4096 + mx_perm(crow) * 16;
+            if (rd_over[h]) {
+                *reinterpret_cast<v4u *>(p) = v4u{0u, 0u, 0u, 0u};
+                *reinterpret_cast<v4u *>(p + 2048) = v4u{0u, 0u, 0u, 0u};
+            } else if (rd_used[h] && (*reinterpret_cast<const uint32_t *>(p + 12) & 1u)) {
+                cst_local += __longlong_as_double(0x7ff8000000000000ll);
+            }
+        }
     };
     // the two-stage publication of nps_mx.hip: the strips arrive in groups on a word of their group; the strip whose add
     // completes a group (told by the value its add returned) adds the group's sum to the row's word
@@ -416,6 +500,7 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
                 for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(b[u]));
             }
             mx2_wait_vm<0>();
+            if (ready) ctl_ready_apply();  // (the table this step's deferred part reads has landed: before this step's barrier)
             // ... and the look is issued BEFORE this step's load
             if (due_t) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the staging areas were re-armed with LDS writes)
@@ -456,6 +541,7 @@ static __device__ __forceinline__ void mx2_body(const MxArgs &a, char *const sme
                                  : "memory");
             }
             if (k + 2 < n_t) ctl_dma_bc(k + 2);  // (buffer k & 1: every wave has read the digits of k before this barrier)
+            if (ready && due_t) ctl_dma_bm(jt);  // (buffer jt & 1: last read by the deferred part of the step before this one)
         }
         MXT(3);
         if (due) deferred(jd);
@@ -549,9 +635,12 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
                             int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
                             unsigned long long *d_tally1, nps_locus_stat *d_stats, unsigned long long *d_nloci,
                             double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
-                            unsigned int *d_fix_count) {
+                            unsigned int *d_fix_count, void *d_ops) {
     if (plan.given || n_rows > 0xffffffffull) return hipErrorInvalidValue;
-    hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 1);
+    // the rows' is-missing operands ready made, wherever they do not depend on the rows' tallies
+    const bool internal = prm.imp_sample == NPS_SAMPLE_INT_PS || prm.imp_sample == NPS_SAMPLE_INT_FAIL;
+    if (internal) d_ops = nullptr;
+    hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 1, d_ops);
     if (pe != hipSuccess) return pe;
     const void *fn = (const void *)fused_mx2_kernel<0>;
 #ifdef NPS_DIAGNOSTICS
@@ -602,7 +691,7 @@ hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_un
     a.fix_rows = d_fix_rows;
     a.fix_count = d_fix_count;
     a.part = nullptr;
-    a.ops = nullptr;
+    a.ops = (v4u *)d_ops;
     a.const_part = nullptr;
     a.done = nullptr;
     a.R = 0;

@@ -95,6 +95,10 @@ static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) { 
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
     return d;
 }
+// where row r's is-missing operands live in a Bm table of the second form (nps_mx2.hip): inside a block of 32 rows the even
+// rows first, then the odd ones (a parked mask word holds rows 2l and 2l+1 bit-interleaved: the transposed read hands a lane
+// 16 even rows, then 16 odd)
+static __host__ __device__ inline int mx_perm(int r) { return (r & 96) | ((r & 1) << 4) | ((r >> 1) & 15); }
 // where row r of a unit lives in its 1 KiB LDS image: a lane's two rows stay together (one ds_write_b128), and
 // the 32 lanes of a half wave read 256 different bytes in both transposed reads
 static __host__ __device__ inline int mx_rowoff(int r) {

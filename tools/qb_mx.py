@@ -12,6 +12,7 @@ ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--cases", default="bench")
 ap.add_argument("--fmt", type=int, default=3)
 ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 two reads (tally + accumulation), 2 single read, 3 single read, second form (nps_mx2.hip)")
+ap.add_argument("--imp-sample", default=None, help="ps | homref | fail | int_ps | int_fail (default: the CLI default, int_ps)")
 a = ap.parse_args()
 import torch
 from nimpress_amd import capi
@@ -48,6 +49,8 @@ for key in a.cases.split(","):
         y = min(m, x + (1 << 15))
         co.synth_at(x, x, seed, th[x:y], tm[x:y], tmi[x:y])
     sdef = capi.ScoreDef(capi.row_descs(beta, 0.3 * one))
+    if a.imp_sample:
+        kw = dict(kw, imp_sample=a.imp_sample)
     sc = capi.Scorer(n, capi.make_params(**kw))
     d = torch.empty(n, dtype=torch.float64, device="cuda")
     times = []
