@@ -9,9 +9,10 @@
 //     56-bit fixed-point integers (scale 2^F per score definition) in sign-magnitude, split into fourteen hexadecimal
 //     digits: an FP6 (e2m3) operand byte 00dddd IS the digit d/8, so a digit needs no encoding at all.  The
 //     2-bit codes are FP4 (e2m1) operands as they lie: a nibble 00hl is 0, 0.5, 1, 1.5 -- linear in the code -- and
-//     the second genotype of a nibble, moved one bit down, sits in the exponent field: 0, 1, 2, 4.  Five vector
-//     instructions per 16 genotypes make the four operand registers (two code operands, two is-missing
-//     operands); v_mfma_scale_f32_16x16x128_f8f6f4 with unit-making block scales accumulates exact integers
+//     the second genotype of a nibble, moved two bits down, is the same again (until round 5: one bit down, in the exponent
+//     field, 0, 1, 2, 4 -- a shift less per word, but a second is-missing operand per row for the control waves, whose path
+//     sets the step).  Six vector instructions per 16 genotypes make the four operand registers (two code operands, two
+//     is-missing operands); v_mfma_scale_f32_16x16x128_f8f6f4 with unit-making block scales accumulates exact integers
 //     in float32 (flushed long before 2^24), sixteen columns = fourteen digits, a spare and one NaN flag.
 //   * Layout: strips of 2048 samples x superblocks of 128 rows; a unit = 128 rows x 32 samples = 1 KiB,
 //     row-major [row][8 bytes], two samples per nibble.  One workgroup (8 waves) owns a strip and streams all
@@ -206,14 +207,12 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     auto accumulate = [&](uint32_t k, const char *slot) {
         if (k >= n_t || n_my == 0 || (DBG & 2)) return;
         const char *tab = smem + kLdsTables + (k % kTabBufs) * 6144;
-        v8i Bc, Bme, Bmo;
+        v8i Bc, Bme;
         {
             const v3i c0 = tr6(tab + fr0), c1 = tr6(tab + fr1);
             const v3i e0 = tr6(tab + 2048 + fr0), e1 = tr6(tab + 2048 + fr1);
-            const v3i o0 = tr6(tab + 4096 + fr0), o1 = tr6(tab + 4096 + fr1);
             Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
             Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
-            Bmo = v8i{o0[0], o0[1], o0[2], o1[0], o1[1], o1[2], 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -225,15 +224,15 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t s1 = w[r] >> 1;
                     ce[r] = (int)(w[r] & 0x33333333u);       // even sample: 00hl = code / 2
-                    co[r] = (int)(s1 & 0x66666666u);         // odd sample: 0hl0 = 0, 1, 2, 4
+                    co[r] = (int)((w[r] >> 2) & 0x33333333u);  // odd sample, moved down: 00hl = code / 2 as well
                     me[r] = (int)(w[r] & s1 & 0x11111111u);  // even sample missing: 0001 = 1/2
                     mo[r] = (int)(w[r] & s1 & 0x44444444u);  // odd sample missing: 0100 = 2
                 }
                 // block scales (E8M0): codes 0,1,2,3 | 0,1,2,4; missing bit 1; digits d/8 -> d
                 C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ce, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(co, Bc, C[u][1], 4, 2, 0, 127, 0, 130);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(co, Bc, C[u][1], 4, 2, 0, 128, 0, 130);
                 C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(me, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bmo, C[u][1], 4, 2, 0, 126, 0, 130);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
             }
         }
     };
@@ -278,7 +277,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                : GIVEN ? a.tally[row]
                        : __hip_atomic_load(&a.tally[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    // complete tallies of superblock k (x) -> the row's three operands in table buffer k % kTabBufs
+    // complete tallies of superblock k (x) -> the row's two operands (beta digits, is-missing digits) in table buffer k % kTabBufs
     MxPreX px;  // (of npre: made by ctl_pre_extra() while the look at the row's word is still under way)
     px.w1d = 0.0;
     px.w3 = px.w4 = 0;
@@ -292,11 +291,10 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         uint32_t wc[3], wme[3], wmo[3];
         int used;
         double cst;
-        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, px, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst);  // (strip 0 of the row's team)
+        mx_row(a, x, valid && ok && !(DBG & 8), row, npre, px, strip == 0 && a.stats != nullptr, wc, wme, wmo, used, cst, false);  // (strip 0 of the row's team)
         char *p = smem + kLdsTables + (k % kTabBufs) * 6144 + crow * 16;
         *reinterpret_cast<v4u *>(p) = v4u{wc[0], wc[1], wc[2], 0u};
         *reinterpret_cast<v4u *>(p + 2048) = v4u{wme[0], wme[1], wme[2], 0u};
-        *reinterpret_cast<v4u *>(p + 4096) = v4u{wmo[0], wmo[1], wmo[2], 0u};
         nloci_local += (uint32_t)__popcll(__ballot(used != 0));
         cst_local += cst;
     };

@@ -160,7 +160,8 @@ struct MxPreX {
 };
 static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long long x, bool live, uint64_t row,
                                               const MxPre &pre, const MxPreX &px, bool write_stats, uint32_t (&wc)[3],
-                                              uint32_t (&wme)[3], uint32_t (&wmo)[3], int &used, double &cst) {
+                                              uint32_t (&wme)[3], uint32_t (&wmo)[3], int &used, double &cst,
+                                              bool need_odd = true) {
     wc[0] = wc[1] = wc[2] = wme[0] = wme[1] = wme[2] = wmo[0] = wmo[1] = wmo[2] = 0u;
     used = 0;
     cst = 0.0;
@@ -196,7 +197,8 @@ static __device__ __forceinline__ void mx_row(const MxArgs &a, unsigned long lon
         const bool dead = (pre.flags & 1u) != 0;  // a non-finite beta makes every sample's sum NaN (0 * NaN, NaN + x), as in the reference
         uint32_t e[3], o[3];
         mx_codes(wi - px.w3, bad ? 1u : 0u, e);  // a missing genotype has code 3 (4 in the odd operand)
-        mx_codes(wi - px.w4, bad ? 1u : 0u, o);
+        if (need_odd) mx_codes(wi - px.w4, bad ? 1u : 0u, o);  // (nps_mx.hip reads odd samples as code / 2 too: one operand)
+        else o[0] = o[1] = o[2] = 0u;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             wc[i] = dead ? 0u : pre.c[i];
