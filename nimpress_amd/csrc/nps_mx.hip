@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UD, int UC>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -121,9 +121,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave < kBig ? wave * kUD
-                   : wave < kDW ? kBig * kUD + (wave - kBig) * kUD2
-                                : kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
+    const int u0 = wave < kDW ? wave * UD : kDW * UD + (wave - kDW) * UC;  // (UD units per data wave, UC per control wave)
     const int crow = lane + 64 * (wave - kDW);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
@@ -477,35 +475,36 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-template <int DBG, bool GIVEN>
+// UD / UC: units of a data wave / of a control wave, 6 UD + 2 UC = 64.  Two splits are built (round 5):
+//   9 + 5   the control waves carry five units beside their 64 rows each;
+//   10 + 2  (253 VGPRs, possible since the rows have ONE is-missing operand) the control waves -- whose path is the step's
+//           longest: look, operands, publication AND their own units -- carry two.  Where a strip's workgroup is alone with
+//           its rows (one row team: more than 128 strips) that shortens the step: 500 000 samples 22.0 -> 21.3 ms, 400 000
+//           18.8 -> 18.6; with two or more teams per strip the nine-unit split is as fast or faster (200 000 samples: 9.1
+//           against 9.7 ms), so the launcher picks by the plan.
+template <int DBG, bool GIVEN, int UD, int UC>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
+    static_assert(kDW * UD + 2 * UC == 64 && UC >= 1, "units of a strip");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
-    const int u0 = wave < kBig ? wave * kUD : kBig * kUD + (wave - kBig) * kUD2;  // (data waves)
     if (wave >= kDW) {
         // the control waves are the step's critical path and share their SIMD with a data wave: up to ~200 strips per
         // team they issue first (200 000 samples 9.95 -> 9.29 ms, 400 000 20.5 -> 19.6, 100 000 and 250 000 +1 %); at
         // 245 strips the step is set by the hand-over chain instead and the priority costs up to 2.5 %
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
-        // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units,
-        //  and the control waves are the step's critical path -- their five units took as long as a data wave's nine)
-        const int uc0 = kBig * kUD + (kDW - kBig) * kUD2 + (wave - kDW) * kUC;
-        if (kUC > 0 && nu - uc0 >= kUC)
-            mx_body<(kUC > 0 ? kUC : 1), false, true, DBG, GIVEN>(a, smem);
+        // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units)
+        const int uc0 = kDW * UD + (wave - kDW) * UC;
+        if (nu - uc0 >= UC)
+            mx_body<UC, false, true, DBG, GIVEN, UD, UC>(a, smem);
         else
-            mx_body<(kUC > 0 ? kUC : 1), true, true, DBG, GIVEN>(a, smem);  // (kUC = 0: no units, n_my = 0)
-    } else if (wave < kBig) {
-        if (nu - u0 >= kUD)
-            mx_body<kUD, false, false, DBG, GIVEN>(a, smem);
-        else
-            mx_body<kUD, true, false, DBG, GIVEN>(a, smem);
+            mx_body<UC, true, true, DBG, GIVEN, UD, UC>(a, smem);
     } else {
-        if (nu - u0 >= kUD2)
-            mx_body<kUD2, false, false, DBG, GIVEN>(a, smem);
+        if (nu - wave * UD >= UD)
+            mx_body<UD, false, false, DBG, GIVEN, UD, UC>(a, smem);
         else
-            mx_body<kUD2, true, false, DBG, GIVEN>(a, smem);
+            mx_body<UD, true, false, DBG, GIVEN, UD, UC>(a, smem);
     }
 }
 
@@ -880,25 +879,29 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 0);
         if (pe != hipSuccess) return pe;
     }
-    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true> : (const void *)fused_mx_kernel<0, false>;
+    // one row team (more than 128 strips): the control waves carry two units instead of five (see fused_mx_kernel)
+    const bool light_ctl = !plan.given && plan.Q == 1;
+    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true, kUD, kUC>
+                     : light_ctl ? (const void *)fused_mx_kernel<0, false, 10, 2>
+                                 : (const void *)fused_mx_kernel<0, false, kUD, kUC>;
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
     if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false>; break;
+        case 1: fn = (const void *)fused_mx_kernel<1, false, kUD, kUC>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false, kUD, kUC>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false, kUD, kUC>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false, kUD, kUC>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false, kUD, kUC>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false, kUD, kUC>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false, kUD, kUC>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false, kUD, kUC>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false, kUD, kUC>; break;
         default: break;
         }
 #endif
-    static const void *attr_set[2] = {nullptr, nullptr};
-    const int which = plan.given ? 1 : 0;
+    static const void *attr_set[3] = {nullptr, nullptr, nullptr};
+    const int which = plan.given ? 1 : (light_ctl ? 2 : 0);
     if (attr_set[which] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -943,10 +946,11 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         const uint32_t ng = (plan.P + 63) / 64;
         a.grp_strips = g > 0 ? (uint32_t)std::max(16, g) : (plan.P + ng - 1) / ng;
     }
+    if (getenv("NPS_MX_PRIO")) a.ctl_prio = (uint32_t)atoi(getenv("NPS_MX_PRIO"));
 #endif
     const dim3 grid(plan.P * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        hipLaunchKernelGGL((fused_mx_kernel<0, true>), grid, dim3(kMxThreads), kLdsBytes, st, a);
+        hipLaunchKernelGGL((fused_mx_kernel<0, true, kUD, kUC>), grid, dim3(kMxThreads), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};

@@ -34,9 +34,7 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kDW = NPS_MX_DW;           // data waves 0..kDW-1; the two control waves follow
 constexpr int kMxThreads = (kDW + 2) * 64;
-constexpr int kBig = kDW;                // data waves 0..kBig-1 carry kUD units, data waves kBig..kDW-1 carry kUD2
 constexpr int kUD = NPS_MX_UD;
-constexpr int kUD2 = NPS_MX_UD;
 constexpr int kUC = NPS_MX_UC;           // units of the two control waves, which do the per-row work of 64 rows each
 constexpr int kTabBufs = 2;
 constexpr uint32_t kFlushSb = 1024;      // superblocks between flushes of the float32 digit sums (131 072 rows x 75 < 2^24)
@@ -140,7 +138,7 @@ static_assert(sizeof(MxPre) == 32, "MxPre layout");
 // nps_mx2.hip reads only (w1, wfb) of a row when it makes the row's operands: the two flags travel as sentinels
 constexpr long long kMxDeadW1 = (long long)0x8000000000000000ull;   // flags & 1: beta is not finite
 constexpr long long kMxNanWfb = (long long)0x8000000000000000ull;   // flags & 2: the imputed dosage x beta is NaN
-static_assert(kBig * kUD + (kDW - kBig) * kUD2 + 2 * kUC == 64, "units of a strip");
+static_assert(kDW * kUD + 2 * kUC == 64, "units of a strip");
 
 // n / d for 0 <= n <= d < 2^27 (0 / 0 = NaN), within an ulp: the weights it feeds are rounded to 2^-56 anyway
 static __device__ __forceinline__ double fast_ratio(double n, double d) {
