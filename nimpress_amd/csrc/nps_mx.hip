@@ -965,7 +965,7 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         // round trip after front(); 7 = tables)
         static const char *nm[16] = {"look-issue", "front", "barrier", "publish-begin", "accumulate", "publish-end", "look-wait",
                                      "tables", "loop/flush", "-", "-", "-", "-", "-", "-", "-"};
-        for (int w : {0, 3, kDW, kDW + 1}) {
+        for (int w = 0; w < kDW + 2; ++w) {
             fprintf(stderr, "mx timers wave %d (cycles per step):", w);
             for (int i = 0; i < 9; ++i) fprintf(stderr, "  %s %.0f", nm[i], (double)h[w][i] / plan.n_sb);
             fprintf(stderr, "\n");
