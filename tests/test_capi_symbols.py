@@ -77,3 +77,18 @@ def test_comm_library_exports_every_symbol_of_nps_comm_h():
         with pytest.raises(capi.NpsError) as ei:
             capi.Comm(1)
         assert ei.value.status == capi.E_NODEVICE
+
+
+def test_release_libraries_read_no_environment_variable():
+    """the release build has no run-time switches: neither library imports getenv (diagnostics builds -- tools/mkexp.sh
+    -DNPS_DIAGNOSTICS -- do, and are never what the package loads)"""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if not nm:
+        pytest.skip("no nm")
+    for path in (capi.LIB_PATH, capi.COMM_LIB_PATH):
+        if not os.path.exists(path):
+            pytest.skip("library not built")
+        out = subprocess.run([nm, "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+        assert "getenv" not in out, path
