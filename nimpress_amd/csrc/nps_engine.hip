@@ -1940,7 +1940,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                        c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
                                        (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1,
                                        use_v2 ? c->d_mx_fix : nullptr, use_v2 ? fix_count : nullptr, co->d_data, c->d_rlut,
-                                       gt2x_superblocks(co->n_rows), cohort_row0 >> 7));
+                                       gt2x_superblocks(co->n_rows), cohort_row0 >> 7,
+                                       !use_v2 && !mxp.given && mxp.U < 64 /* launch_fused_mx cut its own strips */));
                 HIP_TRY(hipMemsetAsync(const_slots, 0, sizeof(double) * 2 * mxp.Q, c->stream));
                 if (use_v2) HIP_TRY(hipMemsetAsync(fix_count, 0, sizeof(unsigned int), c->stream));
             }

@@ -299,6 +299,10 @@ struct MxPlan {
     bool v2 = false;     // the single-read run may use nps_mx2.hip (code x beta on arrival, is-missing masks parked)
     uint32_t P = 0, Q = 0, nu_last = 0, n_sb = 0, n_flush = 0;  // strips, row teams per strip (superblock k belongs to team k % Q)
     uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
+    // the first form (launch_fused_mx) may cut the unit sequence into strips of U = 62 units instead of the layout's 64
+    // where that puts more compute units to work (500 000 samples: 253 strips instead of 245): Pv strips, the last of
+    // nu_last_v units.  U = 64: Pv = P.  Every other kernel works on the layout's strips.
+    uint32_t U = 64, Pv = 0, nu_last_v = 0;
 };
 // two_pass: plan the tally + accumulate pair whatever the shape (NPS_MODE_TWOPASS)
 hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pass, MxPlan *plan);
@@ -321,7 +325,8 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
                           unsigned long long *d_status, const uint32_t *d_fix_rows = nullptr,
                           const unsigned int *d_fix_count = nullptr, const void *d_units = nullptr,
-                          const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0);
+                          const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0,
+                          bool vstrips = false /* the digit sums come from launch_fused_mx with plan.U < 64 */);
 hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
                           int sentinels /* 0 flags; 1 flags + sentinels in (w1, wfb); 2 sentinels, flags word = superblock + 1 */,
                           void *d_ops = nullptr /* 32 bytes per padded row: the rows' is-missing operands ready made (nps_mx2.hip) */);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UD, int UC>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int UB, int UC, bool VS>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -120,8 +120,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     const uint32_t n_t = team < a.n_sb ? (a.n_sb - team + a.Q - 1) / a.Q : 0u;  // superblocks of this team
     if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL;
-    const int nu = strip == a.P - 1 ? (int)a.nu_last : 64;
-    const int u0 = wave < kDW ? wave * UD : kDW * UD + (wave - kDW) * UC;  // (UD units per data wave, UC per control wave)
+    const int nu = strip == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
+    // units per wave: UA for data waves 0..3, UB for data waves 4, 5 (the second data wave of SIMD 0 / 1), UC for the control waves
+    const int u0 = wave < 4 ? wave * UA : wave < 6 ? 4 * UA + (wave - 4) * UB : 4 * UA + 2 * UB + (wave - 6) * UC;
     const int crow = lane + 64 * (wave - kDW);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
@@ -130,9 +131,24 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     const int woff = mx_rowoff(2 * lane);
     const int r1off = mx_rowoff(32 * g + q), r2off = mx_rowoff(32 * g + 16 + q);
     const int fr0 = (32 * g + q) * 16, fr1 = (32 * g + 16 + q) * 16;
-    const v4u *const base =
-        a.units + ((uint64_t)strip * 64 * a.n_sb_cohort + (uint64_t)(a.sb0 + team) * nu + u0) * 64 + lane;
-    const uint64_t sb_stride = (uint64_t)nu * 64 * a.Q;  // from one superblock of the team to its next
+    // VS: the strip is a.U consecutive units of the cohort's unit sequence; this wave's first unit is unit g0 of that sequence,
+    // i.e. unit g0 % 64 of layout strip g0 / 64, and its units number bnd, bnd + 1, ... lie at the start of the next layout strip.
+    // Everything here is wave-uniform and kept in scalar registers (readfirstlane: the compiler does not know that the wave
+    // number is uniform); a load's address is a scalar base + the lane's 16 bytes.  (With per-lane base pointers for both
+    // layout strips the ten-unit body spilled 174 registers.)
+    const uint32_t g0 = VS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(strip * a.U + (uint32_t)u0)) : 0u;
+    const uint32_t ps_a = VS ? g0 >> 6 : strip;
+    const int bnd = VS ? 64 - (int)(g0 & 63u) : 64;
+    const uint32_t nu_a = VS ? (ps_a == a.P_phys - 1 ? a.nu_last_phys : 64u) : (uint32_t)nu;
+    const uint32_t nu_b = VS ? (ps_a + 1 == a.P_phys - 1 ? a.nu_last_phys : 64u) : 0u;
+    const v4u *const base =  // (!VS: a pointer per lane, as ever)
+        a.units + ((uint64_t)ps_a * 64 * a.n_sb_cohort + (uint64_t)(a.sb0 + team) * nu_a + (VS ? 0u : (uint32_t)u0)) * 64 + (VS ? 0 : lane);
+    const uint64_t sb_stride = (uint64_t)nu_a * 64 * a.Q;  // from one superblock of the team to its next
+    const char *const sbase_a = reinterpret_cast<const char *>(base) + (uint64_t)(g0 & 63u) * 1024;                   // (VS)
+    const char *const sbase_b = reinterpret_cast<const char *>(
+        a.units + ((uint64_t)(ps_a + 1) * 64 * a.n_sb_cohort + (uint64_t)(a.sb0 + team) * nu_b) * 64);               // (VS)
+    const uint64_t sstride_a = sb_stride * 16, sstride_b = (uint64_t)nu_b * 64 * a.Q * 16;                            // bytes
+    const uint32_t lane_off = (uint32_t)lane * 16u;
 
     v4f C[NU][2];
 #pragma unroll
@@ -144,7 +160,13 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         for (int u = 0; u < NU; ++u) bank[s][u] = v4u{0u, 0u, 0u, 0u};
 
     auto load_unit = [&](uint32_t k, int u) -> v4u {
-        return __builtin_nontemporal_load(base + (uint64_t)k * sb_stride + u * 64);
+        if constexpr (VS) {
+            const char *p = u < bnd ? sbase_a + (uint64_t)k * sstride_a + (uint32_t)u * 1024u
+                                    : sbase_b + (uint64_t)k * sstride_b + (uint32_t)(u - bnd) * 1024u;
+            return __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + lane_off));
+        } else {
+            return __builtin_nontemporal_load(base + (uint64_t)k * sb_stride + u * 64);
+        }
     };
     auto load_sb = [&](uint32_t k, v4u(&dst)[NU]) {
         if (k >= n_t) return;
@@ -475,19 +497,21 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     }
 }
 
-// UD / UC: units of a data wave / of a control wave, 6 UD + 2 UC = 64.  Two splits are built (round 5):
+// UA / UB / UC: units of data waves 0..3 / of data waves 4, 5 / of a control wave.  Three splits are built (round 5):
 //   9 + 5   the control waves carry five units beside their 64 rows each;
 //   10 + 2  (253 VGPRs, possible since the rows have ONE is-missing operand) the control waves -- whose path is the step's
 //           longest: look, operands, publication AND their own units -- carry two.  Where a strip's workgroup is alone with
 //           its rows (one row team: more than 128 strips) that shortens the step: 500 000 samples 22.0 -> 21.3 ms, 400 000
 //           18.8 -> 18.6; with two or more teams per strip the nine-unit split is as fast or faster (200 000 samples: 9.1
 //           against 9.7 ms), so the launcher picks by the plan.
-template <int DBG, bool GIVEN, int UD, int UC>
+//   10 + 9 + 2, VS  strips of 62 units cut from the unit sequence instead of the layout's 64 (MxArgs.U): more strips, hence more
+//           compute units at work, and nineteen units instead of twenty on the two SIMDs that set the step.
+template <int DBG, bool GIVEN, int UA, int UB, int UC, bool VS>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
-    static_assert(kDW * UD + 2 * UC == 64 && UC >= 1, "units of a strip");
+    static_assert(kDW == 6 && 4 * UA + 2 * UB + 2 * UC == (VS ? 62 : 64) && UC >= 1, "units of a strip");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
-    const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : 64;
+    const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
     // both bodies pass the same barriers; which one a wave runs is wave-uniform
     if (wave >= kDW) {
         // the control waves are the step's critical path and share their SIMD with a data wave: up to ~200 strips per
@@ -495,16 +519,21 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
         // 245 strips the step is set by the hand-over chain instead and the priority costs up to 2.5 %
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
         // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units)
-        const int uc0 = kDW * UD + (wave - kDW) * UC;
+        const int uc0 = 4 * UA + 2 * UB + (wave - kDW) * UC;
         if (nu - uc0 >= UC)
-            mx_body<UC, false, true, DBG, GIVEN, UD, UC>(a, smem);
+            mx_body<UC, false, true, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
         else
-            mx_body<UC, true, true, DBG, GIVEN, UD, UC>(a, smem);
+            mx_body<UC, true, true, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+    } else if (wave < 4) {
+        if (nu - wave * UA >= UA)
+            mx_body<UA, false, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+        else
+            mx_body<UA, true, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
     } else {
-        if (nu - wave * UD >= UD)
-            mx_body<UD, false, false, DBG, GIVEN, UD, UC>(a, smem);
+        if (nu - (4 * UA + (wave - 4) * UB) >= UB)
+            mx_body<UB, false, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
         else
-            mx_body<UD, true, false, DBG, GIVEN, UD, UC>(a, smem);
+            mx_body<UB, true, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
     }
 }
 
@@ -521,7 +550,7 @@ struct MxFix {
     uint64_t n_sb_cohort;
     uint32_t sb0, nu_last;
 };
-__global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_sb, uint32_t Q, uint32_t P,
+__global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_sb, uint32_t Q, uint32_t P, uint32_t U,
                                                       uint64_t n, double inv_scale, const double *__restrict__ const_sum,
                                                       double *__restrict__ part0, int overwrite,
                                                       unsigned long long *__restrict__ tally, uint64_t n_tally,
@@ -544,8 +573,10 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
     }
     __syncthreads();
     if (i >= n) return;
-    const uint64_t strip = i >> 11;
-    const uint32_t unit = (uint32_t)(i >> 5) & 63u, s = (uint32_t)i & 31u;
+    // (strips of U units: the layout's 64, or the first form's virtual strips)
+    const uint32_t gu = (uint32_t)(i >> 5), s = (uint32_t)i & 31u;
+    const uint64_t strip = U == 64u ? gu >> 6 : gu / U;
+    const uint32_t unit = U == 64u ? gu & 63u : gu - (uint32_t)strip * U;
     const uint32_t e = s & 1u, ii = s >> 1;
     // The sixteen digit sums of a sample are exact integers (float32 below 2^24); they are recombined as exact integers too:
     // value = hi 2^28 + lo with the seven low hexadecimal digits in lo, the seven high ones in hi (each below 2^52 per
@@ -842,7 +873,20 @@ hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pas
     plan->Q = (uint32_t)q;
     const uint64_t n_t = (gm.n_sb + q - 1) / q;  // superblocks of the longest team
     plan->n_flush = (uint32_t)((n_t + kFlushSb - 1) / kFlushSb);
-    plan->cpart_floats = (uint64_t)plan->n_flush * q * gm.P * 64 * 2 * 256;
+    // virtual strips of 62 units for the first form: only where one row team per strip is all there is (more than half the
+    // compute units are strips already) and the finer cut still fits the resident grid
+    plan->U = 64;
+    plan->Pv = gm.P;
+    plan->nu_last_v = gm.nu_last;
+    if (!plan->given && q == 1) {
+        const uint64_t total_units = (uint64_t)(gm.P - 1) * 64 + gm.nu_last, pv = (total_units + 61) / 62;
+        if (pv > gm.P && pv <= (uint64_t)cus && pv <= 255) {
+            plan->U = 62;
+            plan->Pv = (uint32_t)pv;
+            plan->nu_last_v = (uint32_t)(total_units - (pv - 1) * 62);
+        }
+    }
+    plan->cpart_floats = (uint64_t)plan->n_flush * q * std::max(gm.P, plan->Pv) * 64 * 2 * 256;
     plan->v2 = !plan->given && n_rows <= kMx2MaxRows;
     plan->ok = true;
     return hipSuccess;
@@ -880,28 +924,29 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
         if (pe != hipSuccess) return pe;
     }
     // one row team (more than 128 strips): the control waves carry two units instead of five (see fused_mx_kernel)
-    const bool light_ctl = !plan.given && plan.Q == 1;
-    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true, kUD, kUC>
-                     : light_ctl ? (const void *)fused_mx_kernel<0, false, 10, 2>
-                                 : (const void *)fused_mx_kernel<0, false, kUD, kUC>;
+    const bool light_ctl = !plan.given && plan.Q == 1, vstrips = light_ctl && plan.U == 62;
+    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true, kUD, kUD, kUC, false>
+                     : vstrips   ? (const void *)fused_mx_kernel<0, false, 10, 9, 2, true>
+                     : light_ctl ? (const void *)fused_mx_kernel<0, false, 10, 10, 2, false>
+                                 : (const void *)fused_mx_kernel<0, false, kUD, kUD, kUC, false>;
 #ifdef NPS_DIAGNOSTICS
     // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
     if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false, kUD, kUC>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false, kUD, kUC>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false, kUD, kUC>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false, kUD, kUC>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false, kUD, kUC>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false, kUD, kUC>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false, kUD, kUC>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false, kUD, kUC>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false, kUD, kUC>; break;
+        case 1: fn = (const void *)fused_mx_kernel<1, false, kUD, kUD, kUC, false>; break;
+        case 2: fn = (const void *)fused_mx_kernel<2, false, kUD, kUD, kUC, false>; break;
+        case 3: fn = (const void *)fused_mx_kernel<3, false, kUD, kUD, kUC, false>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false, kUD, kUD, kUC, false>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false, kUD, kUD, kUC, false>; break;
+        case 6: fn = (const void *)fused_mx_kernel<6, false, kUD, kUD, kUC, false>; break;
+        case 7: fn = (const void *)fused_mx_kernel<7, false, kUD, kUD, kUC, false>; break;
+        case 15: fn = (const void *)fused_mx_kernel<15, false, kUD, kUD, kUC, false>; break;
+        case 31: fn = (const void *)fused_mx_kernel<31, false, kUD, kUD, kUC, false>; break;
         default: break;
         }
 #endif
-    static const void *attr_set[3] = {nullptr, nullptr, nullptr};
-    const int which = plan.given ? 1 : (light_ctl ? 2 : 0);
+    static const void *attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int which = plan.given ? 1 : (vstrips ? 3 : light_ctl ? 2 : 0);
     if (attr_set[which] != fn) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
@@ -914,8 +959,11 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.n_sb = plan.n_sb;
     a.n_rows = n_rows;
     a.n_samples = n_samples;
-    a.P = plan.P;
-    a.nu_last = plan.nu_last;
+    a.P = vstrips ? plan.Pv : plan.P;
+    a.nu_last = vstrips ? plan.nu_last_v : plan.nu_last;
+    a.U = vstrips ? plan.U : 64u;
+    a.P_phys = plan.P;
+    a.nu_last_phys = plan.nu_last;
     a.Q = plan.Q;
     a.desc = d_desc;
     a.pre = (const MxPre *)d_pre;
@@ -948,9 +996,9 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     }
     if (getenv("NPS_MX_PRIO")) a.ctl_prio = (uint32_t)atoi(getenv("NPS_MX_PRIO"));
 #endif
-    const dim3 grid(plan.P * plan.Q);
+    const dim3 grid((vstrips ? plan.Pv : plan.P) * plan.Q);
     if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        hipLaunchKernelGGL((fused_mx_kernel<0, true, kUD, kUC>), grid, dim3(kMxThreads), kLdsBytes, st, a);
+        hipLaunchKernelGGL((fused_mx_kernel<0, true, kUD, kUD, kUC, false>), grid, dim3(kMxThreads), kLdsBytes, st, a);
         return hipGetLastError();
     }
     void *args[] = {&a};
@@ -980,8 +1028,9 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
                           unsigned long long *d_status, const uint32_t *d_fix_rows, const unsigned int *d_fix_count,
-                          const void *d_units, const void *d_pre, uint64_t n_sb_cohort, uint64_t sb0) {
+                          const void *d_units, const void *d_pre, uint64_t n_sb_cohort, uint64_t sb0, bool vstrips) {
     (void)hipGetLastError();
+    if (vstrips && d_fix_count) return hipErrorInvalidValue;  // (the list of the second form speaks of layout strips)
     const uint64_t blocks = std::max<uint64_t>(std::max<uint64_t>(1, (n_samples + 255) / 256), std::min<uint64_t>(4096, n_tally1 / 1024));
     MxFix fix;
     fix.rows = d_fix_rows;
@@ -991,7 +1040,8 @@ hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpa
     fix.n_sb_cohort = n_sb_cohort;
     fix.sb0 = (uint32_t)sb0;
     fix.nu_last = plan.nu_last;
-    hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_sb, plan.Q, plan.P, n_samples,
+    hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_sb, plan.Q,
+                       vstrips ? plan.Pv : plan.P, vstrips ? plan.U : 64u, n_samples,
                        std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_tally1, n_tally1, d_timeout,
                        d_status, fix);
     return hipGetLastError();

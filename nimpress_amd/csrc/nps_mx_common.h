@@ -51,6 +51,10 @@ struct MxArgs {
     uint64_t n_rows;         // rows of this run
     uint64_t n_samples;
     uint32_t P, nu_last;     // strips, units of the last one
+    // (round 5) virtual strips of the first form: the workgroups' strips are U <= 64 consecutive units of the cohort's unit
+    // sequence, whatever 64-unit strip of the LAYOUT they lie in (a wave's units cross at most one layout boundary): P and
+    // nu_last above count THEM; the layout's own numbers are below.  U = 64: the strips are the layout's.
+    uint32_t U = 64, P_phys = 0, nu_last_phys = 0;
     uint32_t Q;              // row teams per strip: superblock k of the run belongs to team k % Q (grid = Q * P workgroups)
     const nps_row_desc *desc;
     const MxPre *pre;        // per score row, from mx_prep_kernel: what does not depend on the tallies

@@ -439,6 +439,34 @@ def test_gt2x_beta_span_plain_relative_bar(mode):
     assert ref[-1] < 1e-12 * ref[0]
 
 
+@pytest.mark.parametrize("shape", [(300001, 300), (450123, 129), (505920, 130), (505889, 5), (262145, 257)])
+def test_gt2x_strips_of_62_units_vs_oracle(shape):
+    """Where a strip has one row team, the single-read kernel cuts the cohort's unit sequence into strips of 62 units instead
+    of the layout's 64 (more strips = more compute units at work): a wave's units then cross a boundary of the LAYOUT's
+    strips, the last layout strip is ragged, the last virtual strip too (505 920 samples: 255 strips of exactly 62 units;
+    505 889: the last sample's unit is partial; 262 145: 129 layout strips, the last of one sample).  NPS_MODE_FUSED equals
+    the oracle and, to the last bits, the two-read path, which works on the layout's own strips; and itself, bit for bit."""
+    n, m = shape
+    rng = np.random.default_rng(n + 7 * m)
+    co = make_cohort(n, m, 6262, rng)
+    kw = PARAM_GRID[(n + m) % len(PARAM_GRID)]
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
+    scores, nloci, stats = score_gt2x(dev, n, kw, descs, 0.0, mode=capi.MODE_FUSED)
+    two, nloci2, _ = score_gt2x(dev, n, kw, descs, 0.0, mode=capi.MODE_TWOPASS)
+    again, _, _ = score_gt2x(dev, n, kw, descs, 0.0, mode=capi.MODE_FUSED)
+    dev.close()
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+    assert nloci == ref_nloci == nloci2
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(scores, ref_scores, co["beta"], nloci)
+    assert np.array_equal(np.isnan(two), np.isnan(scores))
+    ok = ~np.isnan(two)
+    assert np.allclose(two[ok], scores[ok], rtol=1e-12, atol=1e-15)   # (exact digit sums; the locus constants are added in team order)
+    assert np.array_equal(again.view(np.int64), scores.view(np.int64))
+
+
 @pytest.mark.parametrize("n", [3000, 250000, 300000, 400000, 522240, 530000])
 def test_gt_auto_layout_at_every_size(n):
     """NPS_FMT_GT_AUTO is the strip layout at every size (round 5); NPS_MODE_AUTO equals the oracle whether the run counts its
