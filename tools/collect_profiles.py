@@ -51,11 +51,18 @@ if m2 and os.path.exists(old):
                                    ["## --imp-sample ps: operands ready made (Bm table by LDS-DMA)"] + m2ps[-5:]) + "\n")
 cnt = lines("%s_test_counts_raw.txt" % tag, ("check_scores", "passed", "failed"))
 soak = lines("%s_soak_raw.txt" % tag, ("soak ok", "Error", "error"))
+# (long soak runs appended by hand below the generated part survive a regeneration)
+prev = os.path.join(P, "%s_test_counts.txt" % tag)
+extra = []
+if os.path.exists(prev):
+    body = open(prev).read().splitlines()
+    cut = [i for i, l in enumerate(body) if l.startswith("# tools/soak.py --format")]
+    extra = body[cut[0]:] if cut else []
 if cnt:
     open(os.path.join(P, "%s_test_counts.txt" % tag), "w").write("\n".join([
         "# round %s, final tree: python -m pytest tests/test_gpu_mx.py -q -s (one MI355X): the samples that passed check_scores only through" % tag[1:].lstrip("0"),
         "# its 2^-50 escape, over every call of the module (asserted < 1 in 1000 per call and in total)"] +
         [re.sub(r"^\.+", "", l) for l in cnt] +
-        ["# tools/soak.py on the same box (bit-identical passes, two definitions alternating):"] + soak) + "\n")
+        ["# tools/soak.py on the same box (bit-identical passes, two definitions alternating):"] + soak + extra) + "\n")
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), tag])
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "profiles_readme.py"), tag])
