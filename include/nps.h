@@ -427,6 +427,9 @@ void *nps_stream(nps_ctx *ctx);
  * workgroups side by side over the samples (samples_per_slice each) times `teams` taking row batches in
  * turn; all zero when the shape does not fit the persistent grid (two-pass kernels are used).  For
  * reports and for tests that want to look at every slice. */
+/* (NPS_FMT_GT2X: the single-read kernel's OWN strips -- where a strip has one row team it cuts strips of 62 units = 1 984 samples
+ * from the cohort's unit sequence instead of the layout's 2 048; with the tallies given or more strips than compute units, the
+ * layout's strips) */
 int nps_fused_geometry(nps_ctx *ctx, int format, uint64_t n_rows, uint32_t *slices, uint32_t *teams,
                        uint32_t *samples_per_slice);
 

@@ -2539,9 +2539,11 @@ extern "C" int nps_fused_geometry(nps_ctx *c, int format, uint64_t n_rows, uint3
         // (more strips than compute units: the grid of the accumulation with given tallies -- kept with the cohort, or from
         //  the tally pass; its slices are still the 2048-sample strips)
         if (mp.ok && mp.given) HIP_TRY(mx_plan(c->device, c->n, n_rows, true, &mp));
-        if (slices) *slices = mp.ok ? mp.P : 0;
+        // (the single-read kernel may cut its own strips of 62 units = 1 984 samples from the unit sequence: what the grid IS)
+        const bool vs = mp.ok && !mp.given && mp.U < 64;
+        if (slices) *slices = mp.ok ? (vs ? mp.Pv : mp.P) : 0;
         if (teams) *teams = mp.ok ? mp.Q : 0;
-        if (samples_per_slice) *samples_per_slice = mp.ok ? 2048 : 0;
+        if (samples_per_slice) *samples_per_slice = mp.ok ? (vs ? 32 * mp.U : 2048) : 0;
         return NPS_OK;
     }
     FusedPlan plan;

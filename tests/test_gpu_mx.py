@@ -340,12 +340,15 @@ def test_gt2x_full_size_config3_properties():
     sc0 = capi.Scorer(n, capi.make_params())
     strips, teams, sps = sc0.fused_geometry(m, capi.FMT_GT2X)
     sc0.close()
-    assert strips == 245 and teams == 1 and sps == 2048
+    # (one row team: the kernel cuts strips of 62 units from the unit sequence -- 253 workgroups; the LAYOUT has 245 strips of 64)
+    assert strips == 253 and teams == 1 and sps == 62 * 32
     units = (n + 31) // 32
     us = {units - 1}
-    for p_ in range(strips):
-        first, last = p_ * 64, min(units, (p_ + 1) * 64) - 1
-        us.update(u for u in (first, first + 8, first + 53, first + 54, first + 59, last) if first <= u <= last)
+    for p_ in range(strips):   # of every strip of the kernel: its first unit, one behind a wave boundary (40: wave 4), a control
+        first, last = p_ * 62, min(units, (p_ + 1) * 62) - 1   # wave's unit, the last
+        us.update(u for u in (first, first + 40, first + 59, last) if first <= u <= last)
+    us.update(range(64, units, 64 * 16))      # and units at boundaries of the layout's own 64-unit strips
+    us.update(range(63, units, 64 * 16))
     samples = np.concatenate([np.arange(u * 32, min(n, (u + 1) * 32)) for u in sorted(us)]).astype(np.uint64)
     assert samples[-1] == n - 1
     sums, ref_nloci = refcpu.score_subset(samples, n, 0, seed, th, tm, tmi, beta, eaf, 0,
