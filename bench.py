@@ -1022,7 +1022,7 @@ def compact_line(out):
         mg = out["multi_gpu"]
         c["multi_gpu"] = ({k: _pick(v, ("value", "scaling", "n_gpus", "ms_per_pass", "scoring_ms", "exchange_ms", "nloci"))
                            for k, v in mg.items() if isinstance(v, dict)} if "error" not in mg else _pick(mg, ("error",)))
-    for k in ("parity_failures", "full_object", "rehearsal", "rehearsal_normalised", "seconds"):
+    for k in ("parity_failures", "parity_unchecked", "full_object", "rehearsal", "rehearsal_normalised", "seconds"):
         if k in out:
             c[k] = out[k]
     c = _r(c)
@@ -1035,6 +1035,10 @@ def compact_line(out):
             d = d.get(k, {})
         d.pop(drop[-1], None)
     return c
+
+
+# secondary legs whose result carries a parity check against the oracle (parity_failures walks them)
+PARITY_LEGS = ("given_tallies", "layout_sweep", "size_sweep", "config5_ds", "config5_ds16", "multi_score", "config2", "config4")
 
 
 def emit(out, full_path):
@@ -1300,10 +1304,27 @@ def main():
             leg_s = out.setdefault("seconds", {})
 
             def give_up_extras():
-                # a secondary leg that hangs must not cost the headline: print what there is, end with status 3
-                secondary["deadline"] = {"error": "secondary legs unfinished %.0f s after process start" % args.extras_deadline}
-                emit(out, args.full_out)
-                os._exit(3)
+                # a secondary leg that hangs must not cost the headline: print what there is, end with status 3.  This runs
+                # on the timer's thread while the main thread may be adding keys: the line is made from a SNAPSHOT (retried
+                # if a dictionary changed size under the copy), and the process ends whatever happens here
+                try:
+                    import copy
+                    snap = None
+                    for _ in range(20):
+                        try:
+                            snap = copy.deepcopy(out)
+                            break
+                        except RuntimeError:
+                            time.sleep(0.05)
+                    if snap is None:
+                        snap = {k: v for k, v in list(out.items()) if k != "secondary"}
+                    snap.setdefault("secondary", {})["deadline"] = {
+                        "error": "secondary legs unfinished %.0f s after process start" % args.extras_deadline}
+                    snap["parity_unchecked"] = sorted(set(PARITY_LEGS) - set(k for k, v in snap["secondary"].items()
+                                                                            if isinstance(v, dict) and "skipped" not in v and "error" not in v))
+                    emit(snap, args.full_out)
+                finally:
+                    os._exit(3)
 
             watchdog = threading.Timer(max(1.0, args.extras_deadline - (time.perf_counter() - T_START)), give_up_extras)
             watchdog.daemon = True
@@ -1358,6 +1379,13 @@ def main():
             leg("config2", config2_leg)
             leg("config4", config4_leg)
             watchdog.cancel()
+            # legs that carry a parity check and did not run (time budget): named in the line, so that a slow box cannot
+            # exit 0 having checked nothing but the headline without saying so (--require-all-legs makes it a failure)
+            unchecked = [k for k in PARITY_LEGS if isinstance(secondary.get(k), dict) and "skipped" in secondary[k]]
+            if unchecked:
+                out["parity_unchecked"] = unchecked
+                if args.require_all_legs:
+                    failed += ["unchecked:" + k for k in unchecked]
         if multi_legs is not None:
             out["multi_gpu"] = multi_legs
         bad = parity_failures(out)

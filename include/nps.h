@@ -322,12 +322,6 @@ void nps_cohort_destroy(nps_cohort *c);
 #define NPS_MODE_AUTO 0
 #define NPS_MODE_TWOPASS 1 /* tally kernel, then accumulate kernel (reads the matrix twice) */
 #define NPS_MODE_FUSED 2   /* persistent fused kernel (reads the matrix once) */
-/* NPS_FMT_GT2X cohorts only (elsewhere = NPS_MODE_FUSED): the second form of the single-read strip kernel -- code x beta is
- * accumulated as a superblock arrives, only the is-missing masks wait for the row tallies, rows that turn out to be over
- * --maxmis (nimpress.nim:565-571) are taken back by the pass's epilogue.  Same results as NPS_MODE_FUSED (scores within a
- * few ulps of the sum's terms, statistics bit for bit); slower on MI355X at present, kept as a measured
- * experiment and never picked by NPS_MODE_AUTO. */
-#define NPS_MODE_FUSED_EAGER 3
 int nps_score_cohort(nps_ctx *ctx, const nps_cohort *c, uint64_t cohort_row0,
                      const nps_row_desc *rows, uint64_t n_desc, int mode);
 

@@ -23,7 +23,7 @@ REASON_GENOTYPED, REASON_UNCOVERED, REASON_ABSENT, REASON_FILTERED, REASON_MAXMI
 FMT_GT2, FMT_DS32, FMT_GT2M, FMT_GT2X, FMT_GT_AUTO, FMT_DS16 = 0, 1, 2, 3, 4, 5
 ROW_NOT_IN_SCORE = 4
 MULTI_MAX_SCORES = 8
-MODE_AUTO, MODE_TWOPASS, MODE_FUSED, MODE_FUSED_EAGER = 0, 1, 2, 3
+MODE_AUTO, MODE_TWOPASS, MODE_FUSED = 0, 1, 2
 
 NPS_OK = 0
 E_INVAL, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7

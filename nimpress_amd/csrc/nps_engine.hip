@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -65,7 +66,9 @@ struct nps_cohort {
     // NPS_FMT_GT2X after nps_cohort_keep_tallies: the whole-row tallies (nmissing << 28 | neffect, the tally word of the
     // strip kernel without its arrival count), one per row of every superblock; valid until rows are rewritten
     unsigned long long *d_mx_row_tally = nullptr;
-    bool mx_row_tally_valid = false;
+    // (atomic: contexts on several threads may score one cohort; whoever finds the flag clear takes tally_mutex, the writer
+    //  publishes with release order AFTER the counted tallies are in device memory, readers load with acquire)
+    std::atomic<bool> mx_row_tally_valid{false};
     std::mutex tally_mutex;  // NPS_MODE_AUTO may count them lazily from whichever context scores the cohort first
     // nps_cohort_push_*: rows decoded on the device straight into the cohort (a pinned ring the decode kernel reads
     // over PCIe, on a stream of the cohort's own); every call that reads the cohort waits for it (cohort_quiesce)
@@ -168,10 +171,6 @@ struct nps_ctx {
     uint64_t mx_const_cap = 0;
     unsigned long long *d_mx_tally1 = nullptr;  // first-stage tally words (groups of 16 strips), zero between passes
     uint64_t mx_tally1_cap = 0;
-    uint32_t *d_mx_fix = nullptr;               // nps_mx2.hip: the run's rows over --maxmis (list, any order); its length is
-    uint64_t mx_fix_cap = 0;                    // the word d_timeout[16], zero between passes
-    uint32_t *d_mx_part = nullptr;              // nps_mx3.hip: the strips' partial tallies on their way to the reducers
-    uint64_t mx_part_cap = 0;
     void *d_mx_ops = nullptr;                   // nps_mxg.hip (tallies given): 48 bytes of weight operands per row ...
     uint64_t mx_ops_cap = 0;                    // (in units of 48 bytes)
     double *d_mx_cblk = nullptr;                // ... and one partial sum of locus constants per superblock
@@ -343,9 +342,7 @@ static void free_ctx(nps_ctx *c) {
     (void)hipFree(c->d_mx_cpart);
     (void)hipFree(c->d_mx_const);
     (void)hipFree(c->d_mx_tally1);
-    (void)hipFree(c->d_mx_fix);
     (void)hipFree(c->d_mx_ops);
-    (void)hipFree(c->d_mx_part);
     (void)hipFree(c->d_mx_cblk);
     (void)hipFree(c->d_rtally);
     (void)hipFree(c->d_rlut);
@@ -485,8 +482,6 @@ extern "C" int nps_reset(nps_ctx *c, const nps_params *params) {
         c->params = *params;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (c->broken && c->d_timeout)  // a strip-kernel pass that failed half-way may have left its list of rows behind
-        HIP_TRY(hipMemsetAsync(c->d_timeout + 16, 0, sizeof(unsigned int), c->stream));
     // no stream synchronisation: everything below is ordered on the context's stream, and no call
     // returns with a device-to-host copy still in flight
     return zero_state(c);
@@ -1654,9 +1649,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
     if (co->n_samples != c->n)
         return fail(NPS_E_INVAL, "cohort has %llu samples, context %llu",
                     (unsigned long long)co->n_samples, (unsigned long long)c->n);
-    if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED && mode != NPS_MODE_FUSED_EAGER)
+    if (mode != NPS_MODE_AUTO && mode != NPS_MODE_TWOPASS && mode != NPS_MODE_FUSED)
         return fail(NPS_E_INVAL, "bad mode %d", mode);
-    if (mode == NPS_MODE_FUSED_EAGER && co->format != NPS_FMT_GT2X) mode = NPS_MODE_FUSED;  // (a strip-kernel variant)
     const uint64_t m = def->m;
     rc = check_range(co, cohort_row0, m);
     if (rc) return rc;
@@ -1675,8 +1669,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
-    bool kept_tallies = false, use_v2 = false;
-    uint32_t mx3_R = 0;
+    bool kept_tallies = false;
     if (is_mx && m && c->n) {
         // a cohort that carries its tallies (nps_cohort_keep_tallies) is scored with them given under NPS_MODE_AUTO: the
         // "two-pass" plan (independent workgroups) without its tally pass
@@ -1717,7 +1710,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                         (unsigned long long)c->n, (unsigned long long)m);
         // more strips than compute units: the single-read kernel cannot hold the grid resident; AUTO takes the
         // tally + accumulate pair (two reads), an explicit NPS_MODE_FUSED is refused
-        if ((mxp.given && (mode == NPS_MODE_FUSED || mode == NPS_MODE_FUSED_EAGER)) || (mode == NPS_MODE_FUSED_EAGER && !mxp.v2))
+        if (mxp.given && mode == NPS_MODE_FUSED)
             return fail(NPS_E_UNSUPPORTED, "shape (%llu samples, %llu rows) does not fit the persistent grid of the "
                         "single-read NPS_FMT_GT2X kernel (one 2048-sample strip per compute unit); NPS_MODE_AUTO "
                         "scores it in two reads", (unsigned long long)c->n, (unsigned long long)m);
@@ -1788,25 +1781,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             rc = grow(c, (void **)&c->d_mx_const, &c->mx_const_cap, 8 + 2ull * mxp.Q, sizeof(double));
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double) * c->mx_const_cap, c->stream));
-        }
-        // NPS_MODE_FUSED_EAGER: the second form of the strip kernel (nps_mx2.hip), on request only -- it is not faster
-        // (DESIGN.md 4.2, round 5); a shape it does not take (more strips than compute units) is refused like NPS_MODE_FUSED
-        use_v2 = mode == NPS_MODE_FUSED_EAGER;
-#if defined(NPS_WITH_MX3) && defined(NPS_DIAGNOSTICS)
-        // experiment builds only (tools/mkexp.sh NAME -DNPS_WITH_MX3 -DNPS_DIAGNOSTICS): the third form, nps_mx3.hip -- a
-        // measured negative (profiles/r05_mx3_timers.txt), not part of the library
-        if (use_v2 && getenv("NPS_MX_FORM") && atoi(getenv("NPS_MX_FORM")) == 3) mx3_R = mx3_reducers(c->device, mxp);
-#endif
-        if (mx3_R) {
-            rc = grow(c, (void **)&c->d_mx_part, &c->mx_part_cap, (uint64_t)mxp.Q * 8 * mxp.P * 128, sizeof(uint32_t));
-            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);  // (32 bytes per row used)
-            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_cblk, &c->mx_cblk_cap, m_pad / 128, sizeof(double));
-            if (rc) return rc;
-        }
-        if (use_v2) {
-            rc = grow(c, (void **)&c->d_mx_fix, &c->mx_fix_cap, m_pad, sizeof(uint32_t));
-            if (rc == NPS_OK) rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);  // (32 bytes per row used)
-            if (rc) return rc;
         }
         if (mxp.given) {
             rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);
@@ -1894,7 +1868,6 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                         c->d_rtally));
             }
             hipError_t fe;
-            unsigned int *fix_count = c->d_timeout + 16;  // (zero: context creation, or the memset behind the last fold)
             {
                 ProfScope ps(c, mxp.given ? P_ACCUM : P_FUSED);
                 if (mxp.given)
@@ -1902,25 +1875,7 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F,
                                          kept_tallies ? co->d_mx_row_tally + cohort_row0 : c->d_rtally,
                                          b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci, const_slots,
-                                         c->d_mx_cpart, c->d_mx_ops, c->d_mx_cblk, c->d_timeout + 17);
-#ifdef NPS_WITH_MX3
-                else if (use_v2 && mx3_R) {
-                    // (no row of the tables may carry a superblock's number, no word of the partial tallies a step's tag,
-                    //  from an earlier pass)
-                    HIP_TRY(hipMemsetAsync(c->d_mx_part, 0xFF, sizeof(uint32_t) * (uint64_t)mxp.Q * 8 * mxp.P * 128, c->stream));
-                    HIP_TRY(hipMemsetAsync(c->d_mx_ops, 0, 32ull * m_pad, c->stream));
-                    fe = launch_fused_mx3(c->stream, mxp, mx3_R, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
-                                          b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci, const_slots,
-                                          c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count, c->d_mx_part, c->d_mx_ops,
-                                          c->d_mx_cblk, c->d_timeout + 17);
-                }
-#endif
-                else if (use_v2)
-                    fe = launch_fused_mx2(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
-                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut, c->d_rtally,
-                                          c->d_mx_tally1, b == 0 ? c->d_rstats : nullptr, b == 0 ? c->d_nloci : scratch_nloci,
-                                          const_slots, c->d_mx_cpart, c->d_timeout, c->d_mx_fix, fix_count, c->d_mx_ops);
+                                         c->d_mx_cpart, c->d_mx_ops, c->d_mx_cblk, c->d_timeout + 17, c->d_timeout);
                 else
                     fe = launch_fused_mx(c->stream, mxp, co->d_data, gt2x_superblocks(co->n_rows), cohort_row0 >> 7, c->n, m,
                                          runs[b].d_desc, dev_params(c->params), t_maxmis, F, c->d_rlut,
@@ -1939,11 +1894,8 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, const_slots, c->d_part,
                                        c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
                                        (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1,
-                                       use_v2 ? c->d_mx_fix : nullptr, use_v2 ? fix_count : nullptr, co->d_data, c->d_rlut,
-                                       gt2x_superblocks(co->n_rows), cohort_row0 >> 7,
-                                       !use_v2 && !mxp.given && mxp.U < 64 /* launch_fused_mx cut its own strips */));
+                                       !mxp.given && mxp.U < 64 /* launch_fused_mx cut its own strips */));
                 HIP_TRY(hipMemsetAsync(const_slots, 0, sizeof(double) * 2 * mxp.Q, c->stream));
-                if (use_v2) HIP_TRY(hipMemsetAsync(fix_count, 0, sizeof(unsigned int), c->stream));
             }
             c->chunks_used = std::max(c->chunks_used, 1u);
             c->rtally_clean = true;

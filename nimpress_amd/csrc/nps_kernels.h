@@ -296,7 +296,6 @@ struct MxPlan {
     bool ok = false;
     bool given = false;  // the shape does not fit one cooperative grid (more strips than compute units): the row
                          // tallies come from launch_mx_tally, the accumulation runs as an ordinary grid (two reads)
-    bool v2 = false;     // the single-read run may use nps_mx2.hip (code x beta on arrival, is-missing masks parked)
     uint32_t P = 0, Q = 0, nu_last = 0, n_sb = 0, n_flush = 0;  // strips, row teams per strip (superblock k belongs to team k % Q)
     uint64_t cpart_floats = 0;  // digit sums handed to mx_fold_kernel
     // the first form (launch_fused_mx) may cut the unit sequence into strips of U = 62 units instead of the layout's 64
@@ -318,37 +317,15 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
 // plan.given only: the whole-row tallies of the run's rows into d_tally (zero on entry), one read of the matrix
 hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
                            uint64_t n_samples, unsigned long long *d_tally);
-// d_fix_count != nullptr (after launch_fused_mx2): the rows on the list had code x beta accumulated before their tally was
-// known; their products are taken back per sample (exact integers), and d_status[1] receives the list's length
+// keep (or nullptr): the run's complete tally words (nmissing << 28 | neffect, arrival count stripped) are copied there
+// before they are zeroed -- the cohort's kept tallies as a by-product of a single-read pass
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
-                          unsigned long long *d_status, const uint32_t *d_fix_rows = nullptr,
-                          const unsigned int *d_fix_count = nullptr, const void *d_units = nullptr,
-                          const void *d_pre = nullptr, uint64_t n_sb_cohort = 0, uint64_t sb0 = 0,
-                          bool vstrips = false /* the digit sums come from launch_fused_mx with plan.U < 64 */);
-hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          int sentinels /* 0 flags; 1 flags + sentinels in (w1, wfb); 2 sentinels, flags word = superblock + 1 */,
-                          void *d_ops = nullptr /* 32 bytes per padded row: the rows' is-missing operands ready made (nps_mx2.hip) */);
-// nps_mx2.hip: the same pass with code x beta accumulated on arrival and only the is-missing masks parked (three steps of
-// slack for the hand-over); never for plan.given; d_fix_rows: n_rows uint32, d_fix_count: one zeroed word
-hipError_t launch_fused_mx2(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
-                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
-                            int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
-                            unsigned long long *d_tally1, nps_locus_stat *d_stats, unsigned long long *d_nloci,
-                            double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
-                            unsigned int *d_fix_count,
-                            void *d_ops /* 32 bytes per padded row (or nullptr): used unless --imp-sample is int_* */);
-constexpr uint64_t kMx2MaxRows = 0xffffffffull;
-// nps_mx3.hip: the same pass with the row tallies completed and the rows' operands made ONCE, by R reducer workgroups on
-// the compute units the strips leave idle.  mx3_reducers: how many a plan leaves room for (0: this form does not apply).
-uint32_t mx3_reducers(int device, const MxPlan &plan);
-hipError_t launch_fused_mx3(hipStream_t st, const MxPlan &plan, uint32_t R, const void *d_units, uint64_t n_sb_cohort,
-                            uint64_t sb0, uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
-                            int64_t t_maxmis, int F, void *d_pre, nps_locus_stat *d_stats, unsigned long long *d_nloci,
-                            double *d_const_sum, float *d_cpart, unsigned int *d_timeout, uint32_t *d_fix_rows,
-                            unsigned int *d_fix_count, uint32_t *d_part, void *d_ops, double *d_const_part,
-                            unsigned int *d_done);
+                          unsigned long long *d_status,
+                          bool vstrips = false /* the digit sums come from launch_fused_mx with plan.U < 64 */,
+                          unsigned long long *d_keep = nullptr, uint64_t n_keep = 0);
+hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre);
 // nps_mxg.hip: the run with its row tallies GIVEN (plan.given: kept with the cohort, or from launch_mx_tally): per-row
 // decisions + operands, then an ordinary grid of P x Q workgroups.  d_ops: 48 bytes per row padded to 128 rows;
 // d_const_part: one double per superblock; d_done: one zeroed word (zero again afterwards); d_const_sum as for launch_fused_mx
@@ -356,7 +333,8 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
                            int64_t t_maxmis, int F, const unsigned long long *d_tally, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, void *d_ops,
-                           double *d_const_part, unsigned int *d_done);
+                           double *d_const_part, unsigned int *d_done,
+                           unsigned int *d_timeout /* raised when a wave's wait for its operand tables expires */);
 // rows [row0, row0+n_rows) (row0 a multiple of 128) of a cohort of n_rows_cohort rows; rows past the end inside
 // the last superblock written become zero
 hipError_t launch_synth_gt2x(hipStream_t st, void *d_units, uint64_t n_samples, uint64_t n_rows_cohort, uint64_t row0,

@@ -30,6 +30,7 @@
 //     accumulate k (LDS -> MFMA)            control wave: tables of k before the barrier, publish k+2 after it
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "nps_kernels.h"
@@ -43,37 +44,25 @@ __device__ unsigned long long g_mx_timers[16][16];  // [wave][phase]: cycles sum
 #else
 #define MXT(i) do { } while (0)
 #endif
-// sentinels (nps_mx2.hip): the two flags also travel inside (w1, wfb) -- kMxDeadW1 / kMxNanWfb -- because that kernel's
-// control waves read only those sixteen bytes of a row when they make its operands; rows [n_rows, n_pad) are zeroed
-// (their digits are fetched with the last superblock's)
+// Per score row, everything that does not depend on the row's tally (MxPre); rows [n_rows, n_pad) are zeroed (their digits
+// are fetched with the last superblock's)
 __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__restrict__ desc, uint64_t n_rows, uint64_t n_pad,
-                                                      DevParams prm, double scale, int sentinels, MxPre *__restrict__ pre,
-                                                      v4u *__restrict__ ops) {
-    // (sentinels == 2, nps_mx3.hip: the flags word is replaced by the row's superblock + 1 -- the mark by which a strip
-    //  sees that its LDS-DMA of the beta digits has landed; the flags travel as sentinels)
+                                                      DevParams prm, double scale, MxPre *__restrict__ pre) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_pad) return;
     MxPre o;
     o.c[0] = o.c[1] = o.c[2] = 0u;
     o.flags = 0u;
     o.w1 = o.wfb = 0;
-    // ops (nps_mx2.hip with --imp-sample ps / homref / fail, where the weight of a missing genotype does not depend on the
-    // row's tally): the row's two is-missing operands ready made, [superblock][even | odd operand][128 rows in mx_perm
-    // order] x 16 bytes -- the layout of the kernel's Bm table, which it fills by LDS-DMA; dword 3 of the even row = flags
-    const uint64_t ops_at = (j >> 7) * 256 + (uint64_t)mx_perm((int)(j & 127));
     if (j >= n_rows) {
-        if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
         pre[j] = o;
-        if (ops) ops[ops_at] = ops[ops_at + 128] = v4u{0u, 0u, 0u, 0u};
         return;
     }
-    uint32_t me[3] = {0u, 0u, 0u}, mo[3] = {0u, 0u, 0u};
     const double beta = desc[j].beta, eaf = desc[j].eaf;
     const bool rie = desc[j].ref_is_effect != 0;
     const double inf = __builtin_huge_val(), nan = __longlong_as_double(0x7ff8000000000000ll);
     if (!(fabs(beta) < inf)) {
         o.flags = 1u;
-        if (sentinels) o.w1 = kMxDeadW1;
     } else {
         o.w1 = __double2ll_rn(beta * scale);
         mx_codes(o.w1, 0u, o.c);
@@ -81,23 +70,13 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
                            : (prm.imp_sample == NPS_SAMPLE_FAIL || prm.imp_sample == NPS_SAMPLE_INT_FAIL) ? nan
                                                                                                           : eaf * 2.0;
         const double t = imp * beta;  // the product the reference adds for a missing sample (nimpress.nim:639)
-        long long wfb;
         if (!(fabs(t) < inf)) {
             o.flags = 2u;
-            wfb = 3 * o.w1;
-            o.wfb = sentinels ? kMxNanWfb : wfb;
+            o.wfb = 3 * o.w1;
         } else {
-            o.wfb = wfb = __double2ll_rn(t * scale);
+            o.wfb = __double2ll_rn(t * scale);
         }
-        // (as mx_row makes them from (w1, wfb, flags) when the imputed dosage does not come from the row's tally)
-        mx_codes(wfb - 3 * o.w1, o.flags >> 1, me);
-        mx_codes(wfb - 4 * o.w1, o.flags >> 1, mo);
     }
-    if (ops) {
-        ops[ops_at] = v4u{me[0], me[1], me[2], o.flags};
-        ops[ops_at + 128] = v4u{mo[0], mo[1], mo[2], 0u};
-    }
-    if (sentinels == 2) o.flags = (uint32_t)(j >> 7) + 1u;
     pre[j] = o;
 }
 
@@ -112,7 +91,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int UB, int UC, bool VS>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -121,8 +100,12 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
     if (n_t == 0) return;  // (workgroup-uniform; the plan keeps Q <= n_sb)
     constexpr bool is_ctl = CTL;
     const int nu = strip == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
-    // units per wave: UA for data waves 0..3, UB for data waves 4, 5 (the second data wave of SIMD 0 / 1), UC for the control waves
-    const int u0 = wave < 4 ? wave * UA : wave < 6 ? 4 * UA + (wave - 4) * UB : 4 * UA + 2 * UB + (wave - 6) * UC;
+    // units per wave: UA for data waves 0, 1, U2 for data waves 2, 3 (which share SIMD 2 / 3 with the control waves), UB for data
+    // waves 4, 5 (the second data wave of SIMD 0 / 1), UC for the control waves
+    const int u0 = wave < 2   ? wave * UA
+                   : wave < 4 ? 2 * UA + (wave - 2) * U2
+                   : wave < 6 ? 2 * UA + 2 * U2 + (wave - 4) * UB
+                              : 2 * UA + 2 * U2 + 2 * UB + (wave - 6) * UC;
     const int crow = lane + 64 * (wave - kDW);  // control waves: the row of the superblock this lane works for
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
@@ -159,20 +142,41 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 #pragma unroll
         for (int u = 0; u < NU; ++u) bank[s][u] = v4u{0u, 0u, 0u, 0u};
 
-    auto load_unit = [&](uint32_t k, int u) -> v4u {
+    // (VS) a superblock's two segment bases are made ONCE per superblock and pinned as two scalar pairs: left to itself the
+    // compiler keeps one induction pointer per unit and layout strip and spills scalars into vector lanes for them (round 5:
+    // 135 of them, 3.5 v_readlane per unit and step on the waves that set the step)
+    struct SbPtr {
+        const char *pa, *pb;
+    };
+    const char *const sbase_b2 = sbase_b - (int64_t)bnd * 1024;
+    auto sb_ptr = [&](uint32_t k) -> SbPtr {
+        SbPtr r{nullptr, nullptr};
         if constexpr (VS) {
-            const char *p = u < bnd ? sbase_a + (uint64_t)k * sstride_a + (uint32_t)u * 1024u
-                                    : sbase_b + (uint64_t)k * sstride_b + (uint32_t)(u - bnd) * 1024u;
-            return __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + lane_off));
+            r.pa = sbase_a + (uint64_t)k * sstride_a;
+            r.pb = sbase_b2 + (uint64_t)k * sstride_b;
+#ifdef NPS_MX_SADDR
+            asm volatile("" : "+s"(r.pa), "+s"(r.pb));
+#endif
+        }
+        return r;
+    };
+    auto load_unit = [&](uint32_t k, int u, const SbPtr &sp) -> v4u {
+        if constexpr (VS) {
+            // (an explicit global pointer: the pinned scalars hide where they came from, and a flat load would count on the
+            //  LDS counter as well)
+            typedef const v4u __attribute__((address_space(1))) *gptr;
+            const char *p = (u < bnd ? sp.pa : sp.pb) + (uint32_t)u * 1024u;
+            return __builtin_nontemporal_load((gptr)(uintptr_t)(p + lane_off));
         } else {
             return __builtin_nontemporal_load(base + (uint64_t)k * sb_stride + u * 64);
         }
     };
     auto load_sb = [&](uint32_t k, v4u(&dst)[NU]) {
         if (k >= n_t) return;
+        const SbPtr sp = sb_ptr(k);
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-            if (full || u < n_my) dst[u] = load_unit(k, u);
+            if (full || u < n_my) dst[u] = load_unit(k, u, sp);
     };
 
     // tallyAlleles over the wave's units of a superblock: a lane holds rows 2*lane, 2*lane+1 (32 samples each) of
@@ -203,12 +207,13 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         if (n_my == 0) return;
         Tal t;
         if (k + 3 < n_t) {  // steady state: no per-unit conditions
+            const SbPtr sp = sb_ptr(k + 3);
 #pragma unroll
             for (int u = 0; u < NU; ++u)
                 if (full || u < n_my) {
                     tally_unit(t, b_tal[u]);
                     if (!(DBG & 16)) *reinterpret_cast<v4u *>(s_park + u * 1024 + woff) = b_park[u];
-                    b_park[u] = load_unit(k + 3, u);
+                    b_park[u] = load_unit(k + 3, u, sp);
                 }
             tally_add(k + 2, t);
         } else {
@@ -234,6 +239,50 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
             Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
         }
+#ifdef NPS_MX_INTERLEAVE
+        // One unit = four operand registers x four operands, four matrix instructions.  Issued as "all 24 vector instructions,
+        // then the four MFMAs" (what the compiler makes of the plain loop below) a wave's matrix pipe idles while the operands
+        // are made and its vector issue idles while the dependent MFMA pairs drain.  Here every MFMA is issued as soon as ITS
+        // operand exists, with the next operand's vector work behind it, and the transposed reads of the NEXT unit are under
+        // way during the whole unit: ce -> MFMA -> co -> MFMA -> me -> MFMA -> mo -> MFMA.
+        v2i n01 = tr4(slot + r1off), n23 = tr4(slot + r2off);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (full || u < n_my) {
+                const v2i t01 = n01, t23 = n23;
+                if (u + 1 < NU && (full || u + 1 < n_my)) {
+                    n01 = tr4(slot + (u + 1) * 1024 + r1off);
+                    n23 = tr4(slot + (u + 1) * 1024 + r2off);
+                }
+                const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
+                v8i op = {0, 0, 0, 0, 0, 0, 0, 0};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op[r] = (int)(w[r] & 0x33333333u);
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                v8i op2 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op2[r] = (int)((w[r] >> 2) & 0x33333333u);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op2, Bc, C[u][1], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t hl[4];
+                v8i op3 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hl[r] = w[r] & (w[r] >> 1);
+                    op3[r] = (int)(hl[r] & 0x11111111u);
+                }
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op3, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                v8i op4 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op4[r] = (int)(hl[r] & 0x44444444u);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op4, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (full || u < n_my) {
@@ -255,6 +304,7 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
             }
         }
+#endif
     };
 
     auto store_c = [&](uint32_t f, bool zero) {
@@ -506,9 +556,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 //           against 9.7 ms), so the launcher picks by the plan.
 //   10 + 9 + 2, VS  strips of 62 units cut from the unit sequence instead of the layout's 64 (MxArgs.U): more strips, hence more
 //           compute units at work, and nineteen units instead of twenty on the two SIMDs that set the step.
-template <int DBG, bool GIVEN, int UA, int UB, int UC, bool VS>
+template <int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, int U = (VS ? 62 : 64)>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
-    static_assert(kDW == 6 && 4 * UA + 2 * UB + 2 * UC == (VS ? 62 : 64) && UC >= 1, "units of a strip");
+    static_assert(kDW == 6 && 2 * UA + 2 * U2 + 2 * UB + 2 * UC == U && UC >= 1 && (VS || U == 64), "units of a strip");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
@@ -519,46 +569,44 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
         // 245 strips the step is set by the hand-over chain instead and the priority costs up to 2.5 %
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
         // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units)
-        const int uc0 = 4 * UA + 2 * UB + (wave - kDW) * UC;
+        const int uc0 = 2 * UA + 2 * U2 + 2 * UB + (wave - kDW) * UC;
         if (nu - uc0 >= UC)
-            mx_body<UC, false, true, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+            mx_body<UC, false, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<UC, true, true, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
-    } else if (wave < 4) {
+            mx_body<UC, true, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+    } else if (wave < 2) {
         if (nu - wave * UA >= UA)
-            mx_body<UA, false, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+            mx_body<UA, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<UA, true, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+            mx_body<UA, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+    } else if (wave < 4) {
+        if (nu - (2 * UA + (wave - 2) * U2) >= U2)
+            mx_body<U2, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+        else
+            mx_body<U2, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     } else {
-        if (nu - (4 * UA + (wave - 4) * UB) >= UB)
-            mx_body<UB, false, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+        if (nu - (2 * UA + 2 * U2 + (wave - 4) * UB) >= UB)
+            mx_body<UB, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<UB, true, false, DBG, GIVEN, UA, UB, UC, VS>(a, smem);
+            mx_body<UB, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     }
 }
 
 // Epilogue of a pass: the sixteen digit sums of a sample -> float64, plus the pass's locus constants, into chunk 0
 // of the context's partial scores; the tally words go back to zero; a raised bounded-wait word is recorded.
-// fix (nps_mx2.hip runs): the rows over --maxmis had their code x beta accumulated before their tally was known; the
-// reference replaces every sample's dosage of such a row (nimpress.nim:565-571), so the products are taken back here --
-// this sample's codes of just those rows are re-read (8 bytes per row and 32 samples) and summed as exact integers.
-struct MxFix {
-    const uint32_t *rows;              // [*count] rows of the run, in any order (integer sums commute)
-    const unsigned int *count;         // nullptr: nothing to take back
-    const unsigned long long *units;   // the cohort
-    const MxPre *pre;                  // w1 = round(beta 2^F) per row of the run
-    uint64_t n_sb_cohort;
-    uint32_t sb0, nu_last;
-};
+// keep (or nullptr): the run's complete whole-row tallies are copied there (arrival count stripped) before the words are
+// zeroed -- a cohort's kept tallies as a by-product of its first single-read pass.
 __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ cpart, uint32_t n_sb, uint32_t Q, uint32_t P, uint32_t U,
                                                       uint64_t n, double inv_scale, const double *__restrict__ const_sum,
                                                       double *__restrict__ part0, int overwrite,
                                                       unsigned long long *__restrict__ tally, uint64_t n_tally,
                                                       unsigned long long *__restrict__ tally1, uint64_t n_tally1,
                                                       unsigned int *__restrict__ timeout,
-                                                      unsigned long long *__restrict__ status, const MxFix fix) {
+                                                      unsigned long long *__restrict__ status,
+                                                      unsigned long long *__restrict__ keep, uint64_t n_keep) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    for (uint64_t j = i; j < n_keep; j += nthreads) keep[j] = tally[j] & 0x00FFFFFFFFFFFFFFull;
     for (uint64_t j = i; j < n_tally; j += nthreads) tally[j] = 0ull;
     for (uint64_t j = i; j < n_tally1; j += nthreads) tally1[j] = 0ull;
     if (i == 0 && timeout) {
@@ -600,22 +648,6 @@ __global__ __launch_bounds__(256) void mx_fold_kernel(const float *__restrict__ 
             lo += l;
             hi += h;
             isnan_ = isnan_ || t[15 * 4] != 0.f;
-        }
-    }
-    if (fix.count) {
-        const unsigned int n_fix = *fix.count;
-        if (i == 0) status[1] = n_fix;  // (how many rows of this pass were over --maxmis)
-        const uint32_t nu = strip == P - 1 ? fix.nu_last : 64u;
-        const unsigned long long *ubase = fix.units + (strip * 64 * fix.n_sb_cohort * 64 + unit * 64) * 2;  // (in 8-byte rows)
-        // sum of value x w1 with w1 = h 2^28 + l: |h| < 2^28, 0 <= l < 2^28, value <= 4 -- the same split as above
-        for (unsigned int j = 0; j < n_fix; ++j) {
-            const uint32_t row = fix.rows[j];
-            const unsigned long long w = ubase[((uint64_t)(fix.sb0 + (row >> 7)) * nu * 64) * 2 + (row & 127u)];
-            const uint32_t code = (uint32_t)(w >> (2 * s)) & 3u;
-            const long long v = (long long)((s & 1u) && code == 3u ? 4u : code);  // (odd sample of a pair: 0, 1, 2, 4)
-            const long long w1r = fix.pre[row].w1, w1 = w1r == kMxDeadW1 ? 0 : w1r;  // (a non-finite beta has no digits)
-            hi -= v * (w1 >> 28);
-            lo -= v * (w1 & 0xFFFFFFFll);
         }
     }
     const double total = (double)hi * 268435456.0 + (double)lo;
@@ -887,7 +919,6 @@ hipError_t mx_plan(int device, uint64_t n_samples, uint64_t n_rows, bool two_pas
         }
     }
     plan->cpart_floats = (uint64_t)plan->n_flush * q * std::max(gm.P, plan->Pv) * 64 * 2 * 256;
-    plan->v2 = !plan->given && n_rows <= kMx2MaxRows;
     plan->ok = true;
     return hipSuccess;
 }
@@ -905,12 +936,11 @@ hipError_t launch_mx_tally(hipStream_t st, const MxPlan &plan, const void *d_uni
     return hipGetLastError();
 }
 
-hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre,
-                          int sentinels, void *d_ops) {
+hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n_rows, DevParams prm, int F, void *d_pre) {
     (void)hipGetLastError();
     const uint64_t n_pad = (n_rows + 127) / 128 * 128;
     hipLaunchKernelGGL(mx_prep_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, st, d_desc, n_rows, n_pad, prm,
-                       std::ldexp(1.0, F), sentinels, (MxPre *)d_pre, (v4u *)d_ops);
+                       std::ldexp(1.0, F), (MxPre *)d_pre);
     return hipGetLastError();
 }
 
@@ -920,37 +950,62 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                            unsigned long long *d_tally1, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, unsigned int *d_timeout) {
     {
-        hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre, 0);
+        hipError_t pe = launch_mx_prep(st, d_desc, n_rows, prm, F, d_pre);
         if (pe != hipSuccess) return pe;
     }
     // one row team (more than 128 strips): the control waves carry two units instead of five (see fused_mx_kernel)
-    const bool light_ctl = !plan.given && plan.Q == 1, vstrips = light_ctl && plan.U == 62;
-    const void *fn = plan.given ? (const void *)fused_mx_kernel<0, true, kUD, kUD, kUC, false>
-                     : vstrips   ? (const void *)fused_mx_kernel<0, false, 10, 9, 2, true>
-                     : light_ctl ? (const void *)fused_mx_kernel<0, false, 10, 10, 2, false>
-                                 : (const void *)fused_mx_kernel<0, false, kUD, kUD, kUC, false>;
+    if (plan.given) return hipErrorInvalidValue;  // (given tallies: launch_mx_given, nps_mxg.hip)
+    const bool light_ctl = plan.Q == 1, vstrips = light_ctl && plan.U < 64;
+    const void *fn = nullptr;
+    if (vstrips) {
+        switch (plan.U) {
+        case 62: fn = (const void *)fused_mx_kernel<0, false, 10, 10, 9, 2, true, 62>; break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        fn = light_ctl ? (const void *)fused_mx_kernel<0, false, 10, 10, 10, 2, false> : (const void *)fused_mx_kernel<0, false, kUD, kUD, kUD, kUC, false>;
+    }
 #ifdef NPS_DIAGNOSTICS
-    // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out
+    // diagnostics builds only (tools/mkexp.sh -DNPS_DIAGNOSTICS): NPS_MX_DEBUG selects a kernel with parts left out (1 no tally
+    // popcounts, 4 no hand-over, 5 neither), NPS_MX_SPLIT=UA,U2,UB,UC another split of a 62-unit strip over the eight waves
     static const int dbg = getenv("NPS_MX_DEBUG") ? atoi(getenv("NPS_MX_DEBUG")) : 0;
-    if (!plan.given) switch (dbg) {
-        case 1: fn = (const void *)fused_mx_kernel<1, false, kUD, kUD, kUC, false>; break;
-        case 2: fn = (const void *)fused_mx_kernel<2, false, kUD, kUD, kUC, false>; break;
-        case 3: fn = (const void *)fused_mx_kernel<3, false, kUD, kUD, kUC, false>; break;
-        case 4: fn = (const void *)fused_mx_kernel<4, false, kUD, kUD, kUC, false>; break;
-        case 5: fn = (const void *)fused_mx_kernel<5, false, kUD, kUD, kUC, false>; break;
-        case 6: fn = (const void *)fused_mx_kernel<6, false, kUD, kUD, kUC, false>; break;
-        case 7: fn = (const void *)fused_mx_kernel<7, false, kUD, kUD, kUC, false>; break;
-        case 15: fn = (const void *)fused_mx_kernel<15, false, kUD, kUD, kUC, false>; break;
-        case 31: fn = (const void *)fused_mx_kernel<31, false, kUD, kUD, kUC, false>; break;
+    if (vstrips && plan.U == 62) {
+        switch (dbg) {
+        case 1: fn = (const void *)fused_mx_kernel<1, false, 10, 10, 9, 2, true, 62>; break;
+        case 4: fn = (const void *)fused_mx_kernel<4, false, 10, 10, 9, 2, true, 62>; break;
+        case 5: fn = (const void *)fused_mx_kernel<5, false, 10, 10, 9, 2, true, 62>; break;
         default: break;
         }
+        if (const char *sp = getenv("NPS_MX_SPLIT")) {
+            int ua = 0, u2 = 0, ub = 0, uc = 0;
+            if (sscanf(sp, "%d,%d,%d,%d", &ua, &u2, &ub, &uc) == 4) {
+                const int key = ua * 1000 + u2 * 100 + ub * 10 + uc;
+                switch (key) {
+                case 10 * 1000 + 10 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 10, 10, 8, 3, true, 62>; break;
+                case 9 * 1000 + 10 * 100 + 9 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 9, 3, true, 62>; break;
+                case 9 * 1000 + 10 * 100 + 8 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 8, 4, true, 62>; break;
+#ifdef NPS_MX_INTERLEAVE
+                case 9 * 1000 + 11 * 100 + 9 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 9, 11, 9, 2, true, 62>; break;
+                case 9 * 1000 + 12 * 100 + 8 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 9, 12, 8, 2, true, 62>; break;
+                case 8 * 1000 + 12 * 100 + 9 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 8, 12, 9, 2, true, 62>; break;
+                case 9 * 1000 + 11 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 9, 11, 8, 3, true, 62>; break;
 #endif
-    static const void *attr_set[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int which = plan.given ? 1 : (vstrips ? 3 : light_ctl ? 2 : 0);
-    if (attr_set[which] != fn) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set[which] = fn;
+                default: fprintf(stderr, "NPS_MX_SPLIT %s is not compiled in\n", sp); return hipErrorInvalidValue;
+                }
+            }
+        }
+    }
+#endif
+    static const void *attr_set[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    {
+        int slot = 0;
+        while (slot < 8 && attr_set[slot] && attr_set[slot] != fn) ++slot;
+        if (slot == 8) slot = 0;  // (more kernels than slots: set the attribute again)
+        if (attr_set[slot] != fn) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+            if (e != hipSuccess) return e;
+            attr_set[slot] = fn;
+        }
     }
     MxArgs a;
     a.units = (const v4u *)d_units;
@@ -981,13 +1036,6 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     // strips per first-stage group (measured at 16 / 32 / 48 / 64, ms per 1M rows: 200 000 samples 9.48 / 9.27 / 9.07 /
     // 9.09, 400 000 20.1 / 19.6 / 19.6 / 19.7, 500 000 23.80 / 23.55 / 23.48 / 23.49; 8: slower, 128: slower)
     a.grp_strips = 48u;
-    a.fix_rows = nullptr;
-    a.fix_count = nullptr;
-    a.part = nullptr;
-    a.ops = nullptr;
-    a.const_part = nullptr;
-    a.done = nullptr;
-    a.R = 0;
 #ifdef NPS_MX_GRP_ENV
     if (getenv("NPS_MX_GRP")) {  // (experiment builds) 0 = balanced groups of at most 64
         const int g = atoi(getenv("NPS_MX_GRP"));
@@ -997,10 +1045,6 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     if (getenv("NPS_MX_PRIO")) a.ctl_prio = (uint32_t)atoi(getenv("NPS_MX_PRIO"));
 #endif
     const dim3 grid((vstrips ? plan.Pv : plan.P) * plan.Q);
-    if (plan.given) {  // independent workgroups: an ordinary launch, whatever the grid's size
-        hipLaunchKernelGGL((fused_mx_kernel<0, true, kUD, kUD, kUC, false>), grid, dim3(kMxThreads), kLdsBytes, st, a);
-        return hipGetLastError();
-    }
     void *args[] = {&a};
 #ifdef NPS_MX_TIMERS
     {
@@ -1027,23 +1071,14 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
 hipError_t launch_mx_fold(hipStream_t st, const MxPlan &plan, const float *d_cpart, uint64_t n_samples, int F,
                           const double *d_const_sum, double *d_part0, int overwrite, unsigned long long *d_tally,
                           uint64_t n_tally, unsigned long long *d_tally1, uint64_t n_tally1, unsigned int *d_timeout,
-                          unsigned long long *d_status, const uint32_t *d_fix_rows, const unsigned int *d_fix_count,
-                          const void *d_units, const void *d_pre, uint64_t n_sb_cohort, uint64_t sb0, bool vstrips) {
+                          unsigned long long *d_status, bool vstrips, unsigned long long *d_keep, uint64_t n_keep) {
     (void)hipGetLastError();
-    if (vstrips && d_fix_count) return hipErrorInvalidValue;  // (the list of the second form speaks of layout strips)
+    if (n_keep > n_tally) return hipErrorInvalidValue;
     const uint64_t blocks = std::max<uint64_t>(std::max<uint64_t>(1, (n_samples + 255) / 256), std::min<uint64_t>(4096, n_tally1 / 1024));
-    MxFix fix;
-    fix.rows = d_fix_rows;
-    fix.count = d_fix_count;
-    fix.units = (const unsigned long long *)d_units;
-    fix.pre = (const MxPre *)d_pre;
-    fix.n_sb_cohort = n_sb_cohort;
-    fix.sb0 = (uint32_t)sb0;
-    fix.nu_last = plan.nu_last;
     hipLaunchKernelGGL(mx_fold_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_cpart, plan.n_sb, plan.Q,
                        vstrips ? plan.Pv : plan.P, vstrips ? plan.U : 64u, n_samples,
                        std::ldexp(1.0, -F), d_const_sum, d_part0, overwrite, d_tally, n_tally, d_tally1, n_tally1, d_timeout,
-                       d_status, fix);
+                       d_status, d_keep, n_keep);
     return hipGetLastError();
 }
 

@@ -1,6 +1,5 @@
-// nps_mx_common.h -- what the two strip kernels (nps_mx.hip: codes parked two steps, everything behind the tally;
-// nps_mx2.hip: code x beta accumulated on arrival, only the is-missing masks parked) share: argument block, the per-row
-// precomputed part, weight -> FP6 operand bytes, the per-row decisions.  Internal (not part of the C-ABI).
+// nps_mx_common.h -- what the strip kernels (nps_mx.hip: tallies in the pass; nps_mxg.hip: tallies given) share: argument
+// block, the per-row precomputed part, weight -> FP6 operand bytes, the per-row decisions.  Internal (not part of the C-ABI).
 #pragma once
 #include "nps_kernels.h"
 
@@ -72,20 +71,7 @@ struct MxArgs {
     unsigned int *timeout;
     uint32_t ctl_prio;       // the control waves run at raised issue priority (see fused_mx_kernel)
     uint32_t grp_strips;     // strips per first-stage group of the hand-over (16 .. 64: tally1 is sized for groups of 16)
-    // nps_mx2.hip only: the run's rows over --maxmis, whose eager code x beta mx_fold_kernel takes back (appended by strip 0
-    // of the row's team; fix_count zero on entry)
-    uint32_t *fix_rows;
-    unsigned int *fix_count;
-    // nps_mx3.hip only: the strips' partial tallies on their way to the reducer workgroups, the finished is-missing
-    // operands on their way back, the reducers' partial sums of locus constants
-    uint32_t *part;          // [Q][kMx3PartRing][P][128]: tag << 25 | nmissing << 13 | neffect of one strip and row
-    v4u *ops;                // [n_sb][2 operands][128 rows in mx3 table order] x 16 bytes; fourth dword = superblock + 1
-    double *const_part;      // [n_sb]
-    unsigned int *done;      // one zeroed word: reducers that have finished
-    uint32_t R;              // reducer workgroups (blocks P Q .. P Q + R - 1 of the grid)
 };
-constexpr uint32_t kMx3PartRing = 8;  // steps of partial tallies a team may have in flight
-
 static __device__ __forceinline__ v2i tr4(const char *p) {
     return __builtin_amdgcn_ds_read_tr4_b64_v2i32((NPS_LDS v2i *)p);
 }
@@ -97,10 +83,6 @@ static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) { 
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
     return d;
 }
-// where row r's is-missing operands live in a Bm table of the second form (nps_mx2.hip): inside a block of 32 rows the even
-// rows first, then the odd ones (a parked mask word holds rows 2l and 2l+1 bit-interleaved: the transposed read hands a lane
-// 16 even rows, then 16 odd)
-static __host__ __device__ inline int mx_perm(int r) { return (r & 96) | ((r & 1) << 4) | ((r >> 1) & 15); }
 // where row r of a unit lives in its 1 KiB LDS image: a lane's two rows stay together (one ds_write_b128), and
 // the 32 lanes of a half wave read 256 different bytes in both transposed reads
 static __host__ __device__ inline int mx_rowoff(int r) {
@@ -139,9 +121,6 @@ struct MxPre {
     long long w1, wfb;
 };
 static_assert(sizeof(MxPre) == 32, "MxPre layout");
-// nps_mx2.hip reads only (w1, wfb) of a row when it makes the row's operands: the two flags travel as sentinels
-constexpr long long kMxDeadW1 = (long long)0x8000000000000000ull;   // flags & 1: beta is not finite
-constexpr long long kMxNanWfb = (long long)0x8000000000000000ull;   // flags & 2: the imputed dosage x beta is NaN
 static_assert(kDW * kUD + 2 * kUC == 64, "units of a strip");
 
 // n / d for 0 <= n <= d < 2^27 (0 / 0 = NaN), within an ulp: the weights it feeds are rounded to 2^-56 anyway

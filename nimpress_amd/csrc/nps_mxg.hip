@@ -46,6 +46,7 @@ struct MxgArgs {
     uint32_t Q;              // row teams per strip: superblock k of the run belongs to team k % Q
     const v4u *ops;          // [n_sb][3][128] x 16 bytes from mx_ops_kernel; the fourth dword of a row = its superblock + 1
     float *cpart;            // [n_flush][Q][P][64][2][256]
+    unsigned int *timeout;   // raised when a wave gives up waiting for its operand tables (mx_fold_kernel: sticky status)
 };
 
 // ---- per row: decisions, statistics, operands --------------------------------------------------------------------
@@ -186,12 +187,19 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
         if (wave >= 6 || k >= n_t) return;
         const uint32_t want = team + k * a.Q + 1u;
         const char *p = smem + kGTab + (k & 1u) * 6144u + wave * 1024 + lane * 16 + 12;
+        bool landed = false;
         for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
             asm volatile("" ::: "memory");
             const uint32_t tag = *reinterpret_cast<const uint32_t *>(p);
-            if (__all(tag == want)) break;
+            if (__all(tag == want)) {
+                landed = true;
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
+        // a wave that gives up would multiply by stale or partial operands: say so (the pass then fails with NPS_E_TIMEOUT
+        // instead of returning wrong scores; nps_mx.hip's bounded waits do the same)
+        if (!landed && lane == 0) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     auto store_c = [&](uint32_t f, bool zero) {
@@ -238,6 +246,9 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
             C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(co, Bc, C[u][1], 4, 2, 0, 127, 0, 130);
             C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(me, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
             C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bmo, C[u][1], 4, 2, 0, 126, 0, 130);
+#ifdef NPS_MXG_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);  // (three banks: the operands of one unit alive at a time)
+#endif
         };
         if (k + kBanks < n_t) {
 #pragma unroll
@@ -261,8 +272,8 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     dma_tables(0);
-    load_sb(0, bank[0]);
-    if (kBanks > 1) load_sb(1, bank[kBanks - 1]);
+#pragma unroll
+    for (int b = 0; b < kBanks; ++b) load_sb((uint32_t)b, bank[b]);
     tables_landed(0);
     __syncthreads();
 #ifdef NPS_MX_TIMERS
@@ -281,14 +292,11 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
         __syncthreads();
         GXT(3);
     };
-    if (kBanks == 1) {
-        for (uint32_t k = 0; k < n_t; ++k) step(k, bank[0]);
-    } else {
-        const uint32_t n_steps = (n_t + 1) / 2 * 2;
-        for (uint32_t k = 0; k < n_steps; k += 2) {
-            step(k + 0, bank[0]);
-            step(k + 1, bank[kBanks - 1]);
-        }
+    // (the banks are register arrays: the loop is unrolled by their number so that every step names its bank)
+    const uint32_t n_steps = (n_t + kBanks - 1) / kBanks * kBanks;
+    for (uint32_t k = 0; k < n_steps; k += kBanks) {
+#pragma unroll
+        for (int b = 0; b < kBanks; ++b) step(k + (uint32_t)b, bank[b]);
     }
     store_c((n_t - 1) / kFlushSb, false);
 #ifdef NPS_MX_TIMERS
@@ -315,7 +323,7 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
                            int64_t t_maxmis, int F, const unsigned long long *d_tally, nps_locus_stat *d_stats,
                            unsigned long long *d_nloci, double *d_const_sum, float *d_cpart, void *d_ops,
-                           double *d_const_part, unsigned int *d_done) {
+                           double *d_const_part, unsigned int *d_done, unsigned int *d_timeout) {
     if (!plan.ok || !plan.given) return hipErrorInvalidValue;
     (void)hipGetLastError();
     MxArgs ra;  // (what mx_row reads)
@@ -342,13 +350,6 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
     ra.timeout = nullptr;
     ra.ctl_prio = 0;
     ra.grp_strips = 0;
-    ra.fix_rows = nullptr;
-    ra.fix_count = nullptr;
-    ra.part = nullptr;
-    ra.ops = nullptr;
-    ra.const_part = nullptr;
-    ra.done = nullptr;
-    ra.R = 0;
     hipLaunchKernelGGL(mx_ops_kernel, dim3(plan.n_sb), dim3(128), 0, st, d_desc, n_rows, d_tally, ra, (v4u *)d_ops,
                        d_const_part, d_done);
     hipError_t e = hipGetLastError();
@@ -369,6 +370,7 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
     a.Q = plan.Q;
     a.ops = (const v4u *)d_ops;
     a.cpart = d_cpart;
+    a.timeout = d_timeout;
     hipLaunchKernelGGL(mx_given_kernel, dim3(plan.P * plan.Q), dim3(kGW * 64), kGLdsBytes, st, a);
 #ifdef NPS_MX_TIMERS
     {
@@ -376,7 +378,7 @@ hipError_t launch_mx_given(hipStream_t st, const MxPlan &plan, const void *d_uni
         unsigned long long h[8][8];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mxg_timers), sizeof(h));
         static const char *nm[5] = {"dma-issue", "work", "landing", "barrier", "loop"};
-        for (int w : {0, 3, 7}) {
+        for (int w = 0; w < kGW; ++w) {
             fprintf(stderr, "mxg timers wave %d (cycles per step, %llu steps):", w, h[w][7]);
             for (int i = 0; i < 5; ++i) fprintf(stderr, "  %s %.0f", nm[i], (double)h[w][i] / (double)std::max<unsigned long long>(h[w][7], 1));
             fprintf(stderr, "\n");

@@ -97,6 +97,30 @@ def test_bench_three_ranks_strong_scaling_rehearsal():
     assert d["config"]["parallelism"].startswith("one score, rows sharded x3")
 
 
+def test_bench_eight_ranks_weak_scaling_rehearsal():
+    """The driver's N = 8 command has never met an 8-GPU node (SCALE_rNN: skipped): its whole host path -- eight ranks, the
+    all-gather of eight score rows, both strong-scaling legs, the compact line -- runs here over gloo.  The line must stay
+    under 4 KiB with `multi_gpu` summarised, and report the eight ranks it really had."""
+    full = {}
+    d = _rehearse(8, [], full=full)
+    assert d["rehearsal"] and d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"].startswith("score-sharded x8") and d["config"]["nloci"] == 640
+    legs = d["multi_gpu"]
+    gt, ds = legs["configs2_gt_rows_sharded"], legs["configs4_ds_rows_sharded"]
+    assert gt["scaling"] == ds["scaling"] == "strong" and gt["n_gpus"] == ds["n_gpus"] == 8
+    assert gt["nloci"] == 640 and ds["nloci"] == 1000 and gt["value"] > 0 and ds["value"] > 0
+    assert "workload" not in ds and "workload" in full["multi_gpu"]["configs4_ds_rows_sharded"]
+    # (a rank whose block of rows is empty still takes part in the all-reduce: eight partial sums of 1.0 each)
+    assert abs(d["rehearsal_normalised"][0] - 8.0 / 2000.0) < 1e-15 and d["rehearsal_normalised"][1] == 1000
+
+
+def test_bench_eight_ranks_strong_scaling_rehearsal():
+    d = _rehearse(8, ["--scaling", "strong"])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["nloci"] == 640 and d["config"]["parallelism"].startswith("one score, rows sharded x8")
+    assert abs(d["rehearsal_normalised"][0] - 8.0 / 1280.0) < 1e-15 and d["rehearsal_normalised"][1] == 640
+
+
 def test_bench_legs_watchdog_keeps_the_headline_line():
     """N > 1: if the strong-scaling legs do not finish in time (a collective some rank never reaches), rank 0 still
     prints the headline line -- without the legs -- and ends with status 3 (the other ranks: non-zero)"""

@@ -85,3 +85,5 @@ def test_comm_from_a_plain_c_host(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "comm_driver ok: 1 device(s)" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    # the per-rank lines a first run on N GPUs is read by: one per rank and layout, no MISMATCH
+    assert r.stdout.count("comm_driver rank 0 device 0:") == 2 and "MISMATCH" not in r.stdout, r.stdout[-800:]

@@ -554,77 +554,6 @@ def test_gt2x_kept_tallies_vs_oracle(shape):
     dev.close()
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (33, 1), (2047, 127), (2049, 129), (4096, 257), (20000, 1001), (16385, 47),
-                                   (40000, 385), (70000, 2000), (3000, 40000), (250000, 700), (500000, 2100)])
-def test_gt2x_eager_mode_vs_oracle(shape):
-    """NPS_MODE_FUSED_EAGER (nps_mx2.hip, the round-4 verdict's experiment A): code x beta accumulated when a superblock
-    arrives, the is-missing masks parked three steps, rows over --maxmis taken back by the epilogue from a list (make_cohort
-    puts one row in seven over any --maxmis <= 0.3, so the list is long here).  Same bars as the first form: statistics and
-    nloci bit for bit, scores within 1e-6 relative; and equal to the first form's scores within a few ulps of the sum."""
-    n, m = shape
-    rng = np.random.default_rng(n * 11 + m)
-    co = make_cohort(n, m, 2468, rng)
-    kw = PARAM_GRID[(n + m + 1) % len(PARAM_GRID)]
-    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
-    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
-    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
-    scores, nloci, stats = score_gt2x(dev, n, kw, descs, 0.125, mode=capi.MODE_FUSED_EAGER)
-    one, nloci1, stats1 = score_gt2x(dev, n, kw, descs, 0.125, mode=capi.MODE_FUSED)
-    again, _, _ = score_gt2x(dev, n, kw, descs, 0.125, mode=capi.MODE_FUSED_EAGER)
-    dev.close()
-    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.125)
-    assert nloci == ref_nloci == nloci1
-    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
-    check_scores(scores, ref_scores, co["beta"], nloci)
-    assert np.array_equal(np.isnan(one), np.isnan(scores))
-    both = ~np.isnan(one)
-    assert np.allclose(one[both], scores[both], rtol=1e-12, atol=1e-15)
-    assert np.array_equal(again.view(np.int64), scores.view(np.int64))      # bit-reproducible (integer sums, fixed order)
-
-
-@pytest.mark.parametrize("pk", range(len(PARAM_GRID)))
-def test_gt2x_eager_all_imputation_modes(pk):
-    n, m = 3000, 200
-    rng = np.random.default_rng(1900 + pk)
-    co = make_cohort(n, m, 97 + pk, rng)
-    co["eaf"][5] = np.nan                      # ps imputes NaN for this row
-    co["beta"][9] = np.nan                     # a NaN beta: every sample's sum is NaN, as in the reference (d * NaN)
-    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
-    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
-    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
-    for kw in (PARAM_GRID[pk], dict(PARAM_GRID[pk], maxmis=0.0)):          # (--maxmis=0: EVERY row with a missing call is taken back)
-        scores, nloci, stats = score_gt2x(dev, n, kw, descs, 0.0, mode=capi.MODE_FUSED_EAGER)
-        ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
-        assert nloci == ref_nloci
-        assert_stats_equal(stats, [tuple(s) for s in ref_stats])
-        check_scores(scores, ref_scores, co["beta"], nloci)
-    dev.close()
-
-
-def test_gt2x_eager_mode_refused_where_it_does_not_apply():
-    n, m = 530000, 130
-    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
-    sc = capi.Scorer(n, capi.make_params())
-    with pytest.raises(capi.NpsError) as ei:
-        sc.score_cohort(dev, capi.row_descs(np.ones(m), 0.3 * np.ones(m)), 0, capi.MODE_FUSED_EAGER)
-    assert ei.value.status == capi.E_UNSUPPORTED
-    sc.close()
-    dev.close()
-    # on a row-layout cohort the mode means NPS_MODE_FUSED
-    rng = np.random.default_rng(3)
-    co = make_cohort(5000, 64, 11, rng)
-    g = capi.Cohort(5000, 64)
-    g.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
-    sc = capi.Scorer(5000, capi.make_params())
-    sc.score_cohort(g, capi.row_descs(co["beta"], co["eaf"], None, co["rie"]), 0, capi.MODE_FUSED_EAGER)
-    scores, nloci = sc.finish(0.0)
-    ref_scores, _, ref_nloci = oracle_scores(co, PARAM_GRID[0], 0.0)
-    assert nloci == ref_nloci
-    check_scores(scores, ref_scores, co["beta"], nloci)
-    sc.close()
-    g.close()
-
-
 @pytest.mark.parametrize("n", [300_000, 530_000])
 def test_auto_counts_tallies_once_where_the_resident_grid_does_not_cover_the_chip(n):
     """NPS_FMT_GT_AUTO is the strip layout at every size now.  300 000 samples (147 strips x 1 team: 147 of 256 compute

@@ -307,3 +307,35 @@ def test_score_many_rows_sharded_over_ranks_all_files_per_rank(tmp_path, world):
         return sorted(l for l in text.splitlines() if l.startswith("[") and "] WARN " in l)
     assert warnings(r.stderr) == warnings(r1.stderr)
     assert len(warnings(r.stderr)) > 0
+
+
+def test_score_many_auto_shard_falls_back_to_files_on_format_ds(tmp_path):
+    """`--shard auto` picks the rows x all-files layout whenever there are several ranks and the
+    genotype file has an index -- but that layout's one-pass multi-score path does not take FORMAT/DS records.  Under
+    `auto` every rank falls back to `--shard files` (agreed through an all-reduce of a flag) and the run equals the
+    single-process one; an explicit `--shard rows` stays a hard error."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_cli as tc
+    n, m = 3000, 40
+    entries, recs = tc._ds_cohort(n, m, 4242)
+    spath, path, samples = tc._write_ds_files(tmp_path, n, entries, recs, False)     # BCF2 + CSI, FORMAT/DS only
+    assert os.path.exists(path + ".csi")
+    spath2 = str(tmp_path / "ds_b.score")
+    shutil.copy(spath, spath2)
+    env = dict(os.environ, NIMPRESS_DIST_BACKEND="gloo")
+    exe = [sys.executable, os.path.join(ROOT, "tools", "score_many.py")]
+    out1, out2 = str(tmp_path / "m1.tsv"), str(tmp_path / "m2.tsv")
+    r1 = subprocess.run(exe + ["--gpus", "1", "--afmisp=0", "--out", out1, spath, spath2, path], capture_output=True, text=True,
+                        timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run(exe + ["--gpus", "2", "--afmisp=0", "--out", out2, spath, spath2, path], capture_output=True, text=True,
+                        env=env, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert "sharding the score files instead" in r2.stderr and "rows sharded over the GPUs" not in r2.stderr, r2.stderr[-800:]
+    assert open(out1).read() == open(out2).read()
+    r3 = subprocess.run(exe + ["--gpus", "2", "--shard", "rows", "--afmisp=0", "--out", str(tmp_path / "m3.tsv"), spath, spath2,
+                               path], capture_output=True, text=True, env=env, timeout=600)
+    assert r3.returncode != 0 and "one-pass" in r3.stderr, r3.stderr[-1500:]

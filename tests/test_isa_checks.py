@@ -102,16 +102,6 @@ def test_mx_look_registers_untouched_until_the_hand_written_wait(tmp_path):
     assert n >= 2   # (two control-wave bodies -- full and ragged strips -- per instantiated kernel)
 
 
-def test_mx2_returning_add_registers_untouched_until_the_hand_written_wait(tmp_path):
-    """nps_mx2.hip: the returning add of the publication (`global_atomic_add_x2 ... sc0` in inline asm); its looks and
-    table fetches are LDS-DMA and have no register destination at all"""
-    lines = device_asm(os.path.join(CSRC, "nps_mx2.hip"), tmp_path)
-    n = check_windows(lines, re.compile(r"global_atomic_add_x2\s+(v\[\d+:\d+\]),.*\bsc0\b"), "nps_mx2.hip returning add")
-    assert n >= 2
-    text = "\n".join(lines)
-    assert "global_load_lds_dwordx4" in text and not re.search(r"global_load_dwordx2\s+v\[\d+:\d+\],.*\bsc1\b.*\n\s*;;#ASMEND", text)
-
-
 def test_register_bound_kernels_do_not_spill(tmp_path):
     """Two kernels sit at their register limit by design and lose a third of their speed with the first spilled register:
     the float32 single-read DS kernel (128 VGPRs: sixteen waves per compute unit; round 5: a harmless-looking change of its

@@ -140,9 +140,10 @@ def _row_matrix_worker(rank, world, port, n, m, S, ret):
                 sc.row_gt(refcpu.codes_to_gt(codes[j], n), 2, 1, False, beta[j], eaf[j])
             sums[s_], nloci[s_] = sc.partial()
             sc.finish(0.0)
+        local = (r0, r1, float(np.abs(sums).max()) if sums.size else 0.0, nloci.copy())
         t, total = multi.all_reduce_partial_matrix(torch.from_numpy(sums), nloci)
         out = multi.normalize_matrix(t, total, [0.1 * s_ for s_ in range(S)])
-        ret[rank] = (out.numpy().copy(), total.numpy().copy())
+        ret[rank] = (out.numpy().copy(), total.numpy().copy(), local)
     finally:
         dist.destroy_process_group()
 
@@ -160,9 +161,53 @@ def test_row_sharded_multi_score_all_reduce(m):
         ref, _, ref_nloci = refcpu.score_packed(codes, n, np.zeros(m, np.int32), np.zeros(m, np.int32), beta, eaf,
                                                 refcpu.make_params("ps", "homref", "int_ps", 0.05, 10), 0.1 * s_)
         for r in range(world):
-            got, total = ret[r]
+            got, total, _ = ret[r]
             assert total[s_] == ref_nloci
             assert np.allclose(got[s_], ref, rtol=0, atol=1e-13 * max(1.0, np.abs(beta).sum()))
+
+
+# ---- world size 8 (no 8-GPU node has ever been available, so the N = 8 shapes are rehearsed here) ----
+@pytest.mark.parametrize("n_scores", [8, 11, 5])
+def test_sharded_scores_gathered_in_order_world8(n_scores):
+    """configs[3] in miniature: 8 (or more, or fewer) score definitions over 8 ranks, one all-gather (nimpress.nim:747-753 is
+    the caller that sits on top: one score file per invocation).  With 5 scores three ranks have nothing to score and send
+    padding only; with 11 the gather carries two rows per rank."""
+    world, n, m = 8, 131, 24
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, m, n_scores, ret), nprocs=world, join=True)
+    ref = _score_all(n, m, n_scores)
+    for r in range(world):
+        assert np.array_equal(ret[r], ref, equal_nan=True), r
+
+
+def test_row_sharded_multi_score_world8_empty_blocks():
+    """configs[3]'s 708-row union over 8 ranks in 128-aligned blocks (the multi-score layout's superblocks): six ranks hold
+    rows, two hold EMPTY blocks -- their sums are zero, their nloci 0, and the all-reduce + normalisation still equal the
+    single-rank result on every rank."""
+    world, n, m, S = 8, 67, 708, 2
+    blocks = [multi.shard_rows(m, world, r, align=128) for r in range(world)]
+    assert [b for b in blocks if b[1] > b[0]] == [(0, 128), (128, 256), (256, 384), (384, 512), (512, 640), (640, 708)]
+    assert blocks[6] == (708, 708) and blocks[7] == (708, 708)
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_row_matrix_worker, args=(world, port, n, m, S, ret), nprocs=world, join=True)
+    eaf, codes = _cohort(n, m, 13)
+    for r in (6, 7):
+        r0, r1, absmax, nloci = ret[r][2]
+        assert (r0, r1) == (708, 708) and absmax == 0.0 and not nloci.any()
+    assert sum(int(ret[r][2][3][0]) for r in range(world)) == int(ret[0][1][0])
+    for s_ in range(S):
+        beta = np.round(np.random.default_rng(300 + s_).normal(0, 0.05, m), 4)
+        ref, _, ref_nloci = refcpu.score_packed(codes, n, np.zeros(m, np.int32), np.zeros(m, np.int32), beta, eaf,
+                                                refcpu.make_params("ps", "homref", "int_ps", 0.05, 10), 0.1 * s_)
+        for r in range(world):
+            got, total, _ = ret[r]
+            assert total[s_] == ref_nloci
+            assert np.allclose(got[s_], ref, rtol=0, atol=1e-13 * max(1.0, np.abs(beta).sum()))
+            assert np.array_equal(got[s_], ret[0][0][s_])      # every rank ends with the same bits
 
 
 def test_shard_rows_partition():

@@ -14,7 +14,7 @@ out = ["# round %s: registers, LDS and scratch of the hot kernels as `hipcc -O3 
        "# 'allocated' is the count rounded up to a multiple of 8.  rocprofv3's VGPR_Count column shows HALF of that (it decodes the kernel",
        "# descriptor's granule count with a granule of 4): 124 there = 31 granules x 8 = 248 registers for a kernel that uses 241 .. 248.",
        "%-18s %-62s %5s %9s %5s %7s %8s %8s %6s" % ("source", "kernel", "VGPRs", "allocated", "AGPRs", "spilled", "scratch", "LDS", "waves")]
-for src in ("nps_mx.hip", "nps_mx2.hip", "nps_mxg.hip", "nps_ds_fused.hip", "nps_ds.hip", "nps_multi.hip", "nps_fused.hip"):
+for src in ("nps_mx.hip", "nps_mxg.hip", "nps_ds_fused.hip", "nps_ds.hip", "nps_multi.hip", "nps_fused.hip"):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-parameter",
                         "--cuda-device-only", "-c", os.path.join(ROOT, "nimpress_amd", "csrc", src), "-o", "/dev/null",
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)

@@ -11,7 +11,7 @@ ap.add_argument("--variants", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--cases", default="bench")
 ap.add_argument("--fmt", type=int, default=3)
-ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 two reads (tally + accumulation), 2 single read, 3 single read, second form (nps_mx2.hip)")
+ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 two reads (tally + accumulation), 2 single read")
 ap.add_argument("--imp-sample", default=None, help="ps | homref | fail | int_ps | int_fail (default: the CLI default, int_ps)")
 a = ap.parse_args()
 import torch

@@ -124,7 +124,8 @@ def main(argv=None):
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(local_rank)
     score_files, cohort = args.files[:-1], args.files[-1]
-    if args.shard == "auto":   # (every rank sees the same files: the same choice)
+    shard_auto = args.shard == "auto"
+    if shard_auto:   # (every rank sees the same files: the same choice)
         args.shard = "rows" if world > 1 and not args.one_pass and has_locus_index(cohort) else "files"
     names = host.sample_names(cohort)
     n = len(names)
@@ -153,9 +154,30 @@ def main(argv=None):
     if args.shard == "rows":
         # rows sharded over the GPUs x all files on every GPU: one partial pass, one all-reduce, the normalisation
         d_sums = torch.zeros((S, n), dtype=torch.float64, device=device) if on_gpu else None
-        sums, nl, offs, lg = host.compute_polygenic_scores_multi_partial(
-            score_files, cohort, rank, world, d_out=d_sums.data_ptr() if on_gpu else None, **kw)
-        took()
+        # The one-pass multi-score path does not take everything the file-by-file path takes (FORMAT/DS records; a
+        # definition whose |beta| span exceeds 2^25): under `--shard auto` such an input falls back to `--shard files`, as
+        # the one-pass branch below does -- on EVERY rank or on none (the ranks agree through an all-reduce of a flag);
+        # an explicit `--shard rows` stays a hard error.
+        failed, why = 0, ""
+        try:
+            sums, nl, offs, lg = host.compute_polygenic_scores_multi_partial(
+                score_files, cohort, rank, world, d_out=d_sums.data_ptr() if on_gpu else None, **kw)
+            took()
+        except (capi.NpsError, RuntimeError) as e:
+            if not shard_auto:
+                raise
+            failed, why = 1, str(e)
+        if shard_auto and world > 1:
+            flag = torch.tensor([failed], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = int(flag.item())
+        if failed:
+            if rank == 0:
+                sys.stderr.write("score_many: rows x all-files path not applicable (%s); sharding the score files instead\n"
+                                 % (why or "refused on another rank"))
+            args.shard = "files"
+            d_sums = None
+    if args.shard == "rows":
         for i, lines in enumerate(lg):
             logs[i] = lines
         one_pass_used = True
@@ -167,7 +189,7 @@ def main(argv=None):
         else:
             with np.errstate(divide="ignore", invalid="ignore"):
                 mat = sums / (nl.astype(np.float64) * 2.0)[:, None] + offs[:, None]
-    else:
+    if args.shard != "rows":
         mine = list(range(rank, S, world))
         # this rank's rows of the matrix, in shard order: on the GPU when the gather runs there
         local = None if (world == 1 and not on_gpu) else torch.empty((len(mine), n), dtype=torch.float64, device=device)
