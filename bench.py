@@ -406,15 +406,19 @@ def size_sweep(capi, device, args, seed, steps=3, full=True):
                 p = sc.profile_get(reset=True)
                 ms = p.ms_fused + p.ms_tally + p.ms_params + p.ms_accumulate
                 if i == 0:   # (wall time: the one-time count of the cohort's tallies is not one of the context's launches)
-                    first, first_reads = wall, (2 if (p.n_tally or (co.has_tallies() and co.fmt == capi.FMT_GT2X)) else 1)
+                    # (two reads: a tally launch of the context's own, or -- no in-pass launch at all and the cohort now
+                    #  carries tallies -- the cohort's one-time count ran before a given-tallies pass; ONE read where the
+                    #  in-pass kernel ran and kept what it counted, round 6)
+                    first, first_reads = wall, (2 if (p.n_tally or (co.has_tallies() and co.fmt == capi.FMT_GT2X and p.n_fused == 0)) else 1)
                 else:
                     best = ms if best is None else min(best, ms)
                     reads = 2 if p.n_tally else 1
             r = {"ms_per_pass": best, "frac_of_8TBps": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "reads_of_the_matrix": reads,
                  "first_run_ms": first, "first_run_reads_of_the_matrix": first_reads,
                  "first_run_frac_of_8TBps": alg / (first * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "tallies": ("counted once, kept with the cohort" if (co.fmt == capi.FMT_GT2X and co.has_tallies())
-                             else "counted in the pass"),
+                 "tallies": (("kept with the cohort by the first pass, which counts them in its one read" if first_reads == 1
+                              else "counted once in a pass of their own, kept with the cohort")
+                             if (co.fmt == capi.FMT_GT2X and co.has_tallies()) else "counted in the pass"),
                  "grid": {"slices": geo[0], "teams": geo[1], "samples_per_slice": geo[2]}}
             if not args.no_cpu_baseline:
                 from oracle import refcpu
@@ -452,6 +456,16 @@ def given_tallies(capi, sc, cohort, sdef, d_scores, n, m, headline_ms, steps=5):
     sc.finish_device(0.0, d_scores.data_ptr())
     want = d_scores.clone()
     st_want = sc.flush()
+    # round 6: with nps_cohort_expect_passes(>= 2) the FIRST pass keeps the tallies it counts anyway (no extra read)
+    cohort.expect_passes(2)
+    sc.reset()
+    sc.profile_enable(True)
+    sc.profile_get(reset=True)
+    sc.score_cohort_def(cohort, sdef, 0, capi.MODE_AUTO)
+    sc.finish_device(0.0, d_scores.data_ptr())
+    p = sc.profile_get(reset=True)
+    harvest_ms = p.ms_fused + p.ms_tally + p.ms_params + p.ms_accumulate
+    harvested = bool(cohort.has_tallies() and p.n_fused >= 1 and p.n_tally == 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     cohort.keep_tallies()
@@ -486,6 +500,8 @@ def given_tallies(capi, sc, cohort, sdef, d_scores, n, m, headline_ms, steps=5):
                     "the matrix), scored with the tallies given; NOT the headline, which counts them in the pass",
             "ms_per_pass": best, "frac_of_8TBps": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "one_time_tally_ms": keep_s * 1e3, "headline_ms_per_step": headline_ms, "nloci": int(nl),
+            "first_pass_keeps_its_tallies": {"with": "nps_cohort_expect_passes(2)", "kept_by_the_in_pass_kernel": harvested,
+                                             "that_pass_ms": harvest_ms, "extra_reads_of_the_matrix": 0 if harvested else 1},
             "outputs_equal_headline_within_1e-9_relative": same, "outputs_max_relative_difference": worst,
             "outputs_equal_row_statistics": stats_same,
             "passes_after_which_it_pays": (keep_s * 1e3) / max(headline_ms - best, 1e-9) if best < headline_ms else None}

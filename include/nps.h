@@ -255,12 +255,18 @@ void nps_destroy(nps_ctx *ctx);
 #define NPS_FMT_GT2X 3
 /* nps_cohort_create only: "the 2-bit resident layout this library scores best at this size" -- since round 5 that is
  * NPS_FMT_GT2X at every size (nps_cohort_format tells; use row offsets that are multiples of 128).  Under NPS_MODE_AUTO
- * a run whose resident grid (P = ceil(N / 2048) strips x floor(CUs / P) row teams) covers at least seven tenths of the
- * compute units counts its tallies in the pass (tallyAlleles, nimpress.nim:563, inside the one read).  Other sizes
- * (128 < P < 180: 262 145 .. 366 592 samples on an MI355X; P > CUs: beyond 522 240) count the cohort's tallies ONCE, on the
- * first such run, keep them with the cohort (nps_cohort_keep_tallies) and score with the tallies given: the first run reads
- * the matrix twice, every later run once, at a speed that does not depend on the genotypes.  (Until round 4 these sizes
- * got NPS_FMT_GT2, whose table-lookup kernel runs at 0.47 .. 0.63 of the roofline depending on the genotypes.) */
+ * a run whose resident grid (P = ceil(N / 2048) strips x floor(CUs / P) row teams) covers at least nine tenths of the
+ * compute units counts its tallies in the pass (tallyAlleles, nimpress.nim:563, inside the one read), every time.  Other
+ * sizes keep the cohort's tallies with the cohort -- NPS_MODE_AUTO ATTACHES this cache to the `const nps_cohort` it is given
+ * (dropped by any call that rewrites rows; nps_cohort_has_tallies tells) -- and score later runs with the tallies given:
+ *   P x floor(CUs / P) < 0.9 CUs (e.g. 128 < P < 231: 262 145 .. 471 040 samples on an MI355X): the first whole-cohort run
+ *     is the single read in which the tallies are counted anyway and keeps them as a by-product (round 6: ONE read, 0.51 of
+ *     the roofline at 300 000 samples, 0.65 at 400 000; until then a tally pass + a given-tallies pass, two reads, 0.38);
+ *     later runs 0.73-0.75;
+ *   P > compute units (beyond 522 240 samples): no resident grid exists: the first run counts the tallies in a pass of
+ *     its own (two reads, 0.38-0.39), later runs read once.
+ * nps_cohort_expect_passes asks for the same caching at the sizes whose grid does cover the chip.  (Until round 4 the
+ * awkward sizes got NPS_FMT_GT2, whose table-lookup kernel runs at 0.47 .. 0.63 of the roofline depending on the genotypes.) */
 #define NPS_FMT_GT_AUTO 4
 /* Dosages in 2 bytes per genotype (round 5): k = dosage x 10^4 as uint16, 0 <= k <= 20 000, 0xFFFF = missing.  FORMAT/DS
  * values are decimal text with one to four places (Beagle, minimac, IMPUTE): for every such value in [0, 2] the float32 a
@@ -392,6 +398,10 @@ int nps_multi_finish_device(nps_multi *m, const double *offsets, double *d_score
  * context's rows, for the one exchange of that layout -- a sum all-reduce of both (RCCL).  The caller then applies
  * nimpress.nim:643-649: sums / (2 nloci) + offset (nimpress_amd/multi.py: normalize_matrix). */
 int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64_t *nloci_out);
+/* what nps_multi_create was given (a host that hands scorers to nps_comm_allreduce_partial_multi is checked against these) */
+int nps_multi_n_scores(const nps_multi *m);
+uint64_t nps_multi_n_samples(const nps_multi *m);
+int nps_multi_device(const nps_multi *m);
 /* the same into host memory: sums_out[n_scores][n_samples] (a host caller that exchanges through its own transport) */
 int nps_multi_partial(nps_multi *m, double *sums_out, uint64_t *nloci_out);
 int nps_multi_reset(nps_multi *m, const nps_params *params /* NULL = keep */);
@@ -410,6 +420,13 @@ int nps_cohort_row_tallies(const nps_cohort *c, uint64_t row0, uint64_t nrows, u
  * (BASELINE configs[3]): the decision chain of getImputedDosages (:565-583) sees exactly the same counts.  Any call that
  * rewrites rows (upload, synth, convert) drops the kept tallies; NPS_MODE_FUSED / NPS_MODE_TWOPASS never use them. */
 int nps_cohort_keep_tallies(nps_cohort *c);
+/* A hint (round 6): the caller will score this NPS_FMT_GT2X cohort `n_passes` times (several score files over one cohort,
+ * BASELINE configs[3]; the reference runs computePolygenicScores once per file, nimpress.nim:747-753).  With n_passes >= 2
+ * the first whole-cohort run under NPS_MODE_AUTO -- which counts the tallies in its one read anyway -- keeps them with the
+ * cohort as a by-product (no extra read), and every later run scores with the tallies given (0.75-0.78 of the roofline
+ * instead of 0.62-0.73).  Without the hint NPS_MODE_AUTO does this only where the single-read kernel's grid covers less
+ * than nine tenths of the compute units (see NPS_FMT_GT_AUTO).  0 or 1: no such caching (the default). */
+int nps_cohort_expect_passes(nps_cohort *c, uint32_t n_passes);
 int nps_cohort_has_tallies(const nps_cohort *c); /* 1: the cohort carries whole-row tallies */
 
 /* ---- measurement ------------------------------------------------------------------------ */

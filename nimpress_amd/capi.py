@@ -63,6 +63,7 @@ SYMBOLS = [
     "nps_multi_finish", "nps_multi_finish_device", "nps_multi_reset", "nps_multi_destroy", "nps_multi_timing",
     "nps_cohort_convert", "nps_cohort_row_tallies", "nps_cohort_keep_tallies", "nps_cohort_has_tallies", "nps_multi_set_missing_weight_bits",
     "nps_cohort_push_gt_raw", "nps_cohort_push_bed", "nps_multi_partial_device", "nps_multi_partial",
+    "nps_multi_n_scores", "nps_multi_n_samples", "nps_multi_device", "nps_cohort_expect_passes",
 ]
 
 
@@ -188,6 +189,10 @@ def load(with_torch: bool = True):
     L.nps_multi_finish.argtypes = [vp, vp, vp, vp]
     L.nps_multi_finish_device.argtypes = [vp, vp, vp, vp]
     L.nps_multi_partial_device.argtypes = [vp, vp, vp]
+    L.nps_multi_n_scores.argtypes = [vp]
+    L.nps_multi_n_samples.argtypes = [vp]
+    L.nps_multi_n_samples.restype = u64
+    L.nps_multi_device.argtypes = [vp]
     L.nps_multi_reset.argtypes = [vp, C.POINTER(NpsParams)]
     L.nps_multi_destroy.argtypes = [vp]
     L.nps_multi_destroy.restype = None
@@ -197,6 +202,7 @@ def load(with_torch: bool = True):
     L.nps_cohort_convert.argtypes = [vp, vp]
     L.nps_cohort_row_tallies.argtypes = [vp, u64, u64, vp, vp]
     L.nps_cohort_keep_tallies.argtypes = [vp]
+    L.nps_cohort_expect_passes.argtypes = [vp, C.c_uint32]
     L.nps_cohort_has_tallies.argtypes = [vp]
     _lib = L
     return L
@@ -286,6 +292,11 @@ class Cohort:
         """count every row's tallyAlleles once and keep them with this FMT_GT2X cohort: MODE_AUTO then scores it with the
         tallies given (nps_cohort_keep_tallies)"""
         _check(load().nps_cohort_keep_tallies(self._h))
+
+    def expect_passes(self, n: int):
+        """hint: this cohort will be scored n times (nps_cohort_expect_passes): with n >= 2 the first whole-cohort MODE_AUTO
+        run keeps the tallies it counts anyway, later runs score with them given"""
+        _check(load().nps_cohort_expect_passes(self._h, int(n)))
 
     def has_tallies(self) -> bool:
         return bool(load().nps_cohort_has_tallies(self._h))

@@ -224,6 +224,17 @@ extern "C" int nps_comm_allreduce_partial_multi(nps_comm *c, nps_multi *const *m
         return fail(NPS_E_INVAL, "n_scores %d outside 1..%d", n_scores, NPS_MULTI_MAX_SCORES);
     for (int r = 0; r < c->n; ++r)
         if (!ms[r] || (!d_matrix[r] && n_samples)) return fail(NPS_E_INVAL, "rank %d: scorer / d_matrix is NULL", r);
+    // nps_multi_partial_device writes the scorer's OWN S x n doubles: what the caller says must be what the scorers are, and
+    // every scorer must live on its rank's device (as check_ctxs asks of single-score contexts)
+    for (int r = 0; r < c->n; ++r) {
+        if (nps_multi_device(ms[r]) != c->dev[r])
+            return fail(NPS_E_INVAL, "rank %d: the scorer is on device %d, the communicator's rank on device %d", r,
+                        nps_multi_device(ms[r]), c->dev[r]);
+        if (nps_multi_n_scores(ms[r]) != n_scores || nps_multi_n_samples(ms[r]) != n_samples)
+            return fail(NPS_E_INVAL, "rank %d: the scorer holds %d scores x %llu samples, the call says %d x %llu", r,
+                        nps_multi_n_scores(ms[r]), (unsigned long long)nps_multi_n_samples(ms[r]), n_scores,
+                        (unsigned long long)n_samples);
+    }
     uint64_t total[NPS_MULTI_MAX_SCORES] = {};
     for (int r = 0; r < c->n; ++r) {
         uint64_t nl[NPS_MULTI_MAX_SCORES] = {};
@@ -249,7 +260,10 @@ extern "C" int nps_comm_allreduce_partial_multi(nps_comm *c, nps_multi *const *m
     }
     for (int r = 0; r < c->n; ++r) {
         HIP_TRY(hipSetDevice(c->dev[r]));
-        HIP_TRY(hipMemcpyAsync(c->d_scal[r], scal, sizeof(scal), hipMemcpyHostToDevice, c->stream[r]));
+        // (a blocking copy of 128 bytes: `scal` lives on this frame, and an early error return below must not leave a copy
+        //  from it in flight; the stream's all-reduce is waited for first, the kernel follows on the same stream)
+        HIP_TRY(hipStreamSynchronize(c->stream[r]));
+        HIP_TRY(hipMemcpy(c->d_scal[r], scal, sizeof(scal), hipMemcpyHostToDevice));
         if (count)
             hipLaunchKernelGGL(normalize_matrix_kernel, dim3((uint32_t)((n_samples + 255) / 256), (uint32_t)n_scores), dim3(256),
                                0, c->stream[r], d_matrix[r], n_samples, c->d_scal[r], c->d_scal[r] + NPS_MULTI_MAX_SCORES);
@@ -257,7 +271,7 @@ extern "C" int nps_comm_allreduce_partial_multi(nps_comm *c, nps_multi *const *m
     }
     for (int r = 0; r < c->n; ++r) {
         HIP_TRY(hipSetDevice(c->dev[r]));
-        HIP_TRY(hipStreamSynchronize(c->stream[r]));  // (scal lives on this frame)
+        HIP_TRY(hipStreamSynchronize(c->stream[r]));
     }
     if (nloci_out)
         for (int s = 0; s < n_scores; ++s) nloci_out[s] = total[s];

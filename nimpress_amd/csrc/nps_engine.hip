@@ -70,6 +70,7 @@ struct nps_cohort {
     //  publishes with release order AFTER the counted tallies are in device memory, readers load with acquire)
     std::atomic<bool> mx_row_tally_valid{false};
     std::mutex tally_mutex;  // NPS_MODE_AUTO may count them lazily from whichever context scores the cohort first
+    std::atomic<uint32_t> expect_passes{0};  // nps_cohort_expect_passes: how often the caller will score this cohort (0: not said)
     // nps_cohort_push_*: rows decoded on the device straight into the cohort (a pinned ring the decode kernel reads
     // over PCIe, on a stream of the cohort's own); every call that reads the cohort waits for it (cohort_quiesce)
     hipStream_t push_stream = nullptr;
@@ -1669,30 +1670,44 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
         return fail(NPS_E_INVAL, "cohort_row0 must be a multiple of 4 (rows are stored in groups of 4)");
     HIP_TRY(hipSetDevice(c->device));
     MxPlan mxp;
-    bool kept_tallies = false;
+    bool kept_tallies = false, harvest = false;
     if (is_mx && m && c->n) {
         // a cohort that carries its tallies (nps_cohort_keep_tallies) is scored with them given under NPS_MODE_AUTO: the
         // "two-pass" plan (independent workgroups) without its tally pass
-        kept_tallies = co->mx_row_tally_valid && mode == NPS_MODE_AUTO;
+        kept_tallies = co->mx_row_tally_valid.load(std::memory_order_acquire) && mode == NPS_MODE_AUTO;
         if (!kept_tallies && mode == NPS_MODE_AUTO) {
-            // does the single-read kernel's resident grid cover the chip at this size?  If not -- or if there are more
-            // strips than compute units -- count the cohort's tallies once and keep them (the cohort's own cache: rewriting
-            // rows drops it); this and every later pass then reads the matrix once with the tallies given
+            // Does the single-read kernel's resident grid cover the chip at this size, and will the cohort be scored again?
+            //   * a resident grid exists (P <= compute units) and the run covers the whole cohort: the pass counts the tallies
+            //     anyway -- where later passes want them given (the grid covers less than nine tenths of the chip, or the
+            //     caller said nps_cohort_expect_passes >= 2) its epilogue KEEPS them with the cohort (`harvest`): the first
+            //     run is one read, every later one runs with the tallies given (round 6; until then the first run of such
+            //     a size was a tally pass + a given-tallies pass: two reads);
+            //   * no resident grid (more strips than compute units), or a partial run of at least a quarter of the cohort:
+            //     count the cohort's tallies once (one more read) and keep them (the cohort's own cache: rewriting rows
+            //     drops it); shorter runs tally just their own rows (two reads of those rows).
             MxPlan p1;
             HIP_TRY(mx_plan(c->device, c->n, m, false, &p1));
             int cus = 0;
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            const bool covers = p1.ok && !p1.given && (uint64_t)p1.P * p1.Q * 10 >= (uint64_t)cus * 7;
-            // (short runs stay with the in-pass kernel: a tally pass over the whole cohort would cost more than it saves)
-            if (p1.ok && !covers && (p1.given || m >= 16384)) {
-                nps_cohort *mco = const_cast<nps_cohort *>(co);
-                std::lock_guard<std::mutex> lk(mco->tally_mutex);
-                if (!mco->mx_row_tally_valid) {
-                    rc = nps_cohort_keep_tallies(mco);
-                    if (rc) return rc;
-                    HIP_TRY(hipSetDevice(c->device));
+            // (nine tenths, by measurement: at 400 000 samples -- 196 strips, 77 % of the chip -- the in-pass kernel runs at
+            //  0.64-0.67 of the roofline and the same cohort with its tallies given at 0.73-0.75; until round 6, when keeping
+            //  the tallies still cost a pass of its own, the line was drawn at seven tenths)
+            const bool covers = p1.ok && !p1.given && (uint64_t)p1.P * p1.Q * 10 >= (uint64_t)cus * 9;
+            const bool want_kept = !covers || co->expect_passes.load(std::memory_order_relaxed) >= 2;
+            const bool whole = cohort_row0 == 0 && m == co->n_rows;
+            if (p1.ok && want_kept) {
+                if (!p1.given && whole && m >= 1024) {
+                    harvest = true;
+                } else if ((p1.given || (!covers && m >= 16384)) && m * 4 >= co->n_rows) {
+                    nps_cohort *mco = const_cast<nps_cohort *>(co);
+                    std::lock_guard<std::mutex> lk(mco->tally_mutex);
+                    if (!mco->mx_row_tally_valid.load(std::memory_order_acquire)) {
+                        rc = nps_cohort_keep_tallies(mco);
+                        if (rc) return rc;
+                        HIP_TRY(hipSetDevice(c->device));
+                    }
+                    kept_tallies = true;
                 }
-                kept_tallies = true;
             }
         }
         const bool two_pass = mode == NPS_MODE_TWOPASS || kept_tallies;
@@ -1781,6 +1796,17 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             rc = grow(c, (void **)&c->d_mx_const, &c->mx_const_cap, 8 + 2ull * mxp.Q, sizeof(double));
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(c->d_mx_const, 0, sizeof(double) * c->mx_const_cap, c->stream));
+        }
+        if (harvest) {  // (the cohort's kept tallies: allocated once, by whoever harvests first)
+            nps_cohort *mco = const_cast<nps_cohort *>(co);
+            std::lock_guard<std::mutex> lk(mco->tally_mutex);
+            if (!mco->d_mx_row_tally) {
+                if (hipMalloc(&mco->d_mx_row_tally, sizeof(unsigned long long) * gt2x_superblocks(co->n_rows) * 128) != hipSuccess) {
+                    (void)hipGetLastError();
+                    mco->d_mx_row_tally = nullptr;
+                    harvest = false;  // (no room: the pass runs as it always did)
+                }
+            }
         }
         if (mxp.given) {
             rc = grow(c, (void **)&c->d_mx_ops, &c->mx_ops_cap, m_pad, 48);
@@ -1894,11 +1920,19 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
                 HIP_TRY(launch_mx_fold(c->stream, mxp, c->d_mx_cpart, c->n, F, const_slots, c->d_part,
                                        c->chunks_used == 0 ? 1 : 0, c->d_rtally, m_pad, c->d_mx_tally1,
                                        (uint64_t)((mxp.P + 15) / 16) * m_pad, c->d_timeout, c->d_nloci + 1,
-                                       !mxp.given && mxp.U < 64 /* launch_fused_mx cut its own strips */));
+                                       !mxp.given && mxp.U < 64 /* launch_fused_mx cut its own strips */,
+                                       harvest && b == 0 && !mxp.given ? co->d_mx_row_tally : nullptr,
+                                       harvest && b == 0 && !mxp.given ? m_pad : 0));
                 HIP_TRY(hipMemsetAsync(const_slots, 0, sizeof(double) * 2 * mxp.Q, c->stream));
             }
             c->chunks_used = std::max(c->chunks_used, 1u);
             c->rtally_clean = true;
+        }
+        if (harvest && !mxp.given) {
+            // the kept tallies are published only once they ARE in device memory (another context may score this cohort
+            // from another thread and stream): one wait, on the cohort's first pass only
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const_cast<nps_cohort *>(co)->mx_row_tally_valid.store(true, std::memory_order_release);
         }
         return done();
     }
@@ -2121,6 +2155,11 @@ extern "C" int nps_cohort_keep_tallies(nps_cohort *c) {
     HIP_TRY(launch_mx_tally(nullptr, mp, c->d_data, n_sb, 0, c->n_samples, c->d_mx_row_tally));
     HIP_TRY(hipDeviceSynchronize());
     c->mx_row_tally_valid = true;
+    return NPS_OK;
+}
+extern "C" int nps_cohort_expect_passes(nps_cohort *c, uint32_t n_passes) {
+    if (!c) return fail(NPS_E_INVAL, "cohort is NULL");
+    c->expect_passes.store(n_passes, std::memory_order_relaxed);
     return NPS_OK;
 }
 extern "C" int nps_cohort_has_tallies(const nps_cohort *c) {
@@ -2435,6 +2474,10 @@ extern "C" int nps_multi_finish_device(nps_multi *m, const double *offsets, doub
     if (m->n && !d_scores_out) return fail(NPS_E_INVAL, "d_scores_out is NULL");
     return multi_finish_common(m, offsets, d_scores_out, nullptr, nloci_out);
 }
+
+extern "C" int nps_multi_n_scores(const nps_multi *m) { return m ? m->S : 0; }
+extern "C" uint64_t nps_multi_n_samples(const nps_multi *m) { return m ? m->n : 0; }
+extern "C" int nps_multi_device(const nps_multi *m) { return m ? m->device : -1; }
 
 extern "C" int nps_multi_partial_device(nps_multi *m, double *d_sums_out, uint64_t *nloci_out) {
     if (!m) return fail(NPS_E_INVAL, "ctx is NULL");

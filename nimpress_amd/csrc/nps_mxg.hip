@@ -33,8 +33,12 @@ __device__ unsigned long long g_mxg_timers[8][8];
 #endif
 constexpr int kGW = 8;                                   // waves of a workgroup, all alike
 constexpr int kGU = 8;                                   // units per wave: 64 in all
-constexpr uint32_t kGTrans = 0;                          // [kGW][2 units][1 KiB]: the code image on its way to the transposed read
-constexpr uint32_t kGTab = kGW * 2048u;                  // [2][3 operands][128 rows][16 bytes]
+#ifndef NPS_MXG_TRANS
+#define NPS_MXG_TRANS 2   // units of a wave that are on their way through LDS at a time (8: all of them, see work())
+#endif
+constexpr uint32_t kGTransUnits = NPS_MXG_TRANS;
+constexpr uint32_t kGTrans = 0;                          // [kGW][kGTransUnits][1 KiB]: the code image on its way to the transposed read
+constexpr uint32_t kGTab = kGW * kGTransUnits * 1024u;   // [2][3 operands][128 rows][16 bytes]
 constexpr uint32_t kGLdsBytes = kGTab + 2 * 6144u;
 static_assert(kGW * kGU == 64, "units of a strip");
 
@@ -151,7 +155,7 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
     const int n_my = GUARD ? max(0, min(NU, nu - u0)) : NU;  // wave-uniform
     constexpr bool full = !GUARD;
 
-    char *const trans = smem + kGTrans + (size_t)wave * 2048;
+    char *const trans = smem + kGTrans + (size_t)wave * (kGTransUnits * 1024u);
     const int woff = mx_rowoff(2 * lane);
     const int r1off = mx_rowoff(32 * g + q), r2off = mx_rowoff(32 * g + 16 + q);
     const int fr0 = (32 * g + q) * 16, fr1 = (32 * g + 16 + q) * 16;
@@ -228,9 +232,11 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
             Bmo = v8i{o0[0], o0[1], o0[2], o1[0], o1[1], o1[2], 0, 0};
         }
         auto one = [&](int u, bool refill) {
-            char *const tp = trans + (u & 1) * 1024;
-            *reinterpret_cast<v4u *>(tp + woff) = b[u];
-            if (refill) b[u] = load_unit(k + kBanks, u);
+            char *const tp = trans + (u % (int)kGTransUnits) * 1024;
+            if (kGTransUnits < (uint32_t)NU) {
+                *reinterpret_cast<v4u *>(tp + woff) = b[u];
+                if (refill) b[u] = load_unit(k + kBanks, u);
+            }
             const v2i t01 = tr4(tp + r1off), t23 = tr4(tp + r2off);
             const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
             v8i ce = {0, 0, 0, 0, 0, 0, 0, 0}, co = ce, me = ce, mo = ce;
@@ -250,6 +256,17 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
             __builtin_amdgcn_sched_barrier(0);  // (three banks: the operands of one unit alive at a time)
 #endif
         };
+        if (kGTransUnits >= (uint32_t)NU) {
+            // all of the wave's units go through LDS at once: the writes (and the refills behind them) first, then the
+            // transposed reads -- no write -> read round trip inside a unit's chain
+            const bool refill = k + kBanks < n_t;
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (full || u < n_my) {
+                    *reinterpret_cast<v4u *>(trans + u * 1024 + woff) = b[u];
+                    if (refill) b[u] = load_unit(k + kBanks, u);
+                }
+        }
         if (k + kBanks < n_t) {
 #pragma unroll
             for (int u = 0; u < NU; ++u)

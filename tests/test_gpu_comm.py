@@ -63,6 +63,13 @@ def test_comm_one_device_equals_finish():
     assert np.array_equal(np.isnan(got), np.isnan(want_m))
     ok = ~np.isnan(want_m)
     assert np.max(np.abs(got[ok] - want_m[ok]) / np.maximum(np.abs(want_m[ok]), 1e-12)) <= 1e-12
+    # refusals: what the call says must be what the scorers hold (a mismatch would be a device buffer overrun)
+    msc.reset()
+    msc.score_cohort(gm, mdef)
+    with pytest.raises(capi.NpsError):
+        comm.allreduce_partial_multi([msc], S - 1, n, offs[:S - 1], [dm.data_ptr()])
+    with pytest.raises(capi.NpsError):
+        comm.allreduce_partial_multi([msc], S, n - 1, offs, [dm.data_ptr()])
     # refusals: a context on another device / differing sample counts / too many devices
     with pytest.raises(capi.NpsError):
         capi.Comm(capi.device_count() + 1)

@@ -557,9 +557,10 @@ def test_gt2x_kept_tallies_vs_oracle(shape):
 @pytest.mark.parametrize("n", [300_000, 530_000])
 def test_auto_counts_tallies_once_where_the_resident_grid_does_not_cover_the_chip(n):
     """NPS_FMT_GT_AUTO is the strip layout at every size now.  300 000 samples (147 strips x 1 team: 147 of 256 compute
-    units) and 530 000 (259 strips: more than compute units): the first NPS_MODE_AUTO run counts the cohort's tallies and
-    keeps them, later runs read the matrix once with the tallies given; equal to the oracle either way; rewriting rows drops
-    the tallies and the next run counts again.  (300 000 x 16 384 -- the lazy rule wants that many rows -- is checked as
+    units) and 530 000 (259 strips: more than compute units): the first NPS_MODE_AUTO run leaves the cohort's tallies with
+    the cohort -- at 300 000 as a by-product of the single read that counts them anyway (round 6: one launch of the in-pass
+    kernel, no tally pass), at 530 000 from a tally pass of their own -- later runs read the matrix once with the tallies
+    given; equal to the oracle either way; rewriting rows drops the tallies and the next run counts again.  (300 000 x 16 384 -- the lazy rule wants that many rows -- is checked as
     bench.py checks the full size: a few hundred samples from all over the cohort scored over ALL rows by the oracle's
     subset path, fed with the device's row statistics, of which 200 rows are recounted over all samples; the whole-cohort
     oracle took 45 s of the suite for this one case.)"""
@@ -593,7 +594,16 @@ def test_auto_counts_tallies_once_where_the_resident_grid_does_not_cover_the_chi
         stats = sc.flush()
         scores, nloci = sc.finish(0.0)
         sc.close()
-        assert dev.has_tallies() and p.n_fused == 0 and p.n_tally == 0 and p.n_accumulate >= 1
+        if big and k == 0:
+            assert dev.has_tallies() and p.n_fused >= 1 and p.n_tally == 0 and p.n_accumulate == 0    # in the pass, kept
+        else:
+            assert dev.has_tallies() and p.n_fused == 0 and p.n_tally == 0 and p.n_accumulate >= 1     # given
+        if k == 0:
+            first = scores.copy()
+        else:   # exact integer digit sums in both kernels: the same scores
+            ok = ~np.isnan(first)
+            assert np.array_equal(np.isnan(scores), np.isnan(first))
+            assert np.allclose(scores[ok], first[ok], rtol=1e-12, atol=1e-18)
         if big:
             pick = np.random.default_rng(5 + k)
             rows = np.unique(np.concatenate([pick.choice(m, 200, replace=False), [0, 3, 7, m - 1]])).astype(np.uint64)
@@ -614,6 +624,108 @@ def test_auto_counts_tallies_once_where_the_resident_grid_does_not_cover_the_chi
             check_scores(scores, ref_scores, co["beta"], nloci)
     dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
     assert not dev.has_tallies()
+    dev.close()
+
+
+def test_expect_passes_keeps_the_tallies_of_the_first_pass():
+    """nps_cohort_expect_passes (round 6): at a size whose resident grid covers the chip NPS_MODE_AUTO counts the tallies in
+    every pass -- unless the caller says the cohort will be scored again: then the first whole-cohort pass keeps what it
+    counted (no extra read) and later passes run with the tallies given.  The kept tallies are the oracle's; a run over
+    PART of the cohort keeps nothing."""
+    n, m = 70_000, 2000
+    rng = np.random.default_rng(77)
+    co = make_cohort(n, m, 1234, rng)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
+    dev.synth(0, co["seed"], co["th"], co["tm"], co["tmi"])
+    descs = capi.row_descs(co["beta"], co["eaf"], None, co["rie"])
+    kw = PARAM_GRID[0]
+    ref_scores, ref_stats, ref_nloci = oracle_scores(co, kw, 0.0)
+
+    def run(row0=0, d=descs):
+        sc = capi.Scorer(n, capi.make_params(**kw))
+        sc.profile_enable(True)
+        sc.score_cohort(dev, d, row0, capi.MODE_AUTO)
+        p = sc.profile_get(reset=True)
+        stats = sc.flush()
+        scores, nloci = sc.finish(0.0)
+        sc.close()
+        return p, stats, scores, nloci
+
+    for _ in range(2):                                  # no hint: in the pass, every time
+        p, stats, scores, nloci = run()
+        assert p.n_fused >= 1 and p.n_accumulate == 0 and not dev.has_tallies()
+    dev.expect_passes(8)
+    p, _, _, _ = run(128, descs[128:])                  # a partial run keeps nothing
+    assert p.n_fused >= 1 and not dev.has_tallies()
+    p, stats, first, nloci = run()
+    assert p.n_fused >= 1 and p.n_tally == 0 and p.n_accumulate == 0 and dev.has_tallies()
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    check_scores(first, ref_scores, co["beta"], nloci)
+    nm, ne = dev.row_tallies(0, m)                      # what was kept is what tallyAlleles gives
+    assert np.array_equal(nm, stats["nmissing"].astype(nm.dtype))          # (the statistics were just checked against the oracle's)
+    assert np.array_equal(ne.astype(np.float64), stats["neffect"])
+    p, stats, again, nloci = run()
+    assert p.n_fused == 0 and p.n_accumulate >= 1      # given
+    assert nloci == ref_nloci
+    assert_stats_equal(stats, [tuple(s) for s in ref_stats])
+    ok = ~np.isnan(first)
+    assert np.array_equal(np.isnan(again), np.isnan(first)) and np.allclose(again[ok], first[ok], rtol=1e-12, atol=1e-18)
+    dev.synth(0, co["seed"] + 1, co["th"], co["tm"], co["tmi"])
+    assert not dev.has_tallies()
+    dev.close()
+
+
+def test_two_threads_score_one_auto_cohort():
+    """two contexts on two threads score ONE cohort under NPS_MODE_AUTO at a size where the first run
+    attaches kept tallies to the cohort (280 000 samples: 137 strips).  Whoever comes first counts and publishes them (an
+    atomic flag, release / acquire); both threads get the single-threaded result, bit for bit among the given-tallies runs."""
+    import threading
+    n, m = 280_000, 2048
+    rng = np.random.default_rng(99)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.1, m)
+    miss[::7] = 0.3
+    beta = np.round(rng.normal(0, 0.02, m), 4)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    descs = capi.row_descs(beta, eaf)
+    out, errs = {}, []
+
+    def work(tag, dev, passes):
+        try:
+            sc = capi.Scorer(n, capi.make_params())
+            res = []
+            for _ in range(passes):
+                sc.reset()
+                sc.score_cohort(dev, descs, 0, capi.MODE_AUTO)
+                res.append(sc.finish(0.0))
+            sc.close()
+            out[tag] = res
+        except Exception as e:     # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    ref_dev = capi.Cohort(n, m, fmt=capi.FMT_GT_AUTO)
+    ref_dev.synth(0, 31, th, tm, tmi)
+    work("ref", ref_dev, 2)
+    ref_dev.close()
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT_AUTO)
+    dev.synth(0, 31, th, tm, tmi)
+    assert not dev.has_tallies()
+    ts = [threading.Thread(target=work, args=(k, dev, 3)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert dev.has_tallies()
+    ref_first, ref_given = out["ref"]
+    ok = ~np.isnan(ref_first[0])
+    for k in range(2):
+        for scores, nloci in out[k]:
+            assert nloci == ref_first[1] == ref_given[1]
+            assert np.array_equal(np.isnan(scores), ~ok)
+            assert np.allclose(scores[ok], ref_first[0][ok], rtol=1e-12, atol=1e-18)
+        assert np.array_equal(out[k][-1][0].view(np.int64), ref_given[0].view(np.int64))   # (both with the tallies given)
     dev.close()
 
 
