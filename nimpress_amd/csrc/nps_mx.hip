@@ -142,9 +142,8 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 #pragma unroll
         for (int u = 0; u < NU; ++u) bank[s][u] = v4u{0u, 0u, 0u, 0u};
 
-    // (VS) a superblock's two segment bases are made ONCE per superblock and pinned as two scalar pairs: left to itself the
-    // compiler keeps one induction pointer per unit and layout strip and spills scalars into vector lanes for them (round 5:
-    // 135 of them, 3.5 v_readlane per unit and step on the waves that set the step)
+    // (VS) a superblock's two segment bases are made once per superblock.  (The 135 scalars this instantiation keeps in vector
+    // lanes are not read back in the steady loop of an unguarded body -- profiles/r06_mx_variants.txt, part 4.)
     struct SbPtr {
         const char *pa, *pb;
     };
@@ -154,9 +153,6 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
         if constexpr (VS) {
             r.pa = sbase_a + (uint64_t)k * sstride_a;
             r.pb = sbase_b2 + (uint64_t)k * sstride_b;
-#ifdef NPS_MX_SADDR
-            asm volatile("" : "+s"(r.pa), "+s"(r.pb));
-#endif
         }
         return r;
     };
@@ -239,50 +235,6 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
             Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
         }
-#ifdef NPS_MX_INTERLEAVE
-        // One unit = four operand registers x four operands, four matrix instructions.  Issued as "all 24 vector instructions,
-        // then the four MFMAs" (what the compiler makes of the plain loop below) a wave's matrix pipe idles while the operands
-        // are made and its vector issue idles while the dependent MFMA pairs drain.  Here every MFMA is issued as soon as ITS
-        // operand exists, with the next operand's vector work behind it, and the transposed reads of the NEXT unit are under
-        // way during the whole unit: ce -> MFMA -> co -> MFMA -> me -> MFMA -> mo -> MFMA.
-        v2i n01 = tr4(slot + r1off), n23 = tr4(slot + r2off);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (full || u < n_my) {
-                const v2i t01 = n01, t23 = n23;
-                if (u + 1 < NU && (full || u + 1 < n_my)) {
-                    n01 = tr4(slot + (u + 1) * 1024 + r1off);
-                    n23 = tr4(slot + (u + 1) * 1024 + r2off);
-                }
-                const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
-                v8i op = {0, 0, 0, 0, 0, 0, 0, 0};
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op[r] = (int)(w[r] & 0x33333333u);
-                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                v8i op2 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op2[r] = (int)((w[r] >> 2) & 0x33333333u);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op2, Bc, C[u][1], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                uint32_t hl[4];
-                v8i op3 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hl[r] = w[r] & (w[r] >> 1);
-                    op3[r] = (int)(hl[r] & 0x11111111u);
-                }
-                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op3, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                v8i op4 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op4[r] = (int)(hl[r] & 0x44444444u);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op4, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#else
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (full || u < n_my) {
@@ -304,7 +256,6 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
                 C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
             }
         }
-#endif
     };
 
     auto store_c = [&](uint32_t f, bool zero) {
@@ -984,12 +935,6 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                 case 10 * 1000 + 10 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 10, 10, 8, 3, true, 62>; break;
                 case 9 * 1000 + 10 * 100 + 9 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 9, 3, true, 62>; break;
                 case 9 * 1000 + 10 * 100 + 8 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 8, 4, true, 62>; break;
-#ifdef NPS_MX_INTERLEAVE
-                case 9 * 1000 + 11 * 100 + 9 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 9, 11, 9, 2, true, 62>; break;
-                case 9 * 1000 + 12 * 100 + 8 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 9, 12, 8, 2, true, 62>; break;
-                case 8 * 1000 + 12 * 100 + 9 * 10 + 2: fn = (const void *)fused_mx_kernel<0, false, 8, 12, 9, 2, true, 62>; break;
-                case 9 * 1000 + 11 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 9, 11, 8, 3, true, 62>; break;
-#endif
                 default: fprintf(stderr, "NPS_MX_SPLIT %s is not compiled in\n", sp); return hipErrorInvalidValue;
                 }
             }

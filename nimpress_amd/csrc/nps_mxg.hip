@@ -33,10 +33,8 @@ __device__ unsigned long long g_mxg_timers[8][8];
 #endif
 constexpr int kGW = 8;                                   // waves of a workgroup, all alike
 constexpr int kGU = 8;                                   // units per wave: 64 in all
-#ifndef NPS_MXG_TRANS
-#define NPS_MXG_TRANS 2   // units of a wave that are on their way through LDS at a time (8: all of them, see work())
-#endif
-constexpr uint32_t kGTransUnits = NPS_MXG_TRANS;
+constexpr uint32_t kGTransUnits = 2;                     // units of a wave on their way through LDS at a time (all eight at once,
+                                                         // writes first, then the transposed reads: 21.6-21.8 ms against 20.3-20.8)
 constexpr uint32_t kGTrans = 0;                          // [kGW][kGTransUnits][1 KiB]: the code image on its way to the transposed read
 constexpr uint32_t kGTab = kGW * kGTransUnits * 1024u;   // [2][3 operands][128 rows][16 bytes]
 constexpr uint32_t kGLdsBytes = kGTab + 2 * 6144u;
@@ -233,10 +231,8 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
         }
         auto one = [&](int u, bool refill) {
             char *const tp = trans + (u % (int)kGTransUnits) * 1024;
-            if (kGTransUnits < (uint32_t)NU) {
-                *reinterpret_cast<v4u *>(tp + woff) = b[u];
-                if (refill) b[u] = load_unit(k + kBanks, u);
-            }
+            *reinterpret_cast<v4u *>(tp + woff) = b[u];
+            if (refill) b[u] = load_unit(k + kBanks, u);
             const v2i t01 = tr4(tp + r1off), t23 = tr4(tp + r2off);
             const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
             v8i ce = {0, 0, 0, 0, 0, 0, 0, 0}, co = ce, me = ce, mo = ce;
@@ -252,21 +248,7 @@ static __device__ __forceinline__ void mxg_body(const MxgArgs &a, char *const sm
             C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(co, Bc, C[u][1], 4, 2, 0, 127, 0, 130);
             C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(me, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
             C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mo, Bmo, C[u][1], 4, 2, 0, 126, 0, 130);
-#ifdef NPS_MXG_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);  // (three banks: the operands of one unit alive at a time)
-#endif
         };
-        if (kGTransUnits >= (uint32_t)NU) {
-            // all of the wave's units go through LDS at once: the writes (and the refills behind them) first, then the
-            // transposed reads -- no write -> read round trip inside a unit's chain
-            const bool refill = k + kBanks < n_t;
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-                if (full || u < n_my) {
-                    *reinterpret_cast<v4u *>(trans + u * 1024 + woff) = b[u];
-                    if (refill) b[u] = load_unit(k + kBanks, u);
-                }
-        }
         if (k + kBanks < n_t) {
 #pragma unroll
             for (int u = 0; u < NU; ++u)
