@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, bool IL>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -234,6 +234,51 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             const v3i e0 = tr6(tab + 2048 + fr0), e1 = tr6(tab + 2048 + fr1);
             Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
             Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
+        }
+        if constexpr (IL) {
+        // IL: every MFMA of a unit is issued as soon as ITS operand exists (ce -> MFMA -> co -> MFMA -> me -> MFMA -> mo ->
+        // MFMA, the transposed reads of the NEXT unit under way during the whole unit) instead of the compiler's "24 vector
+        // instructions, then four MFMAs".  Not faster (profiles/r06_mx_variants.txt, part 2: vector and matrix issue of a SIMD do
+        // not overlap) but 30 registers lighter: what lets a data wave carry eleven or twelve units, i.e. the control waves
+        // carry NONE (round 6: the instantiations for cohorts whose step is the control waves' path).
+        v2i n01 = tr4(slot + r1off), n23 = tr4(slot + r2off);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (full || u < n_my) {
+                const v2i t01 = n01, t23 = n23;
+                if (u + 1 < NU && (full || u + 1 < n_my)) {
+                    n01 = tr4(slot + (u + 1) * 1024 + r1off);
+                    n23 = tr4(slot + (u + 1) * 1024 + r2off);
+                }
+                const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
+                v8i op = {0, 0, 0, 0, 0, 0, 0, 0};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op[r] = (int)(w[r] & 0x33333333u);
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                v8i op2 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op2[r] = (int)((w[r] >> 2) & 0x33333333u);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op2, Bc, C[u][1], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t hl[4];
+                v8i op3 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hl[r] = w[r] & (w[r] >> 1);
+                    op3[r] = (int)(hl[r] & 0x11111111u);
+                }
+                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op3, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+                v8i op4 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op4[r] = (int)(hl[r] & 0x44444444u);
+                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op4, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+            return;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -507,9 +552,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 //           against 9.7 ms), so the launcher picks by the plan.
 //   10 + 9 + 2, VS  strips of 62 units cut from the unit sequence instead of the layout's 64 (MxArgs.U): more strips, hence more
 //           compute units at work, and nineteen units instead of twenty on the two SIMDs that set the step.
-template <int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, int U = (VS ? 62 : 64)>
+template <int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, int U = (VS ? 62 : 64), bool IL = false>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
-    static_assert(kDW == 6 && 2 * UA + 2 * U2 + 2 * UB + 2 * UC == U && UC >= 1 && (VS || U == 64), "units of a strip");
+    static_assert(kDW == 6 && 2 * UA + 2 * U2 + 2 * UB + 2 * UC == U && UC >= 0 && (VS || U == 64), "units of a strip");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
@@ -521,25 +566,27 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
         // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units)
         const int uc0 = 2 * UA + 2 * U2 + 2 * UB + (wave - kDW) * UC;
-        if (nu - uc0 >= UC)
-            mx_body<UC, false, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+        // (UC == 0: control waves without units of their own -- the guarded body with room for one unit and none to take,
+        //  since the data waves' units already add up to the strip)
+        if (UC > 0 && nu - uc0 >= UC)
+            mx_body<(UC > 0 ? UC : 1), false, true, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
         else
-            mx_body<UC, true, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<(UC > 0 ? UC : 1), true, true, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
     } else if (wave < 2) {
         if (nu - wave * UA >= UA)
-            mx_body<UA, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<UA, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
         else
-            mx_body<UA, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<UA, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
     } else if (wave < 4) {
         if (nu - (2 * UA + (wave - 2) * U2) >= U2)
-            mx_body<U2, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<U2, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
         else
-            mx_body<U2, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<U2, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
     } else {
         if (nu - (2 * UA + 2 * U2 + (wave - 4) * UB) >= UB)
-            mx_body<UB, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<UB, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
         else
-            mx_body<UB, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
+            mx_body<UB, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
     }
 }
 
@@ -895,6 +942,11 @@ hipError_t launch_mx_prep(hipStream_t st, const nps_row_desc *d_desc, uint64_t n
     return hipGetLastError();
 }
 
+#ifndef NPS_MX_FEW_STRIPS
+#define NPS_MX_FEW_STRIPS 176
+#endif
+constexpr uint32_t kMxFewStrips = NPS_MX_FEW_STRIPS;  // layout strips up to which the 9|10|8|4 split is used (one row team)
+
 hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_units, uint64_t n_sb_cohort, uint64_t sb0,
                            uint64_t n_samples, uint64_t n_rows, const nps_row_desc *d_desc, DevParams prm,
                            int64_t t_maxmis, int F, void *d_pre, unsigned long long *d_tally,
@@ -910,7 +962,14 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
     const void *fn = nullptr;
     if (vstrips) {
         switch (plan.U) {
-        case 62: fn = (const void *)fused_mx_kernel<0, false, 10, 10, 9, 2, true, 62>; break;
+        // 10|10|9|2 where the strips fill the chip; with fewer strips (up to ~176 of the layout's: 360 000 samples) the step is
+        // the two data waves of SIMD 0 / 1 (nineteen units x ~300 cycles) while the control waves wait 1 600 cycles at the
+        // barrier (profiles/r06_mx_timers.txt, 300 000 samples): 9|10|8|4 moves two units per SIMD pair over to them
+        // (300 000 samples: 16.9 ms against 18.0-18.5; no gain from 400 000 on, profiles/r06_mx_variants.txt part 7)
+        case 62:
+            fn = plan.P <= kMxFewStrips ? (const void *)fused_mx_kernel<0, false, 9, 10, 8, 4, true, 62>
+                                        : (const void *)fused_mx_kernel<0, false, 10, 10, 9, 2, true, 62>;
+            break;
         default: return hipErrorInvalidValue;
         }
     } else {
@@ -935,6 +994,15 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                 case 10 * 1000 + 10 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 10, 10, 8, 3, true, 62>; break;
                 case 9 * 1000 + 10 * 100 + 9 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 9, 3, true, 62>; break;
                 case 9 * 1000 + 10 * 100 + 8 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 9, 10, 8, 4, true, 62>; break;
+                case 8 * 1000 + 10 * 100 + 8 * 10 + 5: fn = (const void *)fused_mx_kernel<0, false, 8, 10, 8, 5, true, 62>; break;
+                case 8 * 1000 + 10 * 100 + 9 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 8, 10, 9, 4, true, 62>; break;
+                case 7 * 1000 + 10 * 100 + 8 * 10 + 6: fn = (const void *)fused_mx_kernel<0, false, 7, 10, 8, 6, true, 62>; break;
+                case 8 * 1000 + 12 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 8, 12, 8, 3, true, 62, true>; break;
+                case 8 * 1000 + 11 * 100 + 8 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 8, 11, 8, 4, true, 62, true>; break;
+                case 10 * 1000 + 11 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 10, 11, 10, 0, true, 62, true>; break;
+                case 9 * 1000 + 12 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 9, 12, 10, 0, true, 62, true>; break;
+                case 10 * 1000 + 12 * 100 + 9 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 10, 12, 9, 0, true, 62, true>; break;
+                case 11 * 1000 + 10 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 11, 10, 10, 0, true, 62, true>; break;
                 default: fprintf(stderr, "NPS_MX_SPLIT %s is not compiled in\n", sp); return hipErrorInvalidValue;
                 }
             }
