@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void mx_prep_kernel(const nps_row_desc *__rest
 // Teams: workgroup b works for strip b % P in team b / P and walks the superblocks team, team + Q, ... of the run
 // (local index t <-> superblock team + t Q): whatever addresses memory uses the superblock, whatever alternates
 // between the two halves of a double buffer uses t.  The hand-over of a row involves the P strips of ONE team.
-template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, bool IL>
+template <int NU, bool GUARD, bool CTL, int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS>
 static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane >> 4, q = lane & 15;
@@ -234,51 +234,6 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
             const v3i e0 = tr6(tab + 2048 + fr0), e1 = tr6(tab + 2048 + fr1);
             Bc = v8i{c0[0], c0[1], c0[2], c1[0], c1[1], c1[2], 0, 0};
             Bme = v8i{e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], 0, 0};
-        }
-        if constexpr (IL) {
-        // IL: every MFMA of a unit is issued as soon as ITS operand exists (ce -> MFMA -> co -> MFMA -> me -> MFMA -> mo ->
-        // MFMA, the transposed reads of the NEXT unit under way during the whole unit) instead of the compiler's "24 vector
-        // instructions, then four MFMAs".  Not faster (profiles/r06_mx_variants.txt, part 2: vector and matrix issue of a SIMD do
-        // not overlap) but 30 registers lighter: what lets a data wave carry eleven or twelve units, i.e. the control waves
-        // carry NONE (round 6: the instantiations for cohorts whose step is the control waves' path).
-        v2i n01 = tr4(slot + r1off), n23 = tr4(slot + r2off);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (full || u < n_my) {
-                const v2i t01 = n01, t23 = n23;
-                if (u + 1 < NU && (full || u + 1 < n_my)) {
-                    n01 = tr4(slot + (u + 1) * 1024 + r1off);
-                    n23 = tr4(slot + (u + 1) * 1024 + r2off);
-                }
-                const uint32_t w[4] = {(uint32_t)t01[0], (uint32_t)t01[1], (uint32_t)t23[0], (uint32_t)t23[1]};
-                v8i op = {0, 0, 0, 0, 0, 0, 0, 0};
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op[r] = (int)(w[r] & 0x33333333u);
-                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op, Bc, C[u][0], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                v8i op2 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op2[r] = (int)((w[r] >> 2) & 0x33333333u);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op2, Bc, C[u][1], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                uint32_t hl[4];
-                v8i op3 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hl[r] = w[r] & (w[r] >> 1);
-                    op3[r] = (int)(hl[r] & 0x11111111u);
-                }
-                C[u][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op3, Bme, C[u][0], 4, 2, 0, 128, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-                v8i op4 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op4[r] = (int)(hl[r] & 0x44444444u);
-                C[u][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(op4, Bme, C[u][1], 4, 2, 0, 126, 0, 130);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-            return;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -552,9 +507,9 @@ static __device__ __forceinline__ void mx_body(const MxArgs &a, char *const smem
 //           against 9.7 ms), so the launcher picks by the plan.
 //   10 + 9 + 2, VS  strips of 62 units cut from the unit sequence instead of the layout's 64 (MxArgs.U): more strips, hence more
 //           compute units at work, and nineteen units instead of twenty on the two SIMDs that set the step.
-template <int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, int U = (VS ? 62 : 64), bool IL = false>
+template <int DBG, bool GIVEN, int UA, int U2, int UB, int UC, bool VS, int U = (VS ? 62 : 64)>
 __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(const MxArgs a) {
-    static_assert(kDW == 6 && 2 * UA + 2 * U2 + 2 * UB + 2 * UC == U && UC >= 0 && (VS || U == 64), "units of a strip");
+    static_assert(kDW == 6 && 2 * UA + 2 * U2 + 2 * UB + 2 * UC == U && UC >= 1 && (VS || U == 64), "units of a strip");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 slots][64 units][1 KiB] | tables | tallies
     const int wave = threadIdx.x >> 6;
     const int nu = blockIdx.x % a.P == a.P - 1 ? (int)a.nu_last : (VS ? (int)a.U : 64);
@@ -566,27 +521,25 @@ __global__ __launch_bounds__(kMxThreads, (kDW + 2) / 4) void fused_mx_kernel(con
         if (a.ctl_prio) __builtin_amdgcn_s_setprio(3);
         // (the unguarded body for every strip but a ragged last one: the guarded loops do not pipeline across units)
         const int uc0 = 2 * UA + 2 * U2 + 2 * UB + (wave - kDW) * UC;
-        // (UC == 0: control waves without units of their own -- the guarded body with room for one unit and none to take,
-        //  since the data waves' units already add up to the strip)
-        if (UC > 0 && nu - uc0 >= UC)
-            mx_body<(UC > 0 ? UC : 1), false, true, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+        if (nu - uc0 >= UC)
+            mx_body<UC, false, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<(UC > 0 ? UC : 1), true, true, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<UC, true, true, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     } else if (wave < 2) {
         if (nu - wave * UA >= UA)
-            mx_body<UA, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<UA, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<UA, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<UA, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     } else if (wave < 4) {
         if (nu - (2 * UA + (wave - 2) * U2) >= U2)
-            mx_body<U2, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<U2, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<U2, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<U2, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     } else {
         if (nu - (2 * UA + 2 * U2 + (wave - 4) * UB) >= UB)
-            mx_body<UB, false, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<UB, false, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
         else
-            mx_body<UB, true, false, DBG, GIVEN, UA, U2, UB, UC, VS, IL>(a, smem);
+            mx_body<UB, true, false, DBG, GIVEN, UA, U2, UB, UC, VS>(a, smem);
     }
 }
 
@@ -997,12 +950,6 @@ hipError_t launch_fused_mx(hipStream_t st, const MxPlan &plan, const void *d_uni
                 case 8 * 1000 + 10 * 100 + 8 * 10 + 5: fn = (const void *)fused_mx_kernel<0, false, 8, 10, 8, 5, true, 62>; break;
                 case 8 * 1000 + 10 * 100 + 9 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 8, 10, 9, 4, true, 62>; break;
                 case 7 * 1000 + 10 * 100 + 8 * 10 + 6: fn = (const void *)fused_mx_kernel<0, false, 7, 10, 8, 6, true, 62>; break;
-                case 8 * 1000 + 12 * 100 + 8 * 10 + 3: fn = (const void *)fused_mx_kernel<0, false, 8, 12, 8, 3, true, 62, true>; break;
-                case 8 * 1000 + 11 * 100 + 8 * 10 + 4: fn = (const void *)fused_mx_kernel<0, false, 8, 11, 8, 4, true, 62, true>; break;
-                case 10 * 1000 + 11 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 10, 11, 10, 0, true, 62, true>; break;
-                case 9 * 1000 + 12 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 9, 12, 10, 0, true, 62, true>; break;
-                case 10 * 1000 + 12 * 100 + 9 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 10, 12, 9, 0, true, 62, true>; break;
-                case 11 * 1000 + 10 * 100 + 10 * 10 + 0: fn = (const void *)fused_mx_kernel<0, false, 11, 10, 10, 0, true, 62, true>; break;
                 default: fprintf(stderr, "NPS_MX_SPLIT %s is not compiled in\n", sp); return hipErrorInvalidValue;
                 }
             }
