@@ -8,3 +8,5 @@ timeout -k 10 400 python3 -m pytest tests/test_gpu_mx.py -q -s > gpurun_out/r06_
 bash tools/profile_round.sh r06_ds --format ds --samples 200000 --variants 300000; echo "ds profile rc=$?"
 kill $PP
 tail -c 400 gpurun_out/prof_r06_ds/bench.json
+timeout -k 10 200 python3 tools/qb_harvest.py > gpurun_out/r06_harvest.txt 2>&1; tail -1 gpurun_out/r06_harvest.txt
+timeout -k 10 200 python3 tools/qb_harvest.py --samples 300000 >> gpurun_out/r06_harvest.txt 2>&1; tail -1 gpurun_out/r06_harvest.txt

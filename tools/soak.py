@@ -104,6 +104,14 @@ for j in range(2):   # reference per definition: the two-pass kernels
     refs.append([d.clone(), nl, None])
 if is_strip:
     ref_co.close()
+if a.mode == 0 and is_strip:
+    # NPS_MODE_AUTO may keep the tallies the FIRST pass counts and run every later pass with them given (round 6): two kernels
+    # whose locus constants are summed in different orders (last-bit differences).  One pass up front, so that every compared
+    # pass runs the kernel the steady state runs.
+    sc.reset()
+    sc.score_cohort_def(co, defs[0], 0, a.mode)
+    sc.finish_device(0.0, d.data_ptr())
+    print("auto: tallies kept after the first pass: %s" % co.has_tallies(), flush=True)
 for k in range(a.passes):
     j = k & 1
     sc.reset()
