@@ -259,7 +259,7 @@ void nps_destroy(nps_ctx *ctx);
  * compute units counts its tallies in the pass (tallyAlleles, nimpress.nim:563, inside the one read), every time.  Other
  * sizes keep the cohort's tallies with the cohort -- NPS_MODE_AUTO ATTACHES this cache to the `const nps_cohort` it is given
  * (dropped by any call that rewrites rows; nps_cohort_has_tallies tells) -- and score later runs with the tallies given:
- *   P x floor(CUs / P) < 0.9 CUs (e.g. 128 < P < 231: 262 145 .. 471 040 samples on an MI355X): the first whole-cohort run
+ *   128 < P < 0.9 CUs (262 145 .. 471 040 samples on an MI355X): the first whole-cohort run
  *     is the single read in which the tallies are counted anyway and keeps them as a by-product (round 6: ONE read, 0.51 of
  *     the roofline at 300 000 samples, 0.65 at 400 000; until then a tally pass + a given-tallies pass, two reads, 0.38);
  *     later runs 0.73-0.75;
@@ -425,7 +425,9 @@ int nps_cohort_keep_tallies(nps_cohort *c);
  * the first whole-cohort run under NPS_MODE_AUTO -- which counts the tallies in its one read anyway -- keeps them with the
  * cohort as a by-product (no extra read), and every later run scores with the tallies given (0.75-0.78 of the roofline
  * instead of 0.62-0.73).  Without the hint NPS_MODE_AUTO does this only where the single-read kernel's grid covers less
- * than nine tenths of the compute units (see NPS_FMT_GT_AUTO).  0 or 1: no such caching (the default). */
+ * than nine tenths of the compute units (see NPS_FMT_GT_AUTO).  0 or 1: no such caching (the default).  The hint is ignored
+ * where it would not pay: cohorts of at most 262 144 samples (several row teams per strip: the given-tallies kernel is no
+ * faster there than the pass that counts them). */
 int nps_cohort_expect_passes(nps_cohort *c, uint32_t n_passes);
 int nps_cohort_has_tallies(const nps_cohort *c); /* 1: the cohort carries whole-row tallies */
 

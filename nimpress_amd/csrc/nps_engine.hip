@@ -1693,7 +1693,11 @@ extern "C" int nps_score_cohort_def(nps_ctx *c, const nps_cohort *co, uint64_t c
             //  0.64-0.67 of the roofline and the same cohort with its tallies given at 0.73-0.75; until round 6, when keeping
             //  the tallies still cost a pass of its own, the line was drawn at seven tenths)
             const bool covers = p1.ok && !p1.given && (uint64_t)p1.P * p1.Q * 10 >= (uint64_t)cus * 9;
-            const bool want_kept = !covers || co->expect_passes.load(std::memory_order_relaxed) >= 2;
+            // (only where a strip has ONE row team -- more than 128 strips, 262 144 samples: with several teams per strip the
+            //  given-tallies kernel is no faster than the pass that counts them -- 250 000 samples 11.3 against 11.4 ms,
+            //  200 000 equal -- and slower below: 100 000 samples 5.05 against 4.27 ms, profiles/r06_harvest.txt)
+            const bool one_team = p1.ok && (p1.given || p1.Q == 1);
+            const bool want_kept = one_team && (!covers || co->expect_passes.load(std::memory_order_relaxed) >= 2);
             const bool whole = cohort_row0 == 0 && m == co->n_rows;
             if (p1.ok && want_kept) {
                 if (!p1.given && whole && m >= 1024) {

@@ -631,8 +631,22 @@ def test_expect_passes_keeps_the_tallies_of_the_first_pass():
     """nps_cohort_expect_passes (round 6): at a size whose resident grid covers the chip NPS_MODE_AUTO counts the tallies in
     every pass -- unless the caller says the cohort will be scored again: then the first whole-cohort pass keeps what it
     counted (no extra read) and later passes run with the tallies given.  The kept tallies are the oracle's; a run over
-    PART of the cohort keeps nothing."""
-    n, m = 70_000, 2000
+    PART of the cohort keeps nothing; and the hint is ignored where it would not pay (several row teams per strip: at most
+    262 144 samples -- the given-tallies kernel is no faster there than the pass that counts them)."""
+    small = capi.Cohort(70_000, 1500, fmt=capi.FMT_GT2X)
+    cs = make_cohort(70_000, 1500, 4321, np.random.default_rng(5))
+    small.synth(0, cs["seed"], cs["th"], cs["tm"], cs["tmi"])
+    small.expect_passes(8)
+    for _ in range(2):
+        sc = capi.Scorer(70_000, capi.make_params())
+        sc.profile_enable(True)
+        sc.score_cohort(small, capi.row_descs(cs["beta"], cs["eaf"], None, cs["rie"]), 0, capi.MODE_AUTO)
+        p = sc.profile_get(reset=True)
+        sc.finish(0.0)
+        sc.close()
+        assert p.n_fused >= 1 and p.n_accumulate == 0 and not small.has_tallies()
+    small.close()
+    n, m = 500_000, 2000
     rng = np.random.default_rng(77)
     co = make_cohort(n, m, 1234, rng)
     dev = capi.Cohort(n, m, fmt=capi.FMT_GT2X)
