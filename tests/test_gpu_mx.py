@@ -690,6 +690,48 @@ def test_expect_passes_keeps_the_tallies_of_the_first_pass():
     dev.close()
 
 
+def test_auto_keeps_tallies_with_a_banded_definition():
+    """A definition whose |beta| span needs magnitude bands (one pass per band, band 0 counts nloci and writes the statistics)
+    on a cohort size where NPS_MODE_AUTO keeps the first pass's tallies (280 000 samples: 137 strips): the tallies are taken
+    from band 0's pass, later runs score every band with them given; both agree with the explicit single-read mode."""
+    n, m = 280_000, 1536
+    rng = np.random.default_rng(1601)
+    eaf = np.round(rng.uniform(0.01, 0.5, m), 4)
+    miss = rng.uniform(0.0, 0.1, m)
+    miss[::7] = 0.3
+    beta = np.where(np.arange(m) % 2 == 0, rng.uniform(0.1, 1.0, m) * 10.0, rng.uniform(0.1, 1.0, m) * 1e-12)
+    th, tm, tmi = refcpu.hwe_thresholds(eaf, miss)
+    dev = capi.Cohort(n, m, fmt=capi.FMT_GT_AUTO)
+    dev.synth(0, 77, th, tm, tmi)
+    descs = capi.row_descs(beta, eaf)
+    kw = PARAM_GRID[0]
+    fused, nl_f, st_f = score_gt2x(dev, n, kw, descs, 0.0, mode=capi.MODE_FUSED)
+    assert not dev.has_tallies()
+    runs = []
+    for k in range(3):
+        sc = capi.Scorer(n, capi.make_params(**kw))
+        sc.profile_enable(True)
+        sc.score_cohort(dev, descs, 0, capi.MODE_AUTO)
+        p = sc.profile_get(reset=True)
+        stats = sc.flush()
+        scores, nloci = sc.finish(0.0)
+        sc.close()
+        assert dev.has_tallies()
+        assert (p.n_fused >= 2 and p.n_accumulate == 0) if k == 0 else (p.n_fused == 0 and p.n_accumulate >= 2)   # (two bands)
+        assert nloci == nl_f
+        for key in ("ngenotyped", "nmissing", "neffect", "used", "reason"):
+            assert np.array_equal(stats[key], st_f[key]), key
+        runs.append(scores)
+    assert np.array_equal(runs[0].view(np.int64), fused.view(np.int64))          # the same kernel, the same bits
+    ok = ~np.isnan(fused)
+    assert np.array_equal(np.isnan(runs[1]), ~ok) and np.array_equal(runs[1].view(np.int64), runs[2].view(np.int64))
+    rel = np.abs(runs[1][ok] - fused[ok]) / np.maximum(np.abs(fused[ok]), 1e-300)
+    assert rel.max() <= 1e-11, rel.max()
+    nm, ne = dev.row_tallies(0, m)
+    assert np.array_equal(nm, st_f["nmissing"].astype(nm.dtype)) and np.array_equal(ne.astype(np.float64), st_f["neffect"])
+    dev.close()
+
+
 def test_two_threads_score_one_auto_cohort():
     """two contexts on two threads score ONE cohort under NPS_MODE_AUTO at a size where the first run
     attaches kept tallies to the cohort (280 000 samples: 137 strips).  Whoever comes first counts and publishes them (an
