@@ -687,6 +687,15 @@ def test_expect_passes_keeps_the_tallies_of_the_first_pass():
     assert np.array_equal(np.isnan(again), np.isnan(first)) and np.allclose(again[ok], first[ok], rtol=1e-12, atol=1e-18)
     dev.synth(0, co["seed"] + 1, co["th"], co["tm"], co["tmi"])
     assert not dev.has_tallies()
+    # the rows were rewritten: the next pass counts and keeps the NEW rows' tallies, the one after runs with them given
+    co2 = dict(co, seed=co["seed"] + 1, codes=refcpu.synth_rows(n, 0, m, co["seed"] + 1, co["th"], co["tm"], co["tmi"]))
+    ref2_scores, ref2_stats, ref2_nloci = oracle_scores(co2, kw, 0.0)
+    for k in range(2):
+        p, stats, scores, nloci = run()
+        assert dev.has_tallies() and ((p.n_fused >= 1 and p.n_accumulate == 0) if k == 0 else (p.n_fused == 0 and p.n_accumulate >= 1))
+        assert nloci == ref2_nloci
+        assert_stats_equal(stats, [tuple(s) for s in ref2_stats])
+        check_scores(scores, ref2_scores, co["beta"], nloci)
     dev.close()
 
 
